@@ -1,0 +1,246 @@
+"""ViT tower specs and weight packing (host side, torch-CPU only — no device work here).
+
+The reference towers delegate the arithmetic to HuggingFace vision models
+(clip_encoder.py:24, dinov2_encoder.py:27, siglip_encoder.py:25).  The MI355X
+engine consumes ONE packed layout for all of them; this module converts HF
+`state_dict`s into it and can also synthesise weights with a version-stable
+PRNG (`numpy.random.RandomState`) when no checkpoint is available offline.
+
+Packed layout (fp32 torch tensors on CPU):
+  patch_w [d, 3*p*p]  patch_b [d]|None  cls [d]|None  pos [T, d]
+  pre_ln_g / pre_ln_b [d]|None
+  layers[i]: ln1_g ln1_b wqkv[3d,d] bqkv[3d] wo[d,d] bo[d] ls1[d]|None
+             ln2_g ln2_b w1[m,d] b1[m] w2[d,m] b2[d] ls2[d]|None
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class ViTSpec:
+    name: str
+    image_size: int
+    patch: int
+    d: int
+    layers: int
+    heads: int
+    mlp: int
+    act: str            # quick_gelu | gelu | gelu_tanh
+    eps: float
+    has_cls: bool
+    pre_ln: bool        # CLIP pre_layrnorm
+    patch_bias: bool
+    layerscale: bool    # DINOv2
+    family: str         # clip | dinov2 | siglip
+    pos_grid: int = 0   # native position-embedding grid (DINOv2: 37); 0 = image_size // patch
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch
+
+    @property
+    def num_patches(self) -> int:
+        return self.grid * self.grid
+
+    @property
+    def tokens(self) -> int:
+        return self.num_patches + (1 if self.has_cls else 0)
+
+    def at_resolution(self, image_size: int) -> "ViTSpec":
+        return replace(self, image_size=image_size)
+
+
+# Backbones behind the reference registry (llava_arch.py:29-40; shapes from the public HF configs)
+SPECS: Dict[str, ViTSpec] = {
+    "openai/clip-vit-large-patch14-336": ViTSpec("openai/clip-vit-large-patch14-336", 336, 14, 1024, 24, 16, 4096,
+                                                 "quick_gelu", 1e-5, True, True, False, False, "clip"),
+    "openai/clip-vit-large-patch14": ViTSpec("openai/clip-vit-large-patch14", 224, 14, 1024, 24, 16, 4096,
+                                             "quick_gelu", 1e-5, True, True, False, False, "clip"),
+    "laion/CLIP-ViT-L-14-laion2B-s32B-b82K": ViTSpec("laion/CLIP-ViT-L-14-laion2B-s32B-b82K", 224, 14, 1024, 24, 16,
+                                                     4096, "gelu", 1e-5, True, True, False, False, "clip"),
+    "facebook/dinov2-large": ViTSpec("facebook/dinov2-large", 224, 14, 1024, 24, 16, 4096,
+                                     "gelu", 1e-6, True, False, True, True, "dinov2", pos_grid=37),
+    "google/siglip-base-patch16-224": ViTSpec("google/siglip-base-patch16-224", 224, 16, 768, 12, 12, 3072,
+                                              "gelu_tanh", 1e-6, False, False, True, False, "siglip"),
+}
+
+
+def tiny_spec(family: str, act: Optional[str] = None, image_size: int = 28, patch: int = 7, d: int = 64,
+              layers: int = 3, heads: int = 2, mlp: int = 128) -> ViTSpec:
+    """Small spec of a given family for fixtures / tests."""
+    base = {"clip": SPECS["openai/clip-vit-large-patch14"], "dinov2": SPECS["facebook/dinov2-large"],
+            "siglip": SPECS["google/siglip-base-patch16-224"]}[family]
+    return replace(base, name=f"tiny-{family}", image_size=image_size, patch=patch, d=d, layers=layers,
+                   heads=heads, mlp=mlp, act=act or base.act, pos_grid=0)
+
+
+def spec_from_hf_config(cfg, name: str = "") -> ViTSpec:
+    """Build a spec from a HF CLIPVisionConfig / Dinov2Config / SiglipVisionConfig."""
+    mt = getattr(cfg, "model_type", "")
+    if hasattr(cfg, "vision_config") and mt in ("clip", "siglip"):
+        cfg = cfg.vision_config
+        mt = cfg.model_type
+    act = {"quick_gelu": "quick_gelu", "gelu": "gelu", "gelu_pytorch_tanh": "gelu_tanh", "gelu_new": "gelu_tanh",
+           "gelu_tanh": "gelu_tanh"}[getattr(cfg, "hidden_act", "gelu")]
+    if mt.startswith("clip"):
+        return ViTSpec(name, cfg.image_size, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                       cfg.num_attention_heads, cfg.intermediate_size, act, cfg.layer_norm_eps,
+                       True, True, False, False, "clip")
+    if mt.startswith("dinov2"):
+        return ViTSpec(name, cfg.image_size, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                       cfg.num_attention_heads, int(cfg.hidden_size * cfg.mlp_ratio), act, cfg.layer_norm_eps,
+                       True, False, True, True, "dinov2", pos_grid=cfg.image_size // cfg.patch_size)
+    if mt.startswith("siglip"):
+        return ViTSpec(name, cfg.image_size, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+                       cfg.num_attention_heads, cfg.intermediate_size, act, cfg.layer_norm_eps,
+                       False, False, True, False, "siglip")
+    raise ValueError(f"unsupported HF model_type {mt!r}")
+
+
+def _strip(sd: Dict[str, torch.Tensor], prefixes) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in sd.items():
+        for p in prefixes:
+            if k.startswith(p):
+                k = k[len(p):]
+                break
+        out[k] = v.detach().float().cpu()
+    return out
+
+
+def interpolate_pos(pos: torch.Tensor, has_cls: bool, grid: int) -> torch.Tensor:
+    """Bicubic position-embedding resize (HF Dinov2Embeddings.interpolate_pos_encoding, size= form, fp32)."""
+    cls = pos[:1] if has_cls else pos[:0]
+    patch = pos[1:] if has_cls else pos
+    n = int(round(patch.shape[0] ** 0.5))
+    if n == grid:
+        return pos
+    d = pos.shape[-1]
+    pp = patch.reshape(1, n, n, d).permute(0, 3, 1, 2).float()
+    pp = torch.nn.functional.interpolate(pp, size=(grid, grid), mode="bicubic", align_corners=False)
+    pp = pp.permute(0, 2, 3, 1).reshape(grid * grid, d)
+    return torch.cat([cls, pp], dim=0)
+
+
+def pack_hf_state_dict(sd: Dict[str, torch.Tensor], spec: ViTSpec) -> dict:
+    """HF CLIPVisionModel / Dinov2Model / SiglipVisionModel(.vision_model) state_dict -> packed layout."""
+    d = spec.d
+    if spec.family == "clip":
+        s = _strip(sd, ["vision_model."])
+        w = {
+            "patch_w": s["embeddings.patch_embedding.weight"].reshape(d, -1),
+            "patch_b": None,
+            "cls": s["embeddings.class_embedding"].reshape(d),
+            "pos": s["embeddings.position_embedding.weight"],
+            "pre_ln_g": s["pre_layrnorm.weight"], "pre_ln_b": s["pre_layrnorm.bias"],
+        }
+        lay = lambda i, k: s[f"encoder.layers.{i}.{k}"]
+        names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
+                     ln1="layer_norm1", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+    elif spec.family == "siglip":
+        s = _strip(sd, ["vision_model."])
+        w = {
+            "patch_w": s["embeddings.patch_embedding.weight"].reshape(d, -1),
+            "patch_b": s["embeddings.patch_embedding.bias"],
+            "cls": None,
+            "pos": s["embeddings.position_embedding.weight"],
+            "pre_ln_g": None, "pre_ln_b": None,
+        }
+        lay = lambda i, k: s[f"encoder.layers.{i}.{k}"]
+        names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
+                     ln1="layer_norm1", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+    elif spec.family == "dinov2":
+        s = _strip(sd, ["dinov2."])
+        w = {
+            "patch_w": s["embeddings.patch_embeddings.projection.weight"].reshape(d, -1),
+            "patch_b": s["embeddings.patch_embeddings.projection.bias"],
+            "cls": s["embeddings.cls_token"].reshape(d),
+            "pos": s["embeddings.position_embeddings"].reshape(-1, d),
+            "pre_ln_g": None, "pre_ln_b": None,
+        }
+        lay = lambda i, k: s[f"encoder.layer.{i}.{k}"]
+        names = dict(q="attention.attention.query", k="attention.attention.key", v="attention.attention.value",
+                     o="attention.output.dense", ln1="norm1", ln2="norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+    else:
+        raise ValueError(spec.family)
+    w["pos"] = interpolate_pos(w["pos"], spec.has_cls, spec.grid)
+    layers = []
+    for i in range(spec.layers):
+        L = {
+            "ln1_g": lay(i, names["ln1"] + ".weight"), "ln1_b": lay(i, names["ln1"] + ".bias"),
+            "wqkv": torch.cat([lay(i, names[c] + ".weight") for c in "qkv"], dim=0),
+            "bqkv": torch.cat([lay(i, names[c] + ".bias") for c in "qkv"], dim=0),
+            "wo": lay(i, names["o"] + ".weight"), "bo": lay(i, names["o"] + ".bias"),
+            "ln2_g": lay(i, names["ln2"] + ".weight"), "ln2_b": lay(i, names["ln2"] + ".bias"),
+            "w1": lay(i, names["fc1"] + ".weight"), "b1": lay(i, names["fc1"] + ".bias"),
+            "w2": lay(i, names["fc2"] + ".weight"), "b2": lay(i, names["fc2"] + ".bias"),
+            "ls1": None, "ls2": None,
+        }
+        if spec.layerscale:
+            L["ls1"] = lay(i, "layer_scale1.lambda1")
+            L["ls2"] = lay(i, "layer_scale2.lambda1")
+        layers.append(L)
+    w["layers"] = layers
+    return w
+
+
+def synthetic_weights(spec: ViTSpec, seed: int = 1, n_layers: Optional[int] = None) -> dict:
+    """Deterministic random-init weights (numpy RandomState: stream frozen across versions).
+
+    Scales are chosen so activations stay O(1) through 24 layers (std 0.02 matrices,
+    LN gains around 1, LayerScale around 0.1 for DINOv2-style towers).
+    """
+    rs = np.random.RandomState(seed)
+    d, m, p = spec.d, spec.mlp, spec.patch
+
+    def rn(*shape, std=0.02, mean=0.0):
+        return torch.from_numpy((rs.standard_normal(shape) * std + mean).astype(np.float32))
+
+    w = {
+        "patch_w": rn(d, 3 * p * p), "patch_b": rn(d) if spec.patch_bias else None,
+        "cls": rn(d) if spec.has_cls else None, "pos": rn(spec.tokens, d),
+        "pre_ln_g": rn(d, std=0.1, mean=1.0) if spec.pre_ln else None,
+        "pre_ln_b": rn(d) if spec.pre_ln else None,
+    }
+    layers = []
+    for _ in range(spec.layers if n_layers is None else n_layers):
+        layers.append({
+            "ln1_g": rn(d, std=0.1, mean=1.0), "ln1_b": rn(d),
+            "wqkv": rn(3 * d, d), "bqkv": rn(3 * d),
+            "wo": rn(d, d), "bo": rn(d),
+            "ls1": rn(d, std=0.02, mean=0.1) if spec.layerscale else None,
+            "ln2_g": rn(d, std=0.1, mean=1.0), "ln2_b": rn(d),
+            "w1": rn(m, d), "b1": rn(m), "w2": rn(d, m), "b2": rn(d),
+            "ls2": rn(d, std=0.02, mean=0.1) if spec.layerscale else None,
+        })
+    w["layers"] = layers
+    return w
+
+
+def flatten(w: dict) -> Dict[str, torch.Tensor]:
+    """Packed dict -> flat {name: tensor} (for npz fixtures)."""
+    out = {k: v for k, v in w.items() if k != "layers" and v is not None}
+    for i, L in enumerate(w["layers"]):
+        for k, v in L.items():
+            if v is not None:
+                out[f"layers.{i}.{k}"] = v
+    return out
+
+
+def unflatten(flat: Dict[str, torch.Tensor]) -> dict:
+    w: dict = {k: None for k in ("patch_b", "cls", "pre_ln_g", "pre_ln_b")}
+    layers: Dict[int, dict] = {}
+    for k, v in flat.items():
+        v = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
+        if k.startswith("layers."):
+            _, i, name = k.split(".", 2)
+            layers.setdefault(int(i), {"ls1": None, "ls2": None})[name] = v
+        else:
+            w[k] = v
+    w["layers"] = [layers[i] for i in sorted(layers)]
+    return w

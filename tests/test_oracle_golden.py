@@ -1,0 +1,105 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz, made by make_golden.py)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from law_of_vision_representation_in_mllms_amd import vit_weights as VW
+from oracle import ascore as OA
+from oracle import cscore as OC
+from oracle import projector as OP
+from oracle import vit as OV
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _case_names(z, suffix):
+    return sorted({k.split(".")[0] for k in z.files if k.endswith(suffix)})
+
+
+# --------------------------------------------------------------------------- A score
+@pytest.mark.parametrize("case", ["fp32_small", "fp32_wide", "bf16_inputs"])
+def test_ascore_matches_reference(case):
+    z = np.load(f"{G}/ascore.npz")
+    r336 = [torch.from_numpy(a) for a in z[f"{case}.clip336"]]
+    r224 = [torch.from_numpy(a) for a in z[f"{case}.clip224"]]
+    n = len(r336)
+    # the reference hard-codes 100 tensors; the fixture cycles n distinct images -> weights per image
+    reps = np.array([len(range(j, 100, n)) for j in range(n)], dtype=np.float64)
+    tol = 1e-6 if "fp32" in case else 1e-2     # bf16 case: reference did its arithmetic in bf16
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        oth = [torch.from_numpy(a) for a in z[f"{case}.{enc}"]]
+        s336 = np.array([OA.max_cos_mean(o, r) for o, r in zip(oth, r336)])
+        s224 = np.array([OA.max_cos_mean(o, r) for o, r in zip(oth, r224)])
+        got = ((s336 * reps).sum() / 100 + (s224 * reps).sum() / 100) / 2
+        want = float(z[f"{case}.result.{enc}"])
+        assert abs(got - want) <= tol * max(1.0, abs(want)), (enc, got, want)
+
+
+def test_ascore_self_similarity_is_one():
+    x = torch.randn(17, 40)
+    assert abs(OA.max_cos_mean(x, x) - 1.0) < 1e-6
+
+
+# --------------------------------------------------------------------------- C score
+def test_cscore_transfer_matches_reference():
+    z = np.load(f"{G}/cscore_transfer.npz")
+    for name in _case_names(z, ".xy"):
+        P, C, K, soft, win = z[f"{name}.meta"].tolist()
+        f1, f2 = torch.from_numpy(z[f"{name}.f1"]), torch.from_numpy(z[f"{name}.f2"])
+        kps = torch.from_numpy(z[f"{name}.kps"])
+        idx = OC.kpts_to_patch_idx(kps, P)
+        assert np.array_equal(idx, z[f"{name}.patch_idx"]), name
+        d1, d2 = OC.descriptors_from_map(f1, P), OC.descriptors_from_map(f2, P)
+        xy = OC.keypoint_transfer(d1, d2, idx, P, 840, bool(soft), win).numpy()
+        np.testing.assert_allclose(xy, z[f"{name}.xy"], rtol=0, atol=2e-3, err_msg=name)
+
+
+def test_cscore_pck_matches_reference():
+    z = np.load(f"{G}/cscore_pck.npz")
+    P, C = z["meta"].tolist()
+    per_cat, weights = [], []
+    for cat in ("catA", "catB"):
+        feats = z[f"{cat}.feats"]
+        fi = z[f"{cat}.file_img"]
+        kps = torch.from_numpy(z[f"{cat}.kps"])
+        thr = z[f"{cat}.thr"].tolist()
+        maps = [torch.from_numpy(feats[i]) for i in fi]
+        correct, img_correct, preds = OC.category_pck(maps, list(range(len(thr))), kps, thr, P)
+        np.testing.assert_allclose(correct, z[f"{cat}.correct"], atol=1e-6)
+        np.testing.assert_allclose(img_correct, z[f"{cat}.img_correct"], atol=1e-6)
+        K = kps.shape[1]
+        np.testing.assert_allclose(torch.stack(preds).numpy(), z[f"{cat}.pred"][:, :K], atol=2e-3)  # renumber_used_points pads to 30
+        per_cat.append(img_correct[:3])
+        weights.append(img_correct[3])
+    w = OC.weighted_pcks(per_cat, weights)
+    assert 0 <= w[2] <= w[1] <= w[0] <= 1
+
+
+# --------------------------------------------------------------------------- ViT towers
+@pytest.mark.parametrize("tag", ["clip_quick", "clip_gelu", "dinov2_native", "dinov2_interp", "siglip"])
+def test_vit_oracle_matches_hf(tag):
+    z = np.load(f"{G}/vit_tiny.npz")
+    spec = eval(str(z[f"{tag}.spec"]), {"ViTSpec": VW.ViTSpec})
+    flat = {k[len(tag) + 3:]: z[k] for k in z.files if k.startswith(f"{tag}.w.")}
+    w = VW.unflatten(flat)
+    px = torch.from_numpy(z[f"{tag}.pixels"])
+    sel = "cls_patch" if spec.family == "siglip" else "patch"
+    feat = OV.tower_features(spec, w, px, select_layer=-2, select_feature=sel)
+    want = torch.from_numpy(z[f"{tag}.feat"])
+    assert feat.shape == want.shape
+    err = (feat - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (tag, err)
+
+
+# --------------------------------------------------------------------------- projector
+def test_projector_oracle_matches_reference():
+    z = np.load(f"{G}/projector.npz")
+    x = torch.from_numpy(z["x"])
+    y = OP.mlp_gelu(x, [torch.from_numpy(z["w.0.weight"]), torch.from_numpy(z["w.2.weight"])],
+                    [torch.from_numpy(z["w.0.bias"]), torch.from_numpy(z["w.2.bias"])])
+    np.testing.assert_allclose(y.numpy(), z["y"], atol=1e-5)
+    yl = OP.mlp_gelu(x, [torch.from_numpy(z["wl.weight"])], [torch.from_numpy(z["wl.bias"])])
+    np.testing.assert_allclose(yl.numpy(), z["y_linear"], atol=1e-5)
