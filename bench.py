@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: CLIP ViT-L/14-336 vision-tower feature extraction (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (patch-embed -> pre-LN -> 23 encoder layers -> hidden_states[-2], CLS dropped) over
+one batch of 256 synthetic images per GPU, inputs already resident in HBM.  Images are independent units, so the path
+shards over ranks with no data-path collective (weak scaling); value = images of ALL ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the bf16 MFMA GEMM, fc1 shape): algorithmic FLOP per launch / its average launch
+                duration, timed with HIP events on the launch stream inside this run; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline  the CPU oracle (fp32 restatement of the reference's HF arithmetic, oracle/vit.py) on a bounded sample of
+                the same workload on this host's cores (rank 0, N=1 only).  Reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL = "openai/clip-vit-large-patch14-336"
+BATCH = 256
+N_LAYERS = 23                     # select_layer = -2: the 24th layer is never needed
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def flops_per_image(spec, n_layers):
+    T, d, m = spec.tokens, spec.d, spec.mlp
+    per_layer = 2 * T * d * 3 * d + 2 * T * d * d + 4 * T * T * d + 4 * T * d * m
+    patch = 2 * spec.num_patches * (3 * spec.patch ** 2) * d
+    return n_layers * per_layer + patch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the scoring path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # RCCL
+
+    from law_of_vision_representation_in_mllms_amd import _lib, engine
+    from law_of_vision_representation_in_mllms_amd import vit_weights as VW
+
+    spec = VW.SPECS[MODEL]
+    weights = VW.synthetic_weights(spec, seed=1, n_layers=N_LAYERS)      # same tower replica on every rank
+    eng = engine.VitEngine(spec, weights, dev)
+    B = args.batch
+    rs = np.random.RandomState(2 + rank)
+    px = torch.from_numpy(rs.standard_normal((B, 3, spec.image_size, spec.image_size)).astype(np.float32))
+    px = px.to(torch.bfloat16).to(dev)                                   # inputs resident in HBM before timing
+    out = torch.empty(B, spec.tokens, spec.d, dtype=torch.bfloat16, device=dev)
+
+    def step():
+        return eng.forward(px, n_layers=N_LAYERS, out=out)[:, 1:]        # feature_select 'patch' (clip_encoder.py:31-32)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        feats = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(feats.float()).all()
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    fl_img = flops_per_image(spec, N_LAYERS)
+
+    # ---- roofline of the dominant kernel, timed with HIP events on the launch stream
+    roof, kern = None, {}
+    if rank == 0:
+        M, d, m = B * spec.tokens, spec.d, spec.mlp
+        x = torch.randn(M, d, device=dev).to(torch.bfloat16)
+        hmlp = torch.randn(M, m, device=dev).to(torch.bfloat16)
+        L0 = weights["layers"][0]
+        w1 = L0["w1"].to(dev).to(torch.bfloat16)
+        w2 = L0["w2"].to(dev).to(torch.bfloat16)
+        wqk = L0["wqkv"][: 2 * d].to(dev).to(torch.bfloat16).contiguous()
+        wo = L0["wo"].to(dev).to(torch.bfloat16)
+        b1 = L0["b1"].to(dev)
+
+        def time_kernel(fn, reps=10):
+            fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / reps * 1e-3
+
+        o1 = torch.empty(M, m, dtype=torch.bfloat16, device=dev)
+        o2 = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+        oqk = torch.empty(M, 2 * d, dtype=torch.bfloat16, device=dev)
+        shapes = {
+            "fc1 (M x 4096 x 1024, bias+QuickGELU)": (lambda: engine.gemm(x, w1, b1, _lib.EPI_ACT, act="quick_gelu", out=o1), 2.0 * M * m * d),
+            "fc2 (M x 1024 x 4096, bias+residual)": (lambda: engine.gemm(hmlp, w2, None, _lib.EPI_RESID, resid=o2, out=o2), 2.0 * M * m * d),
+            "qk  (M x 2048 x 1024, bias)": (lambda: engine.gemm(x, wqk, None, _lib.EPI_BIAS, out=oqk), 2.0 * M * 2 * d * d),
+            "out (M x 1024 x 1024, bias+residual)": (lambda: engine.gemm(x, wo, None, _lib.EPI_RESID, resid=o2, out=o2), 2.0 * M * d * d),
+        }
+        for name, (fn, fl) in shapes.items():
+            sec = time_kernel(fn)
+            kern[name] = {"ms": round(sec * 1e3, 4), "tflops": round(fl / sec / 1e12, 1)}
+        # attention (its own kernel): 4*T*T*d flop per image per layer
+        qk_act = torch.randn(M, 2 * d, device=dev).to(torch.bfloat16)
+        vt = engine.linear_vt(x, wo, None)
+        sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, spec.tokens, spec.heads, 0.125))
+        kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1)}
+        top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_128<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"],
+                "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),
+                                  "frac": round(fl_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                  "gflop_per_image": round(fl_img / 1e9, 1)},
+                "kernels": kern}
+        del x, hmlp, o1, o2, oqk, qk_act, vt
+
+    # ---- CPU baseline: the oracle on a bounded sample, host cores of this box (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import vit as OV
+        n = args.cpu_images
+        torch.set_num_threads(os.cpu_count() or 1)
+        sample = px[:n].float().cpu()
+        OV.tower_features(spec, weights, sample[:1], select_layer=N_LAYERS)        # warm
+        c0 = time.perf_counter()
+        ref = OV.tower_features(spec, weights, sample, select_layer=N_LAYERS)
+        cdt = time.perf_counter() - c0
+        got = feats[:n].float().cpu()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        cpu = {"value": round(n / cdt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n} of the same 336x336 images, fp32, oracle/vit.py (torch CPU), 23 layers",
+               "gpu_vs_cpu_rel_l2": round(rel, 5)}
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec ViT-L/14@336 feature-extract", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CLIP ViT-L/14-336 vision_tower feature-extract (hidden_states[-2], 23 layers run), "
+                                   f"batch {B} per GPU, random-init weights, N(0,1) pixels resident in HBM",
+                       "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

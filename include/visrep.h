@@ -1,0 +1,109 @@
+/* libvisrep_hip.so — C ABI of the MI355X (gfx950) vision-representation scoring path.
+ *
+ * Drop-in boundary: the reference is pure Python on PyTorch; its hot path is a chain of stock
+ * PyTorch calls.  Each entry point below replaces one such call chain and is what a ctypes binding inside the
+ * reference would load.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor .data_ptr()) unless marked HOST
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is enqueued
+ *     asynchronously on it; nothing here synchronises, allocates or frees device memory
+ *   - return value 0 = ok, negative = error (VISREP_ERR_*); visrep_last_error() gives the message; no C++
+ *     exception crosses the boundary; no global mutable state besides the thread-local error string
+ *   - bf16 tensors are raw uint16 storage (torch.bfloat16), row-major, leading dimensions in ELEMENTS
+ */
+#ifndef VISREP_H
+#define VISREP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VISREP_VERSION 100
+
+enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
+enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
+/* GEMM epilogues */
+enum {
+    VISREP_EPI_BIAS = 0,   /* C = A W^T + bias                                   (nn.Linear)                    */
+    VISREP_EPI_ACT = 1,    /* C = act(A W^T + bias)                              (Linear + QuickGELU/GELU)      */
+    VISREP_EPI_RESID = 2,  /* C = resid + ls * (A W^T + bias)                    (Linear + LayerScale + add)    */
+    VISREP_EPI_VT = 3,     /* V^T scatter for visrep_mhsa_fwd (see below)                                        */
+    VISREP_EPI_PATCH = 4,  /* patch-embed: row remap past the CLS row + position add                             */
+    VISREP_EPI_F32 = 5     /* C(fp32) = A W^T + bias                                                             */
+};
+enum { VISREP_ACT_NONE = 0, VISREP_ACT_QUICK_GELU = 1, VISREP_ACT_GELU_ERF = 2, VISREP_ACT_GELU_TANH = 3 };
+
+int visrep_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+size_t visrep_last_error(char* buf, size_t n);
+
+/* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
+ * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from
+ * llava/model/multimodal_encoder/clip_encoder.py:48) and the mm_projector Sequential
+ * (llava/model/multimodal_projector/builder.py:40-47).
+ * A [M,K] bf16 (lda), W [N,K] bf16 (ldw, nn.Linear layout), bias [N] fp32 or NULL, C [M,N] bf16 (fp32 for EPI_F32).
+ * N % 128 == 0, K % 64 == 0.  resid (bf16, same shape/ld as C, may alias C) and ls (fp32 [N] or NULL) are used by
+ * EPI_RESID only. */
+int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
+                     int epilogue, int act, const void* resid, const float* ls, void* stream);
+
+/* ---- LayerNorm over the last dim (torch.nn.LayerNorm in the HF blocks; CLIP pre_layrnorm).  x,y bf16 [rows,d];
+ * gamma/beta fp32 [d]; fp32 statistics; y may alias x. */
+int visrep_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int rows, int d, float eps,
+                     void* stream);
+
+/* ---- multi-head self-attention forward (HF CLIPAttention / Dinov2SelfAttention / SiglipAttention: softmax(QK^T
+ * scale) V, fp32 softmax).  qk: [B*T, 2*H*64] bf16 (Q | K, head-major columns); vt: V^T as written by
+ * visrep_gemm_bf16(..., VISREP_EPI_VT): [H*64, ldvt] with ldvt >= round_up(B*T, 64), % 64 == 0, columns beyond B*T
+ * finite; out: [B*T, H*64] bf16.  head_dim must be 64. */
+int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo, int B, int T, int H, int head_dim,
+                    float scale, void* stream);
+
+/* ---- patch embedding pieces (HF CLIPVisionEmbeddings / Dinov2Embeddings / SiglipVisionEmbeddings) */
+int visrep_im2col(const void* pixels, int pixel_dtype, void* cols, int B, int Himg, int Wimg, int patch, int Kpad, void* stream);
+int visrep_cls_rows(void* x, int ldx, const float* cls, const float* pos, int B, int T, int d, void* stream);
+int visrep_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
+
+/* ---- composed tower forward: replaces `self.vision_tower(images, output_hidden_states=True).hidden_states[k]`
+ * (clip_encoder.py:48-49, dinov2_encoder.py:51-52, siglip_encoder.py:49-50). */
+typedef struct {
+    int image_size, patch, d, heads, mlp, layers, tokens, has_cls, pre_ln, act, kpad;
+    float eps;
+} visrep_vit_config;
+typedef struct {           /* device pointers; matrices bf16 [out,in], vectors fp32; ls1/ls2 NULL when no LayerScale */
+    const float *ln1_g, *ln1_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo; const float* ls1;
+    const float *ln2_g, *ln2_b; const void* w1; const float* b1; const void* w2; const float* b2; const float* ls2;
+} visrep_vit_layer;
+typedef struct {
+    const void* patch_w;   /* bf16 [d, kpad], zero padded past 3*p*p */
+    const float *patch_b, *cls, *pos, *pre_ln_g, *pre_ln_b;   /* patch_b / cls / pre_ln_* may be NULL */
+    const visrep_vit_layer* layers;   /* HOST array of `layers` entries */
+} visrep_vit_weights;
+size_t visrep_vit_workspace_bytes(const visrep_vit_config* cfg, int B);
+/* hidden: [B, tokens, d] bf16 — receives hidden_states[n_layers] (the residual stream lives in it). */
+int visrep_vit_forward(const visrep_vit_config* cfg, const visrep_vit_weights* w, const void* pixels, int pixel_dtype, void* hidden,
+                       int B, int n_layers, void* workspace, void* stream);
+
+/* ---- A score (A_score/compute.py:12-15,54-72): scores[img] = mean_t max_s cos(other[img][t], ref[img][s]).
+ * other [n_img,Nt,D], ref [n_img,Nr,D] contiguous, dtype VISREP_BF16 (D%16==0) or VISREP_F32 (D%8==0);
+ * scores fp32 [n_img]; workspace of visrep_ascore_workspace_bytes(). */
+size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr);
+int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, int dtype, float* scores,
+                         void* workspace, void* stream);
+
+/* ---- C score (C_score/utils/utils_correspondence.py:345-382 calculate_keypoint_transformation with get_flow,
+ * C_score/pck_train.py:24-29 normalize_feats): feats = bank of [C, P*P] fp32 maps; per pair image indices, source
+ * patch indices [n_pairs,kmax] (kmax <= 32), keypoint counts; lin = float32(np.linspace(-1,1,P)); xy [n_pairs,kmax,2]. */
+int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
+                           const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int window, int soft_eval, float beta,
+                           float anno_stride, float anno_half, void* stream);
+/* per-pair PCK hit counts (C_score/pck_train.py:101,149-163): kps1/kps2 [n_pairs,kmax,3] (x,y,vis) fp32, thresholds
+ * fp64 [n_pairs], alphas3 = HOST pointer to 3 floats; counts int32 [n_pairs,4] = hits@a0,a1,a2, n_visible. */
+int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp, int n_pairs,
+                     int kmax, const float* alphas3, int* counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

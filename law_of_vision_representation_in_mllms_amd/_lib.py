@@ -1,0 +1,105 @@
+"""ctypes binding of libvisrep_hip.so (the C ABI in include/visrep.h).
+
+There is NO CPU fallback: if the library cannot be loaded (or built with hipcc), every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libvisrep_hip.so")
+
+BF16, F32 = 0, 1
+EPI_BIAS, EPI_ACT, EPI_RESID, EPI_VT, EPI_PATCH, EPI_F32 = range(6)
+ACT = {"none": 0, "quick_gelu": 1, "gelu": 2, "gelu_erf": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3}
+
+
+class VitConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("image_size", "patch", "d", "heads", "mlp", "layers", "tokens", "has_cls", "pre_ln",
+                                       "act", "kpad")] + [("eps", C.c_float)]
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ls1", "ln2_g", "ln2_b", "w1", "b1",
+                                          "w2", "b2", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("patch_w", "patch_b", "cls", "pos", "pre_ln_g", "pre_ln_b")] + [
+        ("layers", C.POINTER(VitLayer))]
+
+
+# name -> (restype, argtypes); every symbol include/visrep.h declares
+_vp, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+SIGNATURES = {
+    "visrep_version": (_i, []),
+    "visrep_last_error": (_sz, [C.c_char_p, _sz]),
+    "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "visrep_im2col": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "visrep_cls_rows": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "visrep_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
+    "visrep_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
+    "visrep_vit_forward": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
+    "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "visrep_cscore_transfer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
+    "visrep_pck_count": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if needed and possible) the HIP library; raises RuntimeError when impossible."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH) and build_if_missing:
+            from . import build
+            build.build_lib()
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m law_of_vision_representation_in_mllms_amd.build` "
+                               "(there is no CPU fallback for the scoring path)")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(256)
+    load().visrep_last_error(buf, 256)
+    return buf.value.decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libvisrep_hip {what} failed (code {rc}): {last_error()}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible (torch.cuda.is_available() is False): the scoring path has no CPU fallback")
+    return load()
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())

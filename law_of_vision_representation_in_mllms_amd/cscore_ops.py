@@ -1,0 +1,58 @@
+"""Device entry points of the C score (visrep_cscore_transfer / visrep_pck_count).  See csrc/cscore.hip."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def lin_table(P: int, device) -> torch.Tensor:
+    # utils_correspondence.py:239-242: torch.tensor(np.linspace(-1, 1, P)).float()
+    return torch.tensor(np.linspace(-1, 1, P)).float().to(device)
+
+
+@torch.no_grad()
+def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_idx: torch.Tensor, nkp: torch.Tensor, P: int,
+             window: int = 5, soft_eval: bool = True, beta: float = 0.02, anno_size: int = 840) -> torch.Tensor:
+    """Keypoint transfer for a batch of pairs.
+
+    bank [n_images, C, P*P] fp32 (the reference's on-disk [1, C, P, P] maps, flattened); img1/img2/nkp int32 [n];
+    patch_idx int32 [n, kmax] (kmax <= 32).  Returns xy fp32 [n, kmax, 2] in the annotation frame.
+    """
+    lib = _lib.require_gpu()
+    if bank.dtype != torch.float32 or bank.dim() != 3 or bank.shape[2] != P * P:
+        raise ValueError("bank must be fp32 [n_images, C, P*P]")
+    bank = bank.contiguous()
+    n, kmax = patch_idx.shape
+    dev = bank.device
+    i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+    img1, img2, patch_idx, nkp = i32(img1), i32(img2), i32(patch_idx), i32(nkp)
+    xy = torch.zeros(n, kmax, 2, dtype=torch.float32, device=dev)
+    stride = anno_size / P
+    rc = lib.visrep_cscore_transfer(_lib.ptr(bank), _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(patch_idx), _lib.ptr(nkp),
+                                    _lib.ptr(lin_table(P, dev)), _lib.ptr(xy), n, kmax, P, bank.shape[1], int(window), int(soft_eval),
+                                    float(beta), float(stride), float(stride // 2), _lib.stream_ptr())
+    _lib.check(rc, "visrep_cscore_transfer")
+    return xy
+
+
+@torch.no_grad()
+def pck_counts(xy: torch.Tensor, kps1: torch.Tensor, kps2: torch.Tensor, thresholds: torch.Tensor, nkp: torch.Tensor,
+               alphas=(0.1, 0.05, 0.01)) -> torch.Tensor:
+    """counts int32 [n, 4] = hits@alpha0..2, n_visible (pck_train.py:101,149-163)."""
+    lib = _lib.require_gpu()
+    dev = xy.device
+    n, kmax, _ = xy.shape
+    kps1 = kps1.to(device=dev, dtype=torch.float32).contiguous()
+    kps2 = kps2.to(device=dev, dtype=torch.float32).contiguous()
+    thr = thresholds.to(device=dev, dtype=torch.float64).contiguous()
+    nkp = nkp.to(device=dev, dtype=torch.int32).contiguous()
+    counts = torch.zeros(n, 4, dtype=torch.int32, device=dev)
+    a = (C.c_float * 3)(*[float(np.float32(x)) for x in alphas])
+    rc = lib.visrep_pck_count(_lib.ptr(xy.contiguous()), _lib.ptr(kps1), _lib.ptr(kps2), _lib.ptr(thr), _lib.ptr(nkp), n, kmax, a,
+                              _lib.ptr(counts), _lib.stream_ptr())
+    _lib.check(rc, "visrep_pck_count")
+    return counts

@@ -1,0 +1,189 @@
+// A score on gfx950:  score[img] = mean_t max_s cos(other[img][t], ref[img][s])
+// (reference: A_score/compute.py:12-15 normalize_feat, :54-72 cosine_similarity -> max(dim=1) -> mean).
+//
+// The reference materialises an [Nt, Nr, D] broadcast product (5.4 GB at 576x576x4096); here the cross-Gram is an
+// MFMA contraction whose [Nt, Nr] result never leaves registers: per-row scale factors (the two normalisations of the
+// reference folded into one fp32 factor per row) are applied in the epilogue, the row max over s is taken in the
+// accumulator layout and only one partial sum per 64-row tile is written.
+//
+//   pass 1  ascore_row_scale : c(x) = 1/(|x|+1e-10) / max(|x|/(|x|+1e-10), 1e-8)   one wave per row, 16-B loads
+//   pass 2  ascore_maxcos    : "swapped" Gram  G^T = R O^T  (A operand = ref rows s, B operand = other rows t), so a
+//           lane owns ONE target row t = lane&31 and sees 16 s per MFMA tile -> max over s is in-lane + one lane^32
+//           exchange.  Operands are loaded straight from L2/HBM, 16 B per lane per row (K index = summation index:
+//           both operands use the same lane->k map, so any k permutation is legal):
+//             bf16 inputs: v_mfma_f32_32x32x16_bf16 (products exact in fp32, fp32 accumulate)
+//             fp32 inputs: 4 x v_mfma_f32_32x32x2_f32 per 16-B load (exact fp32 FMA chain)
+//   pass 3  ascore_finalize  : score[img] = sum(partials) / Nt   (fixed order -> deterministic)
+#include "common.h"
+#include "visrep_internal.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void ascore_row_scale(const T* __restrict__ x, long rows, int D, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * D;
+    float sq = 0.f;
+    if (sizeof(T) == 2) {
+        for (int c = lane * 8; c < D; c += 64 * 8) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float a = bf_lo(v[k]), b = bf_hi(v[k]); sq += a * a + b * b; }
+        }
+    } else {
+        for (int c = lane * 4; c < D; c += 64 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+        const float n = sqrtf(sq);
+        const float a = n + 1e-10f;                    // normalize_feat epsilon (compute.py:12-15)
+        scale[row] = (1.0f / a) / fmaxf(n / a, 1e-8f);   // F.cosine_similarity eps on the already-normalised row
+    }
+}
+
+struct AScoreArgs {
+    const void* other; const void* ref;
+    const float* c_other; const float* c_ref;
+    float* partial;
+    int n_img, Nt, Nr, D;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ascore_maxcos(const AScoreArgs p) {
+    __shared__ float red[4][32];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const int ntt = (p.Nt + 63) >> 6;
+    const int img = blockIdx.x / ntt, tt = blockIdx.x - img * ntt;
+    const int wt = wave & 1, ws = wave >> 1;
+    const T* other = reinterpret_cast<const T*>(p.other) + (size_t)img * p.Nt * p.D;
+    const T* ref = reinterpret_cast<const T*>(p.ref) + (size_t)img * p.Nr * p.D;
+    const float* cr = p.c_ref + (size_t)img * p.Nr;
+    const int t = tt * 64 + wt * 32 + lq;
+    const int tc = t < p.Nt ? t : p.Nt - 1;
+    constexpr int EPL = 16 / sizeof(T);                     // elements per 16-B load: 8 bf16 / 4 fp32
+    const T* trow = other + (size_t)tc * p.D + hi * EPL;
+    const int nst = (p.Nr + 63) >> 6;
+    float best = -INFINITY;
+    for (int st = ws; st < nst; st += 2) {
+        const int s_a = st * 64 + lq, s_b = s_a + 32;
+        const T* r0 = ref + (size_t)(s_a < p.Nr ? s_a : p.Nr - 1) * p.D + hi * EPL;
+        const T* r1 = ref + (size_t)(s_b < p.Nr ? s_b : p.Nr - 1) * p.D + hi * EPL;
+        f32x16 acc0 = f32x16{}, acc1 = f32x16{};
+        if (sizeof(T) == 2) {
+            int k = 0;
+            for (; k + 64 <= p.D; k += 64) {             // 12 independent 16-B loads in flight per lane
+                bf16x8 tb[4], a0[4], a1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    tb[u] = *reinterpret_cast<const bf16x8*>(trow + k + 16 * u);
+                    a0[u] = *reinterpret_cast<const bf16x8*>(r0 + k + 16 * u);
+                    a1[u] = *reinterpret_cast<const bf16x8*>(r1 + k + 16 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[u], tb[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[u], tb[u], acc1, 0, 0, 0);
+                }
+            }
+            for (; k < p.D; k += 16) {
+                const bf16x8 tb = *reinterpret_cast<const bf16x8*>(trow + k);
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(r0 + k);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(r1 + k);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, tb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, tb, acc1, 0, 0, 0);
+            }
+        } else {
+            auto step = [&](const float4& tb, const float4& a0, const float4& a1) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, tb.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, tb.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, tb.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, tb.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, tb.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, tb.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, tb.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, tb.w, acc1, 0, 0, 0);
+            };
+            int k = 0;
+            for (; k + 16 <= p.D; k += 16) {
+                const float4 tb0 = *reinterpret_cast<const float4*>(trow + k), tb1 = *reinterpret_cast<const float4*>(trow + k + 8);
+                const float4 a00 = *reinterpret_cast<const float4*>(r0 + k), a01 = *reinterpret_cast<const float4*>(r0 + k + 8);
+                const float4 a10 = *reinterpret_cast<const float4*>(r1 + k), a11 = *reinterpret_cast<const float4*>(r1 + k + 8);
+                step(tb0, a00, a10);
+                step(tb1, a01, a11);
+            }
+            for (; k < p.D; k += 8)
+                step(*reinterpret_cast<const float4*>(trow + k), *reinterpret_cast<const float4*>(r0 + k),
+                     *reinterpret_cast<const float4*>(r1 + k));
+        }
+        // lane holds G[s = st*64 + blk*32 + row(r,hi)][t]; scale by c_ref[s], mask s >= Nr, running max
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s0 = st * 64 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (s0 < p.Nr) best = fmaxf(best, acc0[r] * cr[s0]);
+            if (s0 + 32 < p.Nr) best = fmaxf(best, acc1[r] * cr[s0 + 32]);
+        }
+    }
+    best = fmaxf(best, __shfl_xor(best, 32));
+    if (hi == 0) red[wave][lq] = best;
+    __syncthreads();
+    if (wave < 2) {                                         // wave == wt here; combine the two s-halves, scale by c_other[t]
+        float v = 0.f;
+        if (hi == 0 && t < p.Nt) v = fmaxf(red[wave][lq], red[wave + 2][lq]) * p.c_other[(size_t)img * p.Nt + t];
+        v = wave_sum(v);
+        if (lane == 0) red[wave][0] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = red[0][0] + red[1][0];
+}
+
+__global__ void ascore_finalize(const float* __restrict__ partial, float* __restrict__ score, int n_img, int ntt, int Nt) {
+    const int img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= n_img) return;
+    float s = 0.f;
+    for (int i = 0; i < ntt; ++i) s += partial[img * ntt + i];
+    score[img] = s / (float)Nt;
+}
+
+template <typename T>
+int run(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, float* scores, float* ws, hipStream_t s) {
+    float* c_other = ws;
+    float* c_ref = c_other + (size_t)n_img * Nt;
+    float* partial = c_ref + (size_t)n_img * Nr;
+    const long ro = (long)n_img * Nt, rr = (long)n_img * Nr;
+    hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((ro + 3) / 4)), dim3(256), 0, s, (const T*)other, ro, D, c_other);
+    hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((rr + 3) / 4)), dim3(256), 0, s, (const T*)ref, rr, D, c_ref);
+    AScoreArgs a{other, ref, c_other, c_ref, partial, n_img, Nt, Nr, D};
+    const int ntt = (Nt + 63) / 64;
+    hipLaunchKernelGGL(ascore_maxcos<T>, dim3(n_img * ntt), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ascore_finalize, dim3((n_img + 63) / 64), dim3(64), 0, s, partial, scores, n_img, ntt, Nt);
+    return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr) {
+    return sizeof(float) * ((size_t)n_img * Nt + (size_t)n_img * Nr + (size_t)n_img * ((Nt + 63) / 64));
+}
+
+extern "C" int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, int dtype,
+                                    float* scores, void* workspace, void* stream) {
+    if (n_img <= 0) return 0;
+    if (Nt <= 0 || Nr <= 0 || D <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "ascore: empty tensor");
+    if (dtype == VISREP_BF16) {
+        if (D % 16) return visrep_set_error(VISREP_ERR_SHAPE, "ascore: bf16 path needs D % 16 == 0");
+        const int rc = run<bf16_t>(other, ref, n_img, Nt, Nr, D, scores, (float*)workspace, (hipStream_t)stream);
+        return rc ? visrep_set_error(rc, "ascore: launch failed") : 0;
+    }
+    if (dtype == VISREP_F32) {
+        if (D % 8) return visrep_set_error(VISREP_ERR_SHAPE, "ascore: fp32 path needs D % 8 == 0");
+        const int rc = run<float>(other, ref, n_img, Nt, Nr, D, scores, (float*)workspace, (hipStream_t)stream);
+        return rc ? visrep_set_error(rc, "ascore: launch failed") : 0;
+    }
+    return visrep_set_error(VISREP_ERR_ARG, "ascore: dtype must be VISREP_BF16 or VISREP_F32");
+}

@@ -1,0 +1,191 @@
+// Fused multi-head self-attention forward for ViT towers on gfx950 (head_dim 64, no mask, full softmax).
+//
+//   O[b, q, h, :] = softmax_k( Q[b,q,h,:] . K[b,k,h,:] * scale ) V[b,k,h,:]
+//
+// Layouts (produced by the QKV GEMM epilogues, gemm_bf16.hip):
+//   qk  : [M = B*T, 2*d] bf16 row-major, Q in columns [0,d), K in columns [d,2d), head h at h*64
+//   vt  : [d, ldvt] bf16, row n = h*64+dd, column perm16(m) over the GLOBAL token index m = b*T + t.
+//         perm16 swaps the two middle 4-token groups of every aligned 16-token block (0,2,1,3), so that the eight
+//         keys one lane needs for a 32x32x16 MFMA k-slice are 16 contiguous bytes (see below).
+//   out : [M, d] bf16 row-major (heads concatenated), feeds the out-projection GEMM.
+//
+// Design (flash style, online softmax, fp32 statistics):
+//   * block = 4 waves, 128 query rows of one (b, h); each wave owns 32 query rows
+//   * S^T = K Q^T is computed "swapped" with v_mfma_f32_32x32x16_bf16 (A = K tile from LDS, B = Q fragments held in
+//     registers for the whole kernel): lane l then holds, for ITS query q = l&31, sixteen keys per 32-key tile
+//     (row(r) = (r&3) + 8*(r>>2) + 4*(l>>5)).  Row max / sum need one cross-lane exchange (l ^ 32) only.
+//   * O^T += V^T P^T reuses the S^T registers directly as the B operand (bf16-packed in place): the MFMA k index is
+//     only a summation index, so any permutation applied to BOTH operands is legal; the lane's keys are
+//     {16c+4hi+0..3, 16c+8+4hi+0..3}, which perm16 makes contiguous in the V^T rows -> one ds_read_b128 per operand.
+//   * K / V^T tiles (64 keys) stream through a double-buffered, XOR-swizzled LDS ring filled by global_load_lds;
+//     key tiles are aligned to GLOBAL 64-token blocks, so no per-image padding exists anywhere: the first and last
+//     tile of an image are masked against [b*T, (b+1)*T).
+//   * blockIdx is XCD-remapped so the q-tiles of one (b,h) share an XCD L2 (K/V fetched from HBM once).
+#include "common.h"
+#include "visrep_internal.h"
+
+namespace {
+
+constexpr int KT = 64;                    // keys per tile
+constexpr int TILE_B = KT * 64 * 2;       // 8 KB (K tile or V^T tile)
+constexpr int STAGE_B = 2 * TILE_B;
+constexpr int ATT_LDS = 2 * STAGE_B;      // 32 KB
+
+struct AttnArgs {
+    const bf16_t* qk; const bf16_t* vt; bf16_t* out;
+    int B, T, H, M, ldqk, ldvt, ldo, d;
+    float sc;                              // softmax scale * log2(e)
+};
+
+__global__ __launch_bounds__(256) void attn_fwd_d64(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const int nqt = (p.T + 127) >> 7;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % p.H;
+    const int b = id / p.H;
+    const int tok0 = b * p.T, tok1 = tok0 + p.T;            // this image's global token range
+
+    // ---- Q fragments (B operand: col q = lane&31, k = d index 16*kk + 8*hi .. +8), kept in registers
+    const int qloc = qt * 128 + wave * 32 + lq;
+    const int qrow = tok0 + (qloc < p.T ? qloc : p.T - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8*>(p.qk + (size_t)qrow * p.ldqk + h * 64 + kk * 16 + hi * 8);
+
+    // ---- staging: 64 rows x 8 slots per tile = 2 chunks per thread per tile
+    const int srow = tid >> 3;
+    const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
+    const int m_begin = tok0 & ~63;
+    const int ntile = (((tok1 + 63) & ~63) - m_begin) >> 6;
+    const bf16_t* kbase = p.qk + p.d + h * 64 + lslot * 8;
+    const bf16_t* vbase = p.vt + (size_t)(h * 64 + srow) * p.ldvt + lslot * 8;
+    auto stage = [&](int buf, int it) {
+        char* sk = smem + buf * STAGE_B + wave * 1024;
+        char* sv = sk + TILE_B;
+        const int mt = m_begin + it * KT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int mk = mt + j * 32 + srow;
+            mk = mk < p.M ? mk : p.M - 1;                   // rows past the last token are masked below
+            glds16(kbase + (size_t)mk * p.ldqk, sk + j * 4096);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(vbase + (size_t)(j * 32) * p.ldvt + mt, sv + j * 4096);
+    };
+
+    // fragment read offsets inside a tile: row = 32*blk + lq, logical slot s -> physical s ^ ((lq>>1)&7)
+    const int rsw = (lq >> 1) & 7;
+    const int rbase = lq * 128;
+
+    f32x16 o[2];
+    o[0] = f32x16{}; o[1] = f32x16{};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < ntile) stage(cur ^ 1, it + 1);
+        const char* sk = smem + cur * STAGE_B;
+        const char* sv = sk + TILE_B;
+
+        // ---- S^T tiles: s[kt2] = K[kt2*32.., :] . Q^T
+        f32x16 s[2];
+        s[0] = f32x16{}; s[1] = f32x16{};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + kt2 * 4096 + rbase + (((2 * kk + hi) ^ rsw) << 4));
+                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt2], 0, 0, 0);
+            }
+        }
+        // ---- scale, mask (first / last tile only), running max
+        const int mt = m_begin + it * KT;
+        const bool edge = (mt < tok0) || (mt + KT > tok1);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kt2][r] * p.sc;
+                if (edge) {
+                    const int key = mt + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key < tok0 || key >= tok1) v = -INFINITY;
+                }
+                s[kt2][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);             // finite: every image's first tile holds >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        uint32_t pb[2][8];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kt2][r] - m_new);
+                const float p1 = __builtin_amdgcn_exp2f(s[kt2][r + 1] - m_new);
+                psum += p0 + p1;
+                pb[kt2][r >> 1] = pack_bf16(p0, p1);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+        // ---- O^T += V^T P^T : chunk c = 16 keys; P operand = 4 packed words of s[c>>1], regs 8*(c&1) .. +8
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 pf;
+            {
+                u32x4 w = {pb[c >> 1][4 * (c & 1) + 0], pb[c >> 1][4 * (c & 1) + 1], pb[c >> 1][4 * (c & 1) + 2], pb[c >> 1][4 * (c & 1) + 3]};
+                pf = *reinterpret_cast<bf16x8*>(&w);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + dt * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O[q][d = dt*32 + 8*rg + 4*hi + (0..3)]
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_run;
+    if (qloc < p.T) {
+        bf16_t* orow = p.out + (size_t)(tok0 + qloc) * p.ldo + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                u32x2 v = {pack_bf16(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv),
+                           pack_bf16(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + rg * 8 + hi * 4) = v;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo,
+                               int B, int T, int H, int head_dim, float scale, void* stream) {
+    if (head_dim != 64) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: only head_dim 64 is implemented");
+    if (B <= 0 || T <= 0 || H <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: empty problem");
+    if ((ldqk % 8) || (ldvt % 64) || (ldo % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: bad leading dimension");
+    const long M = (long)B * T;
+    if (ldvt < ((M + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: ldvt must cover round_up(B*T, 64)");
+    AttnArgs a;
+    a.qk = (const bf16_t*)qk; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
+    a.B = B; a.T = T; a.H = H; a.M = (int)M; a.ldqk = ldqk; a.ldvt = ldvt; a.ldo = ldo; a.d = H * 64;
+    a.sc = scale * 1.4426950408889634f;
+    const int nqt = (T + 127) / 128;
+    hipLaunchKernelGGL(attn_fwd_d64, dim3(nqt * H * B), dim3(256), ATT_LDS, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mhsa: launch failed");
+}

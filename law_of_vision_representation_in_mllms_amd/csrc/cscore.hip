@@ -1,0 +1,201 @@
+// C score on gfx950: dense-correspondence keypoint transfer + PCK counting for zero-shot SPair-71k evaluation.
+//
+// Reference path (C_score/): normalize_feats (pck_train.py:24-29) -> sim = D1 D2^T (utils_correspondence.py:360)
+// -> get_flow window soft-argmax (:297-337, :234-256) -> keypoint coordinates (:363-380) -> per-image PCK
+// (pck_train.py:149-163).  The reference builds the full [P^2, P^2] Gram and gathers K <= 30 keypoint rows; only
+// those K rows are computed here.
+//
+// cscore_transfer: one workgroup per image pair.
+//   phase A  rows[k][t] = sum_c F1[c][s_k] * F2[c][t]  with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain):
+//            A operand = gathered source columns (k = keypoint), B operand = target map rows, read straight from
+//            the [C, P^2] fp32 feature maps (128-B coalesced per half wave); squared norms of both operands are
+//            accumulated from the same registers, so normalisation costs no extra HBM pass.
+//            Each wave owns 32-target tiles; HBM traffic per pair = both maps once = 2 * P^2 * C * 4 B.
+//   phase B  per keypoint row (one wave each): first-index argmax, clamped (2w+1)^2 window, entries outside the
+//            window are ZERO (not -inf) and stay in the softmax (reference semantics), beta = 0.02,
+//            expectation over linspace(-1,1,P), un-normalise, clamp, scale to the annotation frame.
+// cscore_pck: per pair hit counts at the three alpha thresholds; the comparison is done in fp64 exactly as the
+//            reference's float32-alpha x float64-threshold promotion does.
+#include "common.h"
+#include "visrep_internal.h"
+
+namespace {
+
+struct CArgs {
+    const float* feats;            // feature bank [n_images][C][P*P] fp32
+    const int* img1; const int* img2;   // per pair image index into the bank
+    const int* patch_idx;          // [n_pairs][kmax] source patch index per keypoint
+    const int* nkp;                // [n_pairs] keypoints in this pair (<= 32)
+    const float* lin;              // [P] float32(np.linspace(-1, 1, P))
+    float* xy;                     // [n_pairs][kmax][2] (x, y) in the annotation frame
+    int n_pairs, kmax, P, C, window, soft;
+    float beta, stride, half;      // anno_size / P, floor(stride / 2)
+};
+
+__global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int PP = p.P * p.P;
+    float* rows = sm;                     // [32][PP]
+    float* n1s = sm + 32 * PP;            // [32]
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const int K = p.nkp[pair];
+    const size_t map_elems = (size_t)p.C * PP;
+    const float* F1 = p.feats + (size_t)p.img1[pair] * map_elems;
+    const float* F2 = p.feats + (size_t)p.img2[pair] * map_elems;
+    const int sk = (lq < K) ? p.patch_idx[(size_t)pair * p.kmax + lq] : 0;
+
+    // ---------------- phase A
+    const int ntile = (PP + 31) >> 5;
+    const float* a_ptr = F1 + (size_t)hi * PP + sk;
+    float n1 = 0.f;
+    bool first = true;
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int t = tile * 32 + lq;
+        const int tc = t < PP ? t : PP - 1;
+        const float* b_ptr = F2 + (size_t)hi * PP + tc;
+        f32x16 acc = f32x16{};
+        float n2 = 0.f;
+        int c = 0;
+        for (; c + 16 <= p.C; c += 16) {                 // 16 independent loads in flight per lane before the MFMA chain
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = a_ptr[(size_t)(c + 2 * u) * PP];
+                b[u] = b_ptr[(size_t)(c + 2 * u) * PP];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                n1 += a[u] * a[u];
+                n2 += b[u] * b[u];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            }
+        }
+        for (; c < p.C; c += 2) {
+            const float a = a_ptr[(size_t)c * PP];
+            const float b = b_ptr[(size_t)c * PP];
+            n1 += a * a;
+            n2 += b * b;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (first) {                                      // every tile re-reads the same source columns: keep the first sum
+            const float n1t = n1 + __shfl_xor(n1, 32);
+            if (wave == 0 && hi == 0) n1s[lq] = sqrtf(n1t) + 1e-10f;    // |d1[s_k]| + eps
+            first = false;
+        }
+        n2 += __shfl_xor(n2, 32);
+        const float inv2 = 1.0f / (sqrtf(n2) + 1e-10f);
+        // lane holds G[k = row(r,hi)][t]; the 1/n1 factor is applied in phase B (n1s may not be visible yet)
+        if (t < PP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rows[((r & 3) + 8 * (r >> 2) + 4 * hi) * PP + t] = acc[r] * inv2;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase B: one wave per keypoint row
+    const int w = p.window;
+    for (int k = wave; k < K; k += 4) {
+        const float inv1 = 1.0f / n1s[k];
+        float* row = rows + k * PP;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int t = lane; t < PP; t += 64) {
+            const float v = row[t] * inv1;
+            row[t] = v;
+            if (v > bv) { bv = v; bi = t; }                        // per lane t increases -> first index kept on ties
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        float ox, oy;
+        if (p.soft) {
+            const int mx = bi % p.P, my = bi / p.P;
+            int x0 = 0, x1 = p.P - 1, y0 = 0, y1 = p.P - 1;
+            if (w > 0) {
+                x0 = max(mx - w, 0); x1 = min(mx + w, p.P - 1);
+                y0 = max(my - w, 0); y1 = min(my + w, p.P - 1);
+            }
+            const bool has_out = (x1 - x0 + 1) * (y1 - y0 + 1) < PP;
+            const float Mx = has_out ? fmaxf(bv, 0.f) : bv;
+            float z = 0.f, ex = 0.f, ey = 0.f;
+            for (int t = lane; t < PP; t += 64) {
+                const int ty = t / p.P, tx = t - ty * p.P;
+                const bool in = tx >= x0 && tx <= x1 && ty >= y0 && ty <= y1;
+                const float v = in ? row[t] : 0.f;
+                const float e = expf((v - Mx) / p.beta);
+                z += e; ex += e * p.lin[tx]; ey += e * p.lin[ty];
+            }
+            z = wave_sum(z); ex = wave_sum(ex); ey = wave_sum(ey);
+            const float pm1 = (float)(p.P - 1);
+            float fx = (ex / z + 1.f) * pm1 / 2.0f;
+            float fy = (ey / z + 1.f) * pm1 / 2.0f;
+            ox = fminf(fmaxf(fx, 0.f), pm1);
+            oy = fminf(fmaxf(fy, 0.f), pm1);
+        } else {
+            ox = (float)(bi % p.P);
+            oy = (float)(bi / p.P);
+        }
+        if (lane == 0) {
+            float* o = p.xy + ((size_t)pair * p.kmax + k) * 2;
+            o[0] = ox * p.stride + p.half;
+            o[1] = oy * p.stride + p.half;
+        }
+    }
+}
+
+// per pair: vis = v1*v2 > 0 ; err = |gt - pred|_2 (fp32) ; hit[a] = err < alpha[a](fp32->fp64) * thr(fp64)
+__global__ void cscore_pck(const float* __restrict__ xy, const float* __restrict__ kps1, const float* __restrict__ kps2,
+                           const double* __restrict__ thr, const int* __restrict__ nkp, int n_pairs, int kmax, float a0,
+                           float a1, float a2, int* __restrict__ counts) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    const int K = nkp[pair];
+    const double th = thr[pair];
+    const double t0 = (double)a0 * th, t1 = (double)a1 * th, t2 = (double)a2 * th;
+    int c0 = 0, c1 = 0, c2 = 0, nv = 0;
+    for (int k = 0; k < K; ++k) {
+        const float* k1 = kps1 + ((size_t)pair * kmax + k) * 3;
+        const float* k2 = kps2 + ((size_t)pair * kmax + k) * 3;
+        if (k1[2] * k2[2] > 0.f) {
+            const float* pr = xy + ((size_t)pair * kmax + k) * 2;
+            const float dx = k2[0] - pr[0], dy = k2[1] - pr[1];
+            const float err = sqrtf(dx * dx + dy * dy);
+            ++nv;
+            c0 += (double)err < t0; c1 += (double)err < t1; c2 += (double)err < t2;
+        }
+    }
+    int* o = counts + (size_t)pair * 4;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = nv;
+}
+
+}  // namespace
+
+extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
+                                      const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int window, int soft_eval,
+                                      float beta, float anno_stride, float anno_half, void* stream) {
+    if (n_pairs <= 0) return 0;
+    if (kmax <= 0 || kmax > 32) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: kmax must be in 1..32");
+    if (P <= 0 || P > 32 || C <= 0 || (C & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: need 1 <= P <= 32 and even C");
+    CArgs a{feats, img1, img2, patch_idx, nkp, lin, xy, n_pairs, kmax, P, C, window, soft_eval, beta, anno_stride, anno_half};
+    const size_t lds = sizeof(float) * ((size_t)32 * P * P + 32);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(cscore_transfer, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "cscore_transfer: launch failed");
+}
+
+extern "C" int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp,
+                                int n_pairs, int kmax, const float* alphas3, int* counts, void* stream) {
+    if (n_pairs <= 0) return 0;
+    hipLaunchKernelGGL(cscore_pck, dim3((n_pairs + 127) / 128), dim3(128), 0, (hipStream_t)stream, xy, kps1, kps2, thresholds, nkp,
+                       n_pairs, kmax, alphas3[0], alphas3[1], alphas3[2], counts);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "pck_count: launch failed");
+}

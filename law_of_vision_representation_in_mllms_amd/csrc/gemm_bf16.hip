@@ -1,0 +1,189 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( A[M,K] * W[N,K]^T )   (nn.Linear layout: both operands K-contiguous)
+//
+// v1 structure ("one barrier per K-tile"):
+//   * 128x128 block tile, BK = 64, 256 threads = 4 waves in 2x2, each wave a 64x64 sub-tile = 4x4 MFMA 16x16x32 tiles
+//   * both operand tiles are staged HBM/L2 -> LDS with global_load_lds dwordx4 (no VGPR round trip), double-buffered:
+//     tile t+1 is issued before the MFMAs of tile t, one vmcnt(0)+barrier per K-tile
+//   * LDS rows are 128 B with the 16-B slot XOR-swizzled by (row>>1)&7 (common.h) -> conflict-free ds_read_b128
+//   * fused epilogues: bias / activation / LayerScale+residual / V-transpose scatter / patch-embed row remap + pos
+//   * blockIdx -> tile mapping is XCD-aware (consecutive tiles share an XCD L2)
+//
+// MFMA operand roles.  __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c): lane l supplies a = Arow[l&15][8*(l>>4)..+8],
+// b = Bcol[l&15][8*(l>>4)..+8]; result lane l holds D[row = 4*(l>>4)+r][col = l&15], r = 0..3.
+//   SWAP = true  (default): a = W fragment (row = n), b = X fragment (col = m)  -> lane holds C[m = l&15][n = 4g+r]:
+//                four consecutive n  -> one 8-byte bf16x4 store per fragment into row-major C.
+//   SWAP = false (V^T epilogue): a = X fragment, b = W fragment -> lane holds C[m = 4g+r][n = l&15]:
+//                four consecutive m -> one 8-byte store into the token-contiguous V^T layout.
+#include "common.h"
+#include "visrep_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 16 KB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + W
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // double buffer = 64 KB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = p.N / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int t = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+
+    // ---- staging addresses: 16-B chunk c = j*256 + tid, row = c>>3 = j*32 + (tid>>3), physical slot = tid&7
+    const int srow = tid >> 3;
+    const int lslot = (tid & 7) ^ ((srow >> 1) & 7);          // logical slot this lane must fetch (swizzle on the source)
+    const bf16_t* ga[4];
+    const bf16_t* gw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ra = m0 + j * 32 + srow;
+        ra = ra < p.M ? ra : p.M - 1;                          // clamp: rows past M are computed but never stored
+        ga[j] = p.A + (size_t)ra * p.lda + lslot * 8;
+        gw[j] = p.W + (size_t)(n0 + j * 32 + srow) * p.ldw + lslot * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * STAGE_BYTES + wave * 1024;
+        char* sw = sa + TILE_BYTES;
+        const int ko = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ga[j] + ko, sa + j * 4096);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(gw[j] + ko, sw + j * 4096);
+    };
+
+    // ---- fragment read offsets (bytes inside a tile); row = base16 + (lane&15), logical slot = kk*4 + (lane>>4)
+    const int fr = lane & 15, fg = lane >> 4;
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = fr * 128 + (((kk * 4 + fg) ^ ((fr >> 1) & 7)) << 4);
+    const int aoff = wm * 64 * 128, woff = TILE_BYTES + wn * 64 * 128;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 xa[4], xw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(sb + aoff + i * 2048 + foff[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xw[i] = *reinterpret_cast<const bf16x8*>(sb + woff + i * 2048 + foff[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (EPI == EPI_VT)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], xw[j], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[j], xa[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();   // waits the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+    }
+
+    // ------------------------------------------------------------------ epilogues
+    if (EPI == EPI_VT) {
+        // lane holds C[m = mb + 4*fg + r][n = nb + fr]; V^T layout: vt[n * ldc + perm16(m)], see attention.hip
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fr;
+            const float b = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + fg * 4;          // multiple of 4
+                if (m < p.M) {   // M is padded to a multiple of 4 by the caller's buffer (columns >= M are never read unmasked)
+                    const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-key groups 1 <-> 2
+                    u32x2 v = {pack_bf16(acc[i][j][0] + b, acc[i][j][1] + b), pack_bf16(acc[i][j][2] + b, acc[i][j][3] + b)};
+                    *reinterpret_cast<u32x2*>(p.C + (size_t)n * p.ldc + mp) = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+        size_t orow = (size_t)m;
+        const float* posrow = nullptr;
+        if (EPI == EPI_PATCH) {       // m = b*P + pidx  ->  token row b*T + cls_off + pidx ; add pos[cls_off + pidx]
+            const int b = m / p.patches, pi = m - b * p.patches;
+            orow = (size_t)b * p.tokens + p.cls_off + pi;
+            posrow = p.pos + (size_t)(p.cls_off + pi) * p.N;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+            }
+            if (EPI == EPI_ACT) {
+                v0 = apply_act(v0, p.act); v1 = apply_act(v1, p.act); v2 = apply_act(v2, p.act); v3 = apply_act(v3, p.act);
+            }
+            if (EPI == EPI_RESID) {
+                if (p.ls) {
+                    const float4 s = *reinterpret_cast<const float4*>(p.ls + n);
+                    v0 *= s.x; v1 *= s.y; v2 *= s.z; v3 *= s.w;
+                }
+                const u32x2 r = *reinterpret_cast<const u32x2*>(p.resid + orow * p.ldc + n);
+                v0 += bf_lo(r[0]); v1 += bf_hi(r[0]); v2 += bf_lo(r[1]); v3 += bf_hi(r[1]);
+            }
+            if (EPI == EPI_PATCH) {
+                const float4 s = *reinterpret_cast<const float4*>(posrow + n);
+                v0 += s.x; v1 += s.y; v2 += s.z; v3 += s.w;
+            }
+            if (EPI == EPI_F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = float4{v0, v1, v2, v3};
+            } else {
+                u32x2 o = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                *reinterpret_cast<u32x2*>(p.C + orow * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_128<EPI>, dim3(ntm * ntn), dim3(256), LDS_BYTES, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+}
+
+}  // namespace
+
+int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
+    if (a.N % BN != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N must be a multiple of 128 and K of 64");
+    if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
+    switch (a.epi) {
+        case EPI_BIAS: return launch<EPI_BIAS>(a, s);
+        case EPI_ACT: return launch<EPI_ACT>(a, s);
+        case EPI_RESID: return launch<EPI_RESID>(a, s);
+        case EPI_VT: return launch<EPI_VT>(a, s);
+        case EPI_PATCH: return launch<EPI_PATCH>(a, s);
+        case EPI_F32: return launch<EPI_F32>(a, s);
+    }
+    return visrep_set_error(VISREP_ERR_ARG, "gemm: unknown epilogue");
+}

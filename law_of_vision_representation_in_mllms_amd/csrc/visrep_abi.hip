@@ -1,0 +1,128 @@
+// C-ABI glue: error handling, the standalone GEMM entry point and the composed ViT tower forward.
+#include <string.h>
+
+#include "common.h"
+#include "visrep_internal.h"
+
+static thread_local char g_err[256] = "";
+
+int visrep_set_error(int code, const char* msg) {
+    strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+    return code;
+}
+
+extern "C" int visrep_version(void) { return VISREP_VERSION; }
+
+extern "C" size_t visrep_last_error(char* buf, size_t n) {
+    const size_t len = strlen(g_err);
+    if (buf && n) {
+        const size_t c = len < n - 1 ? len : n - 1;
+        memcpy(buf, g_err, c);
+        buf[c] = 0;
+    }
+    return len;
+}
+
+extern "C" int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                                int K, int epilogue, int act, const void* resid, const float* ls, void* stream) {
+    if (!A || !W || !C) return visrep_set_error(VISREP_ERR_ARG, "gemm: null pointer");
+    if (epilogue == VISREP_EPI_PATCH) return visrep_set_error(VISREP_ERR_ARG, "gemm: EPI_PATCH is internal to visrep_vit_forward");
+    if (epilogue == VISREP_EPI_RESID && !resid) return visrep_set_error(VISREP_ERR_ARG, "gemm: EPI_RESID needs resid");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias;
+    a.resid = (const bf16_t*)resid; a.ls = ls; a.pos = nullptr;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.epi = epilogue; a.act = act;
+    return visrep_gemm_dispatch(a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ ViT forward
+namespace {
+inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct Ws {
+    size_t h, qk, vt, mlp, total;
+    int ldvt;
+};
+Ws layout(const visrep_vit_config* c, int B) {
+    Ws w;
+    const size_t M = (size_t)B * c->tokens;
+    const size_t Mp = up(M, 128);
+    w.ldvt = (int)(up(M, 64) + 64);
+    size_t off = 0;
+    w.h = off;   off += up(Mp * c->d * 2, 256);
+    w.qk = off;  off += up(Mp * 2 * c->d * 2, 256);
+    w.vt = off;  off += up((size_t)c->d * w.ldvt * 2, 256);
+    const size_t mlp_b = Mp * c->mlp * 2;
+    const size_t cols_b = up((size_t)B * (c->tokens - c->has_cls), 128) * c->kpad * 2;
+    w.mlp = off; off += up(mlp_b > cols_b ? mlp_b : cols_b, 256);   // im2col columns alias the MLP buffer
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t visrep_vit_workspace_bytes(const visrep_vit_config* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return layout(cfg, B).total;
+}
+
+#define VR_TRY(x) do { const int rc_ = (x); if (rc_) return rc_; } while (0)
+
+extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_weights* w, const void* pixels, int pixel_dtype,
+                                  void* hidden, int B, int n_layers, void* workspace, void* stream) {
+    if (!c || !w || !pixels || !hidden || !workspace) return visrep_set_error(VISREP_ERR_ARG, "vit_forward: null pointer");
+    if (B <= 0) return 0;
+    if (n_layers < 0 || n_layers > c->layers) return visrep_set_error(VISREP_ERR_ARG, "vit_forward: n_layers out of range");
+    if (c->d != c->heads * 64) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward: head_dim must be 64");
+    if (c->d % 128 || c->mlp % 128 || c->kpad % 64) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward: d, mlp % 128 and kpad % 64 required");
+    const int grid = c->image_size / c->patch;
+    if (grid * grid + (c->has_cls ? 1 : 0) != c->tokens) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward: tokens != grid^2 + cls");
+    hipStream_t s = (hipStream_t)stream;
+    const Ws L = layout(c, B);
+    char* base = (char*)workspace;
+    bf16_t* x = (bf16_t*)hidden;
+    bf16_t* h = (bf16_t*)(base + L.h);
+    bf16_t* qk = (bf16_t*)(base + L.qk);
+    bf16_t* vt = (bf16_t*)(base + L.vt);
+    bf16_t* mlp = (bf16_t*)(base + L.mlp);
+    const int d = c->d, T = c->tokens, P = grid * grid, M = B * T;
+
+    // ---- embeddings: conv(k = s = patch) as im2col + GEMM with fused (bias, position add, CLS row skip)
+    VR_TRY(visrep_im2col(pixels, pixel_dtype, mlp, B, c->image_size, c->image_size, c->patch, c->kpad, stream));
+    GemmArgs g{};
+    g.A = mlp; g.lda = c->kpad; g.W = (const bf16_t*)w->patch_w; g.ldw = c->kpad; g.C = x; g.ldc = d;
+    g.bias = w->patch_b; g.pos = w->pos; g.M = B * P; g.N = d; g.K = c->kpad; g.epi = EPI_PATCH;
+    g.patches = P; g.tokens = T; g.cls_off = c->has_cls ? 1 : 0;
+    VR_TRY(visrep_gemm_dispatch(g, s));
+    if (c->has_cls) VR_TRY(visrep_cls_rows(x, d, w->cls, w->pos, B, T, d, stream));
+    if (c->pre_ln) VR_TRY(visrep_layernorm(x, d, w->pre_ln_g, w->pre_ln_b, x, d, M, d, c->eps, stream));
+
+    // V^T columns past B*T are read (with zero softmax weight) by the last key tile: keep them finite
+    if (hipMemsetAsync(vt, 0, (size_t)d * L.ldvt * 2, s) != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward: memset failed");
+
+    const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
+    for (int l = 0; l < n_layers; ++l) {
+        const visrep_vit_layer& W = w->layers[l];
+        VR_TRY(visrep_layernorm(x, d, W.ln1_g, W.ln1_b, h, d, M, d, c->eps, stream));
+        GemmArgs a{};
+        a.A = h; a.lda = d; a.K = d; a.M = M;
+        // Q | K projection
+        a.W = (const bf16_t*)W.wqkv; a.ldw = d; a.N = 2 * d; a.C = qk; a.ldc = 2 * d; a.bias = W.bqkv; a.epi = EPI_BIAS;
+        VR_TRY(visrep_gemm_dispatch(a, s));
+        // V projection written transposed + perm16 for the attention kernel
+        a.W = (const bf16_t*)W.wqkv + (size_t)2 * d * d; a.N = d; a.C = vt; a.ldc = L.ldvt; a.bias = W.bqkv + 2 * d; a.epi = EPI_VT;
+        VR_TRY(visrep_gemm_dispatch(a, s));
+        VR_TRY(visrep_mhsa_fwd(qk, 2 * d, vt, L.ldvt, h, d, B, T, c->heads, 64, scale, stream));
+        // out projection + LayerScale + residual (in place on x)
+        a.W = (const bf16_t*)W.wo; a.N = d; a.C = x; a.ldc = d; a.bias = W.bo; a.epi = EPI_RESID; a.resid = x; a.ls = W.ls1;
+        VR_TRY(visrep_gemm_dispatch(a, s));
+        VR_TRY(visrep_layernorm(x, d, W.ln2_g, W.ln2_b, h, d, M, d, c->eps, stream));
+        GemmArgs f{};
+        f.A = h; f.lda = d; f.K = d; f.M = M; f.W = (const bf16_t*)W.w1; f.ldw = d; f.N = c->mlp; f.C = mlp; f.ldc = c->mlp;
+        f.bias = W.b1; f.epi = EPI_ACT; f.act = c->act;
+        VR_TRY(visrep_gemm_dispatch(f, s));
+        f.A = mlp; f.lda = c->mlp; f.K = c->mlp; f.W = (const bf16_t*)W.w2; f.ldw = c->mlp; f.N = d; f.C = x; f.ldc = d;
+        f.bias = W.b2; f.epi = EPI_RESID; f.act = 0; f.resid = x; f.ls = W.ls2;
+        VR_TRY(visrep_gemm_dispatch(f, s));
+    }
+    return 0;
+}

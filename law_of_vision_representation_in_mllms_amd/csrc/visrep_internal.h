@@ -1,0 +1,26 @@
+// Internal (non-ABI) declarations shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/visrep.h"
+
+typedef unsigned short bf16_t;
+
+enum { EPI_BIAS = 0, EPI_ACT = 1, EPI_RESID = 2, EPI_VT = 3, EPI_PATCH = 4, EPI_F32 = 5 };
+
+struct GemmArgs {
+    const bf16_t* A;      // [M, K] row-major, leading dimension lda (elements)
+    const bf16_t* W;      // [N, K] row-major (nn.Linear weight), leading dimension ldw
+    bf16_t* C;            // output, leading dimension ldc (fp32 when epi == EPI_F32)
+    const float* bias;    // [N] or null
+    const bf16_t* resid;  // EPI_RESID: residual rows (may alias C)
+    const float* ls;      // EPI_RESID: optional LayerScale gamma [N]
+    const float* pos;     // EPI_PATCH: position embedding [tokens, N] fp32
+    int M, N, K, lda, ldw, ldc;
+    int epi, act;
+    int patches, tokens, cls_off;   // EPI_PATCH row remap
+};
+
+int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s);
+int visrep_set_error(int code, const char* msg);

@@ -1,0 +1,154 @@
+"""Device-side tower engine: packed ViT weights resident in HBM + the composed HIP forward (visrep_vit_forward).
+
+PyTorch is used for device memory and streams only; every FLOP of the forward runs in libvisrep_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .vit_weights import ViTSpec
+
+
+def _round_up(v: int, a: int) -> int:
+    return (v + a - 1) // a * a
+
+
+class VitEngine:
+    """One ViT tower on one GPU.
+
+    forward(pixels, n_layers) returns hidden_states[n_layers] as a bf16 tensor [B, tokens, d]
+    (index 0 = embeddings (+pre-LN for CLIP), index i = output of encoder layer i — the HF
+    `output_hidden_states=True` convention the reference towers index with `select_layer`).
+    """
+
+    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None):
+        self.lib = _lib.require_gpu()
+        self.spec = spec
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if spec.d != spec.heads * 64:
+            raise ValueError("HIP attention kernel supports head_dim 64 only")
+        if spec.d % 128 or spec.mlp % 128:
+            raise ValueError("d and mlp must be multiples of 128")
+        self.kpad = _round_up(3 * spec.patch * spec.patch, 64)
+        self._keep = []          # device tensors referenced by raw pointers
+        dev = self.device
+
+        def mat(t):              # bf16 [out, in]
+            x = t.detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+            self._keep.append(x)
+            return x
+
+        def vec(t):              # fp32 vector
+            if t is None:
+                return None
+            x = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(x)
+            return x
+
+        pw = torch.zeros(spec.d, self.kpad, dtype=torch.float32)
+        pw[:, : 3 * spec.patch * spec.patch] = weights["patch_w"].float()
+        if weights["pos"].shape[0] != spec.tokens:
+            raise ValueError(f"position embedding has {weights['pos'].shape[0]} rows, spec wants {spec.tokens}")
+        self._patch_w = mat(pw)
+        self._vecs = {k: vec(weights.get(k)) for k in ("patch_b", "cls", "pos", "pre_ln_g", "pre_ln_b")}
+        n = len(weights["layers"])
+        self.n_layers = n
+        self._layers = (_lib.VitLayer * max(n, 1))()
+        for i, L in enumerate(weights["layers"]):
+            ent = self._layers[i]
+            for k in ("wqkv", "wo", "w1", "w2"):
+                setattr(ent, k, mat(L[k]).data_ptr())
+            for k in ("ln1_g", "ln1_b", "bqkv", "bo", "ls1", "ln2_g", "ln2_b", "b1", "b2", "ls2"):
+                v = vec(L.get(k))
+                setattr(ent, k, 0 if v is None else v.data_ptr())
+        self._w = _lib.VitWeights()
+        self._w.patch_w = self._patch_w.data_ptr()
+        for k, v in self._vecs.items():
+            setattr(self._w, k, 0 if v is None else v.data_ptr())
+        self._w.layers = C.cast(self._layers, C.POINTER(_lib.VitLayer))
+        self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
+                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
+        self._ws: Dict[int, torch.Tensor] = {}
+
+    def workspace(self, B: int) -> torch.Tensor:
+        ws = self._ws.get(B)
+        if ws is None:
+            nbytes = self.lib.visrep_vit_workspace_bytes(C.byref(self._cfg), B)
+            self._ws.clear()             # keep one batch size resident
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[B] = ws
+        return ws
+
+    @torch.no_grad()
+    def forward(self, pixels: torch.Tensor, n_layers: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        s = self.spec
+        if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != s.image_size or pixels.shape[3] != s.image_size:
+            raise ValueError(f"Input image size {tuple(pixels.shape)} doesn't match tower ({s.image_size}*{s.image_size}).")
+        n_layers = self.n_layers if n_layers is None else n_layers
+        if not 0 <= n_layers <= self.n_layers:
+            raise ValueError("n_layers out of range")
+        px = pixels.to(self.device)
+        if px.dtype not in (torch.float32, torch.bfloat16):
+            px = px.float()
+        px = px.contiguous()
+        B = px.shape[0]
+        if out is None:
+            out = torch.empty(B, s.tokens, s.d, dtype=torch.bfloat16, device=self.device)
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            rc = self.lib.visrep_vit_forward(C.byref(self._cfg), C.byref(self._w), _lib.ptr(px),
+                                             _lib.F32 if px.dtype == torch.float32 else _lib.BF16,
+                                             _lib.ptr(out), B, n_layers, _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, "visrep_vit_forward")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ thin op wrappers
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS,
+         act: str = "none", resid: Optional[torch.Tensor] = None, ls: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(A @ W^T): A [M,K] bf16, W [N,K] bf16 (nn.Linear layout), fp32 bias/ls.  EPI_VT is exposed via linear_vt()."""
+    lib = _lib.require_gpu()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if epilogue == _lib.EPI_F32 else torch.bfloat16, device=a.device)
+    rc = lib.visrep_gemm_bf16(_lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(out), out.stride(0),
+                              M, N, K, epilogue, _lib.ACT[act], _lib.ptr(resid), _lib.ptr(ls), _lib.stream_ptr())
+    _lib.check(rc, "visrep_gemm_bf16")
+    return out
+
+
+def linear_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """V projection in the attention kernel's V^T layout: returns [N, ldvt] bf16 (see csrc/attention.hip)."""
+    lib = _lib.require_gpu()
+    M, K = a.shape
+    N = w.shape[0]
+    ldvt = _round_up(M, 64) + 64
+    vt = torch.zeros(N, ldvt, dtype=torch.bfloat16, device=a.device)
+    rc = lib.visrep_gemm_bf16(_lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(vt), ldvt, M, N, K,
+                              _lib.EPI_VT, 0, None, None, _lib.stream_ptr())
+    _lib.check(rc, "visrep_gemm_bf16(VT)")
+    return vt
+
+
+def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    y = torch.empty_like(x)
+    rc = lib.visrep_layernorm(_lib.ptr(x), x.stride(0), _lib.ptr(g), _lib.ptr(b), _lib.ptr(y), y.stride(0), x.shape[0], x.shape[1],
+                              eps, _lib.stream_ptr())
+    _lib.check(rc, "visrep_layernorm")
+    return y
+
+
+def mhsa(qk: torch.Tensor, vt: torch.Tensor, B: int, T: int, H: int, scale: float) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device=qk.device)
+    rc = lib.visrep_mhsa_fwd(_lib.ptr(qk), qk.stride(0), _lib.ptr(vt), vt.stride(0), _lib.ptr(out), out.stride(0), B, T, H, 64,
+                             scale, _lib.stream_ptr())
+    _lib.check(rc, "visrep_mhsa_fwd")
+    return out

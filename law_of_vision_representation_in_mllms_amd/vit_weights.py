@@ -244,3 +244,11 @@ def unflatten(flat: Dict[str, torch.Tensor]) -> dict:
             w[k] = v
     w["layers"] = [layers[i] for i in sorted(layers)]
     return w
+
+
+def weights_at_resolution(spec: ViTSpec, w: dict, image_size: int):
+    """Return (spec', w') for another input resolution: only the position embedding changes (bicubic resize)."""
+    spec2 = spec.at_resolution(image_size)
+    w2 = dict(w)
+    w2["pos"] = interpolate_pos(w["pos"], spec.has_cls, spec2.grid)
+    return spec2, w2

@@ -314,6 +314,93 @@ def gen_vit():
     print("vit_tiny.npz", [k for k in out if k.endswith(".feat")])
 
 
+# ----------------------------------------------------------------------------- ViT towers, HIP-runnable shapes
+def _hf_state_from_packed(spec, w, hf_sd):
+    """Inverse of VW.pack_hf_state_dict: write synthetic packed weights into an HF state_dict (test infra only)."""
+    d = spec.d
+    sd = {k: v.clone() for k, v in hf_sd.items()}
+    pre = "vision_model." if any(k.startswith("vision_model.") for k in sd) else ""
+    if spec.family in ("clip", "siglip"):
+        if spec.family == "clip":
+            sd[pre + "embeddings.class_embedding"] = w["cls"].clone()
+            sd[pre + "pre_layrnorm.weight"], sd[pre + "pre_layrnorm.bias"] = w["pre_ln_g"].clone(), w["pre_ln_b"].clone()
+        else:
+            sd[pre + "embeddings.patch_embedding.bias"] = w["patch_b"].clone()
+        sd[pre + "embeddings.patch_embedding.weight"] = w["patch_w"].reshape(d, 3, spec.patch, spec.patch).clone()
+        sd[pre + "embeddings.position_embedding.weight"] = w["pos"].clone()
+        lay = lambda i, k: pre + f"encoder.layers.{i}.{k}"
+        nm = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
+                  ln1="layer_norm1", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+    else:
+        sd["embeddings.cls_token"] = w["cls"].reshape(1, 1, d).clone()
+        sd["embeddings.position_embeddings"] = w["pos"].reshape(1, -1, d).clone()
+        sd["embeddings.patch_embeddings.projection.weight"] = w["patch_w"].reshape(d, 3, spec.patch, spec.patch).clone()
+        sd["embeddings.patch_embeddings.projection.bias"] = w["patch_b"].clone()
+        lay = lambda i, k: f"encoder.layer.{i}.{k}"
+        nm = dict(q="attention.attention.query", k="attention.attention.key", v="attention.attention.value",
+                  o="attention.output.dense", ln1="norm1", ln2="norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+    for i, L in enumerate(w["layers"]):
+        for j, c in enumerate("qkv"):
+            sd[lay(i, nm[c] + ".weight")] = L["wqkv"][j * d:(j + 1) * d].clone()
+            sd[lay(i, nm[c] + ".bias")] = L["bqkv"][j * d:(j + 1) * d].clone()
+        sd[lay(i, nm["o"] + ".weight")], sd[lay(i, nm["o"] + ".bias")] = L["wo"].clone(), L["bo"].clone()
+        sd[lay(i, nm["ln1"] + ".weight")], sd[lay(i, nm["ln1"] + ".bias")] = L["ln1_g"].clone(), L["ln1_b"].clone()
+        sd[lay(i, nm["ln2"] + ".weight")], sd[lay(i, nm["ln2"] + ".bias")] = L["ln2_g"].clone(), L["ln2_b"].clone()
+        sd[lay(i, nm["fc1"] + ".weight")], sd[lay(i, nm["fc1"] + ".bias")] = L["w1"].clone(), L["b1"].clone()
+        sd[lay(i, nm["fc2"] + ".weight")], sd[lay(i, nm["fc2"] + ".bias")] = L["w2"].clone(), L["b2"].clone()
+        if spec.layerscale:
+            sd[lay(i, "layer_scale1.lambda1")], sd[lay(i, "layer_scale2.lambda1")] = L["ls1"].clone(), L["ls2"].clone()
+    return sd
+
+
+def gen_vit_hip():
+    """head_dim 64 / d % 128 configs the HIP engine can run.  Weights are NOT stored: they are regenerated on the GPU box
+    by VW.synthetic_weights(spec, seed) (numpy RandomState, frozen stream); only pixels + reference features are."""
+    import transformers
+    from transformers import (CLIPVisionConfig, CLIPVisionModel, Dinov2Config, Dinov2Model,
+                              SiglipVisionConfig, SiglipVisionModel)
+    clip_mod = load_by_path("ref_clip_encoder", f"{REF}/llava/model/multimodal_encoder/clip_encoder.py")
+    dino_mod = load_by_path("ref_dinov2_encoder", f"{REF}/llava/model/multimodal_encoder/dinov2_encoder.py")
+    out = {"transformers_version": np.array(transformers.__version__)}
+    rs = np.random.RandomState(77)
+    kw = dict(hidden_size=128, num_hidden_layers=3, num_attention_heads=2)
+
+    def tower(cls, model, sel):
+        t = cls.__new__(cls)
+        torch.nn.Module.__init__(t)
+        t.is_loaded, t.vision_tower_name, t.select_layer, t.select_feature, t.vision_tower = True, "x", -2, sel, model
+        return t
+
+    cases = []
+    for tag, act in [("clip_quick", "quick_gelu"), ("clip_gelu", "gelu")]:
+        cfg = CLIPVisionConfig(intermediate_size=256, image_size=42, patch_size=14, hidden_act=act, layer_norm_eps=1e-5, **kw)
+        cases.append((tag, cfg, CLIPVisionModel, 42, 3))
+    dcfg = Dinov2Config(mlp_ratio=2, image_size=28, patch_size=14, hidden_act="gelu", layer_norm_eps=1e-6, **kw)
+    cases.append(("dinov2_native", dcfg, Dinov2Model, 28, 5))
+    cases.append(("dinov2_interp", dcfg, Dinov2Model, 56, 3))
+    scfg = SiglipVisionConfig(intermediate_size=256, image_size=64, patch_size=16, hidden_act="gelu_pytorch_tanh",
+                              layer_norm_eps=1e-6, **kw)
+    cases.append(("siglip", scfg, SiglipVisionModel, 64, 4))
+    for seed, (tag, cfg, Model, res, B) in enumerate(cases, start=100):
+        m = Model(cfg).eval()
+        base = VW.spec_from_hf_config(cfg, tag)
+        w = VW.synthetic_weights(base, seed)                    # native resolution weights
+        m.load_state_dict(_hf_state_from_packed(base, w, m.state_dict()))
+        px = torch.from_numpy(rs.standard_normal((B, 3, res, res)).astype(np.float32))
+        if tag.startswith("clip"):
+            feat = tower(clip_mod.CLIPVisionTower, m, "patch").forward(px)
+        elif tag.startswith("dinov2"):
+            feat = tower(dino_mod.DinoV2VisionTower, m, "patch").forward(px)
+        else:
+            feat = (m.vision_model if hasattr(m, "vision_model") else m)(px, output_hidden_states=True).hidden_states[-2]
+        out[f"{tag}.spec"] = np.array(repr(base))
+        out[f"{tag}.seed"] = np.int64(seed)
+        out[f"{tag}.res"] = np.int64(res)
+        out[f"{tag}.pixels"], out[f"{tag}.feat"] = px.numpy(), feat.numpy()
+    np.savez_compressed(f"{HERE}/vit_hip.npz", **out)
+    print("vit_hip.npz", [(k, out[k].shape) for k in out if k.endswith(".feat")])
+
+
 # ----------------------------------------------------------------------------- projector
 def gen_projector():
     ph = types.ModuleType("ref_proj.perceiver_helpers")
@@ -345,7 +432,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "projector"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "projector"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "projector": gen_projector}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "projector": gen_projector}[w]()

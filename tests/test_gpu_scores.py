@@ -1,0 +1,117 @@
+"""GPU parity tests of the A-score and C-score HIP kernels against the golden vectors and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from law_of_vision_representation_in_mllms_amd import ascore_ops, cscore_ops
+from oracle import ascore as OA
+from oracle import cscore as OC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------------------------------------ A score
+@pytest.mark.parametrize("case", ["fp32_small", "fp32_wide", "bf16_inputs"])
+def test_ascore_golden(case):
+    """Reference-produced results (A_score/compute.py exec'd); 1e-4 relative on fp32-upcast inputs."""
+    z = np.load(f"{G}/ascore.npz")
+    r336 = torch.from_numpy(z[f"{case}.clip336"]).to(DEV)
+    r224 = torch.from_numpy(z[f"{case}.clip224"]).to(DEV)
+    n = r336.shape[0]
+    reps = np.array([len(range(j, 100, n)) for j in range(n)], dtype=np.float64)
+    tol = 1e-4 if "fp32" in case else 1e-2        # bf16 case: the reference itself computed in bf16
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        oth = torch.from_numpy(z[f"{case}.{enc}"]).to(DEV)
+        s336 = ascore_ops.max_cos_mean(oth, r336).double().cpu().numpy()
+        s224 = ascore_ops.max_cos_mean(oth, r224).double().cpu().numpy()
+        got = ((s336 * reps).sum() / 100 + (s224 * reps).sum() / 100) / 2
+        want = float(z[f"{case}.result.{enc}"])
+        assert abs(got - want) <= tol * abs(want), (enc, got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Nt,Nr,D", [(576, 576, 4096), (196, 256, 4096), (256, 576, 1024), (70, 33, 256)])
+def test_ascore_vs_oracle(dtype, Nt, Nr, D):
+    g = torch.Generator().manual_seed(Nt * 7 + Nr)
+    n = 3
+    shared = torch.randn(n, 1, D, generator=g)
+    o = (torch.randn(n, Nt, D, generator=g) + 0.7 * shared).to(dtype)
+    r = (torch.randn(n, Nr, D, generator=g) + 0.7 * shared).to(dtype)
+    o[0, 3] = 0                                                       # zero row -> epsilon path
+    got = ascore_ops.max_cos_mean(o.to(DEV), r.to(DEV)).cpu()
+    want = torch.tensor([OA.max_cos_mean(o[i], r[i]) for i in range(n)])
+    assert ((got - want).abs() / want.abs()).max().item() < 1e-4
+
+
+def test_ascore_self_is_one():
+    x = torch.randn(2, 300, 512)
+    got = ascore_ops.max_cos_mean(x.to(DEV), x.to(DEV)).cpu()
+    assert (got - 1).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ C score
+def test_cscore_transfer_golden():
+    z = np.load(f"{G}/cscore_transfer.npz")
+    names = sorted({k.split(".")[0] for k in z.files if k.endswith(".xy")})
+    for name in names:
+        P, C, K, soft, win = z[f"{name}.meta"].tolist()
+        bank = torch.from_numpy(np.concatenate([z[f"{name}.f1"], z[f"{name}.f2"]], 0)).reshape(2, C, P * P).to(DEV)
+        idx = torch.from_numpy(z[f"{name}.patch_idx"].astype(np.int32))[None]
+        xy = cscore_ops.transfer(bank, torch.tensor([0]), torch.tensor([1]), idx, torch.tensor([K]), P, window=win,
+                                 soft_eval=bool(soft)).cpu().numpy()[0]
+        np.testing.assert_allclose(xy, z[f"{name}.xy"], rtol=0, atol=5e-3, err_msg=name)   # coordinates in a 840-px frame
+
+
+def test_cscore_pck_golden():
+    """compute_pck of the reference on a mini-SPair tree: per-image PCK must match exactly (counts are integers)."""
+    z = np.load(f"{G}/cscore_pck.npz")
+    P, C = z["meta"].tolist()
+    for cat in ("catA", "catB"):
+        feats = torch.from_numpy(z[f"{cat}.feats"]).reshape(-1, C, P * P).to(DEV)
+        fi = z[f"{cat}.file_img"]
+        kps = torch.from_numpy(z[f"{cat}.kps"])
+        thr = torch.from_numpy(z[f"{cat}.thr"])
+        N, K = len(thr), kps.shape[1]
+        idx = torch.from_numpy(np.stack([OC.kpts_to_patch_idx(kps[2 * i], P) for i in range(N)]).astype(np.int32))
+        nkp = torch.full((N,), K, dtype=torch.int32)
+        xy = cscore_ops.transfer(feats, torch.from_numpy(fi[0::2].copy()), torch.from_numpy(fi[1::2].copy()), idx, nkp, P)
+        np.testing.assert_allclose(xy.cpu().numpy(), z[f"{cat}.pred"][:, :K], atol=5e-3)
+        cnt = cscore_ops.pck_counts(xy, kps[0::2], kps[1::2], thr, nkp).cpu().numpy()
+        per_img = cnt[:, :3].astype(np.float32) / cnt[:, 3:4].astype(np.float32)
+        img_correct = per_img.mean(0)
+        np.testing.assert_allclose(img_correct, z[f"{cat}.img_correct"][:3], atol=1e-6)
+        kpt_correct = cnt[:, :3].sum(0) / cnt[:, 3].sum()
+        np.testing.assert_allclose(kpt_correct, z[f"{cat}.correct"][:3], atol=1e-6)
+        assert cnt[:, 3].sum() == int(z[f"{cat}.correct"][3])
+
+
+@pytest.mark.parametrize("P,C", [(16, 1024), (24, 1024), (14, 768), (32, 320)])
+def test_cscore_vs_oracle_full_width(P, C):
+    rs = np.random.RandomState(P * 100 + 1)
+    n_img, n_pairs, K = 6, 10, 20
+    bank = rs.standard_normal((n_img, C, P * P)).astype(np.float32)
+    bank[1:] = 0.5 * bank[:1] + 0.5 * bank[1:]
+    bank_t = torch.from_numpy(bank)
+    i1 = rs.randint(0, n_img, n_pairs).astype(np.int32)
+    i2 = rs.randint(0, n_img, n_pairs).astype(np.int32)
+    kps = np.ones((n_pairs, K, 3), np.float32)
+    kps[:, :, :2] = rs.uniform(0, 839.9, (n_pairs, K, 2))
+    nkp = rs.randint(3, K + 1, n_pairs).astype(np.int32)
+    idx = np.stack([OC.kpts_to_patch_idx(torch.from_numpy(kps[i]), P) for i in range(n_pairs)]).astype(np.int32)
+    xy = cscore_ops.transfer(bank_t.to(DEV), torch.from_numpy(i1), torch.from_numpy(i2), torch.from_numpy(idx), torch.from_numpy(nkp), P)
+    xy = xy.cpu()
+    for i in range(n_pairs):
+        d1 = OC.descriptors_from_map(bank_t[i1[i]].view(1, C, P, P), P)
+        d2 = OC.descriptors_from_map(bank_t[i2[i]].view(1, C, P, P), P)
+        want = OC.keypoint_transfer(d1, d2, idx[i][: nkp[i]], P)
+        assert (xy[i, : nkp[i]] - want).abs().max().item() < 2e-2, i
+
+
+def test_cscore_rejects_too_many_keypoints():
+    bank = torch.zeros(2, 8, 16, device=DEV)
+    with pytest.raises(RuntimeError, match="kmax"):
+        cscore_ops.transfer(bank, torch.tensor([0]), torch.tensor([1]), torch.zeros(1, 40, dtype=torch.int32), torch.tensor([40]), 4)

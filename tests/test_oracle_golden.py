@@ -103,3 +103,24 @@ def test_projector_oracle_matches_reference():
     np.testing.assert_allclose(y.numpy(), z["y"], atol=1e-5)
     yl = OP.mlp_gelu(x, [torch.from_numpy(z["wl.weight"])], [torch.from_numpy(z["wl.bias"])])
     np.testing.assert_allclose(yl.numpy(), z["y_linear"], atol=1e-5)
+
+
+def load_vit_hip_case(tag):
+    """(spec, weights, pixels, reference features) of a HIP-runnable golden case; weights regenerated from the seed."""
+    z = np.load(f"{G}/vit_hip.npz")
+    base = eval(str(z[f"{tag}.spec"]), {"ViTSpec": VW.ViTSpec})
+    w = VW.synthetic_weights(base, int(z[f"{tag}.seed"]))
+    spec, w = VW.weights_at_resolution(base, w, int(z[f"{tag}.res"]))
+    return spec, w, torch.from_numpy(z[f"{tag}.pixels"]), torch.from_numpy(z[f"{tag}.feat"])
+
+
+VIT_HIP_TAGS = ["clip_quick", "clip_gelu", "dinov2_native", "dinov2_interp", "siglip"]
+
+
+@pytest.mark.parametrize("tag", VIT_HIP_TAGS)
+def test_vit_oracle_matches_hf_hip_shapes(tag):
+    spec, w, px, want = load_vit_hip_case(tag)
+    sel = "cls_patch" if spec.family == "siglip" else "patch"
+    feat = OV.tower_features(spec, w, px, select_layer=-2, select_feature=sel)
+    assert feat.shape == want.shape
+    assert (feat - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
