@@ -1,0 +1,122 @@
+"""A score on MI355X — drop-in for A_score/compute.py.
+
+Same module-level names (base_folder, subfolders, normalize_feat, load_tensors, results) and the same printed lines
+(compute.py:84-85).  The reference is a script; importing this module does nothing until `main()` / `compute()` runs, and
+`python -m law_of_vision_representation_in_mllms_amd.A_score.compute --base-folder DIR` reproduces the script behaviour.
+
+Arithmetic: per image mean_t max_s cos(other[t], ref[s]) for ref in {clip336, clip224} (compute.py:54-72) in ONE fused
+HIP kernel per (encoder, reference) over all images (csrc/ascore.hip) — the [Nt, Nr, D] broadcast product of the
+reference is never formed; then python-float means exactly as compute.py:75-81.
+With torch.distributed initialised, images are sharded over ranks and the per-encoder sums are all-reduced (RCCL).
+"""
+import argparse
+import os
+
+import torch
+
+# The benchmark of which A score you want to compute (compute.py:7)
+base_folder = '/any/path/mmbench'
+# The subfolders for features (compute.py:10)
+subfolders = ['clip336', 'clip224', 'dino', 'dit', 'imsd', 'openclip', 'sd1.5', 'sd2.1', 'sd3', 'sdxl']
+results = {}
+
+
+def normalize_feat(feat, epsilon=1e-10):
+    # compute.py:12-15 (kept for API parity; the HIP kernel folds this normalisation into its row scale)
+    norms = torch.linalg.norm(feat, dim=-1, keepdim=True)
+    return feat / (norms + epsilon)
+
+
+def load_tensors(subfolder, n=100):
+    # compute.py:18-28: tensor_1.pt .. tensor_100.pt; any error -> message + empty list (encoder skipped by the caller)
+    tensors = []
+    for i in range(1, n + 1):
+        tensor_path = os.path.join(base_folder, subfolder, f"tensor_{i}.pt")
+        try:
+            tensors.append(torch.load(tensor_path, map_location="cpu"))
+        except Exception as e:
+            print(f"Error loading {tensor_path}: {e}")
+            return []
+    return tensors
+
+
+def _shard(n, rank, world):
+    return list(range(rank, n, world))
+
+
+def _stack(tensors, idx, device):
+    """Images of one encoder share a token count -> one [n, N, D] batch; otherwise group by shape."""
+    groups = {}
+    for i in idx:
+        groups.setdefault(tuple(tensors[i].shape), []).append(i)
+    for shape, ids in groups.items():
+        yield ids, torch.stack([tensors[i] for i in ids]).to(device)
+
+
+def per_image_scores(other_tensors, ref_tensors, idx, device="cuda"):
+    """[(image index, mean_t max_s cos)] for the images in idx (compute.py:54-72 for one reference)."""
+    from .. import ascore_ops
+    out = {}
+    by_other = {}
+    for i in idx:
+        by_other.setdefault((tuple(other_tensors[i].shape), tuple(ref_tensors[i].shape)), []).append(i)
+    for _, ids in by_other.items():
+        o = torch.stack([other_tensors[i].reshape(-1, other_tensors[i].shape[-1]) for i in ids]).to(device)
+        r = torch.stack([ref_tensors[i].reshape(-1, ref_tensors[i].shape[-1]) for i in ids]).to(device)
+        s = ascore_ops.max_cos_mean(o, r).double().cpu()
+        for j, i in enumerate(ids):
+            out[i] = float(s[j])
+    return out
+
+
+def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True):
+    """Returns {subfolder: A score}; mirrors the main loop compute.py:30-85."""
+    global base_folder, results
+    if base is not None:
+        base_folder = base
+    subs = subfolders if subs is None else subs
+    dist = torch.distributed if torch.distributed.is_available() and torch.distributed.is_initialized() else None
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+
+    clip336_tensors = load_tensors('clip336', n_images)
+    clip224_tensors = load_tensors('clip224', n_images)
+    if not clip336_tensors or not clip224_tensors:
+        raise ValueError("Failed to load tensors from 'clip336' or 'clip224' subfolder")
+
+    results = {}
+    for subfolder in subs:
+        other_tensors = load_tensors(subfolder, n_images)
+        if not other_tensors:
+            print(f"Skipping {subfolder} due to loading error.")
+            continue
+        n = min(len(clip336_tensors), len(clip224_tensors), len(other_tensors))       # zip() semantics, compute.py:51
+        idx = _shard(n, rank, world)
+        s336 = per_image_scores(other_tensors, clip336_tensors, idx, device)
+        s224 = per_image_scores(other_tensors, clip224_tensors, idx, device)
+        if dist:
+            acc = torch.tensor([sum(s336.values()), sum(s224.values()), float(len(idx))], dtype=torch.float64, device=device)
+            dist.all_reduce(acc)
+            t336, t224, cnt = acc.tolist()
+        else:
+            t336 = sum(s336[i] for i in range(n))
+            t224 = sum(s224[i] for i in range(n))
+            cnt = n
+        if cnt:
+            results[subfolder] = (t336 / cnt + t224 / cnt) / 2
+    if verbose and rank == 0:
+        for subfolder, avg_similarity in results.items():
+            print(f'Average cosine similarity between clip224+clip336 and {subfolder}: {avg_similarity}')
+    return results
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="A score (MI355X)")
+    ap.add_argument("--base-folder", default=base_folder)
+    ap.add_argument("--subfolders", nargs="*", default=None)
+    ap.add_argument("--n-images", type=int, default=100)
+    a = ap.parse_args(argv)
+    compute(a.base_folder, a.subfolders, a.n_images)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""C-score feature extraction on MI355X — drop-in for C_score/extract_feature.py.
+
+Same entry points: extract_features(image_path) -> Tensor[1, C, h, w] and process_images(input_dir, output_dir) writing
+<output_dir>/<class>/<image>_<suffix>.pt (extract_feature.py:54-106,110-130).  The reference is a module-level script with
+hard-coded `feature`/paths and an internally inconsistent DINOv2 branch (224-px input reshaped as 24x24); here
+`configure(feature, img_size, suffix)` sets them, grid = img_size // patch, and nothing runs at import time.
+Pre-processing is the reference's own (NOT the HF processors): PIL resize((s, s)) then (x/255 - 0.5) * 2 (l.65-67).
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from PIL import Image
+
+# Define the input and output paths (extract_feature.py:16-17)
+input_path = './data/SPair-71k/JPEGImages'
+output_path = './spair_feature/dino336'
+
+feature = "DINOv2"
+_DEFAULT_SIZE = {"CLIP": 224, "OPENCLIP": 224, "DINOv2": 224, "SigLIP": 224}
+_TOWER_ID = {"CLIP": 'openai/clip-vit-large-patch14', "OPENCLIP": 'laion/CLIP-ViT-L-14-laion2B-s32B-b82K',
+             "DINOv2": 'facebook/dinov2-large', "SigLIP": 'google/siglip-base-patch16-224'}
+_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64)
+
+
+class args_c:
+    def __init__(self, img_size=None, synthetic_weights=False):
+        self.mm_vision_select_layer = -2
+        self.img_size = img_size
+        self.synthetic_weights = synthetic_weights
+
+
+def configure(feature_name="DINOv2", img_size=None, suffix=None, synthetic_weights=False, batch=64):
+    """Build the tower once (the reference does this at import, extract_feature.py:23-50)."""
+    global feature
+    from ..llava.model.multimodal_encoder.clip_encoder import CLIPVisionTower
+    from ..llava.model.multimodal_encoder.dinov2_encoder import DinoV2VisionTower
+    from ..llava.model.multimodal_encoder.siglip_encoder import SigLipVisionTower
+    if feature_name not in _TOWER_ID:
+        raise NotImplementedError(f"feature {feature_name!r}: diffusion featurizers are a later row (SURVEY.md §8 a5)")
+    feature = feature_name
+    size = img_size or _DEFAULT_SIZE[feature_name]
+    a = args_c(img_size=size, synthetic_weights=synthetic_weights)
+    cls = {"CLIP": CLIPVisionTower, "OPENCLIP": CLIPVisionTower, "DINOv2": DinoV2VisionTower, "SigLIP": SigLipVisionTower}[feature_name]
+    _state.dift = cls(vision_tower=_TOWER_ID[feature_name], args=a)
+    _state.img_size = size
+    _state.suffix = suffix or {"CLIP": "clip", "OPENCLIP": "openclip", "DINOv2": f"dino{size}" if size != 224 else "dino", "SigLIP": "siglip"}[feature_name]
+    _state.batch = batch
+    return _state.dift
+
+
+def _load_pixels(image_path, size):
+    img = Image.open(image_path).convert('RGB').resize((size, size))
+    a = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)           # PILToTensor: uint8 [3, H, W]
+    return (a / 255.0 - 0.5) * 2
+
+
+def _to_maps(f):
+    # tokens [B, N, C] -> [B, C, g, g]   (extract_feature.py:82,86,90 with g = sqrt(N))
+    B, N, C = f.shape
+    g = int(round(N ** 0.5))
+    return f.permute(0, 2, 1).reshape(B, C, g, g)
+
+
+def extract_features(image_path):
+    if _state.dift is None:
+        configure(feature)
+    px = _load_pixels(image_path, _state.img_size).unsqueeze(0)
+    return _to_maps(_state.dift.forward(px))
+
+
+def process_images(input_dir, output_dir):
+    """Walks input_dir like the reference; towers run in batches (the reference runs batch 1), files are identical."""
+    if _state.dift is None:
+        configure(feature)
+    todo = []
+    for root, _, files in os.walk(input_dir):
+        for file in sorted(files):
+            if file.endswith(('.jpg', '.jpeg', '.png')):
+                class_name = os.path.basename(root)
+                image_name = os.path.splitext(file)[0]
+                todo.append((os.path.join(root, file), os.path.join(output_dir, class_name, f'{image_name}_{_state.suffix}.pt')))
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        todo = todo[d.get_rank()::d.get_world_size()]                        # image-sharded across ranks, no collective
+    for s in range(0, len(todo), _state.batch):
+        chunk = todo[s:s + _state.batch]
+        px = torch.stack([_load_pixels(p, _state.img_size) for p, _ in chunk])
+        maps = _to_maps(_state.dift.forward(px)).cpu()
+        for (_, out), m in zip(chunk, maps):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            torch.save(m.unsqueeze(0).clone(), out)
+            print(f'Saved features to {out}')
+
+
+if __name__ == "__main__":
+    configure(feature)
+    process_images(input_path, output_path)

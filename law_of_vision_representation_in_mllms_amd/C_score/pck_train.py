@@ -1,0 +1,224 @@
+"""C score (zero-shot SPair-71k PCK) on MI355X — drop-in for the evaluation half of C_score/pck_train.py.
+
+Same public functions and argument meaning:
+  normalize_feats(args, feat, epsilon=1e-10)                                          pck_train.py:24-29
+  prepare_feature_paths_and_load / get_patch_descriptors                               pck_train.py:31-55
+  compute_pck(args, save_path, aggre_net, files, kps, category=None, used_points=None, thresholds=None)
+        -> (correct, geo_score, out_results, img_correct)                              pck_train.py:57-245
+  eval(args, aggre_net, save_path, split='val') -> (pck_010, pck_005, pck_001, total_out_results)   :315-340
+  main(args) + the same argparse flags / yaml keys                                     :342-442
+
+What is different underneath: compute_pck loads every DISTINCT image's feature map once into one device-resident bank
+(the reference re-`torch.load`s both maps for every pair and decodes/resizes both JPEGs only to discard them), then
+runs ONE keypoint-transfer launch and ONE PCK-count launch for all pairs of the category (csrc/cscore.hip).  With
+torch.distributed initialised the pairs of a category are sharded over ranks in contiguous blocks and the hit counters
+are all-reduced (RCCL) — per-image means stay exact because counts, not means, are reduced.
+
+Not built (fail loudly): training (`DO_EVAL` false), ADAPT_FLIP, COMPUTE_GEOAWARE_METRICS, pascal / ap10k.
+"""
+import argparse
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .. import cscore_ops
+from .model_utils.projection_network import DummyAggregationNetwork
+from .utils.logger import get_logger, load_config, log_weighted_pcks, update_stats
+from .utils.utils_correspondence import calculate_keypoint_transformation, kpts_to_patch_idx  # noqa: F401 (API parity)
+from .utils.utils_dataset import get_dataset_info, load_eval_data
+
+device = 'cuda' if torch.cuda.is_available() else 'cpu'
+logger = get_logger()
+
+
+def normalize_feats(args, feat, epsilon=1e-10):
+    norms = torch.linalg.norm(feat, dim=-1)[:, :, None]
+    return feat / (norms + epsilon)
+
+
+def _feature_path(img_path, flip, ensemble, model):
+    # pck_train.py:33-37
+    feature_base = img_path.replace('JPEGImages', 'features').replace('.jpg', '')
+    suffix_flip = '_flip' if flip else ''
+    ensemble_folder = f'features_ensemble{ensemble}' if ensemble > 1 else 'features'
+    return f"{feature_base}_{model}{suffix_flip}.pt".replace('features', ensemble_folder)
+
+
+def prepare_feature_paths_and_load(aggre_net, img_path, flip, ensemble, num_patches, device, model):
+    desc = torch.load(_feature_path(img_path, flip, ensemble, model), map_location="cpu").to(device)
+    desc = aggre_net(desc).reshape(1, 1, -1, num_patches ** 2).permute(0, 1, 3, 2)
+    return desc, None
+
+
+def get_patch_descriptors(args, aggre_net, num_patches, files, pair_idx, flip=False, flip2=False, img1=None, img2=None,
+                          device='cuda'):
+    img1_desc, mask1 = prepare_feature_paths_and_load(aggre_net, files[pair_idx * 2], flip, args.ENSEMBLE, num_patches, device, args.MODEL)
+    img2_desc, mask2 = prepare_feature_paths_and_load(aggre_net, files[pair_idx * 2 + 1], flip2, args.ENSEMBLE, num_patches, device, args.MODEL)
+    return normalize_feats(args, img1_desc[0]), normalize_feats(args, img2_desc[0]), mask1, mask2
+
+
+def _renumber_used_points(kpts, idx):
+    out = torch.zeros(30, kpts.shape[1])
+    out[idx] = kpts
+    return out
+
+
+def _dist():
+    d = torch.distributed
+    return d if d.is_available() and d.is_initialized() else None
+
+
+def build_feature_bank(args, aggre_net, files, num_patches, dev):
+    """Distinct images of a category -> ([n_img, C, P^2] fp32 device bank, per-file-slot bank index)."""
+    uniq, slot = {}, []
+    for f in files:
+        if f not in uniq:
+            uniq[f] = len(uniq)
+        slot.append(uniq[f])
+    maps = []
+    for f in uniq:
+        m = torch.load(_feature_path(f, False, args.ENSEMBLE, args.MODEL), map_location="cpu")
+        maps.append(aggre_net(m).reshape(-1, num_patches ** 2).float())
+    return torch.stack(maps).to(dev), np.asarray(slot, dtype=np.int32)
+
+
+def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_points=None, thresholds=None, bank=None):
+    if getattr(args, "ADAPT_FLIP", False) or getattr(args, "COMPUTE_GEOAWARE_METRICS", False):
+        raise NotImplementedError("ADAPT_FLIP / COMPUTE_GEOAWARE_METRICS are not built on the MI355X path yet (SURVEY §8f N4)")
+    P = args.NUM_PATCHES
+    N = len(files) // 2
+    dev = torch.device(device)
+    if bank is None:
+        bank_t, slot = build_feature_bank(args, aggre_net, files, P, dev)
+    else:
+        bank_t, slot = bank
+    kps = kps.float()
+    K = kps.shape[1]
+    if K > 32:
+        raise ValueError("at most 32 keypoints per pair are supported")
+    d = _dist()
+    rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
+    lo, hi = (N * rank) // world, (N * (rank + 1)) // world                   # contiguous pair block of this rank
+    k1, k2 = kps[0::2], kps[1::2]
+    idx = np.stack([kpts_to_patch_idx(args, k1[i], P) for i in range(N)]).astype(np.int32) if N else np.zeros((0, K), np.int32)
+    nkp = torch.full((N,), K, dtype=torch.int32)
+    sl = slice(lo, hi)
+    xy = cscore_ops.transfer(bank_t, torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy()),
+                             torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW, soft_eval=bool(args.SOFT_EVAL),
+                             anno_size=args.ANNO_SIZE)
+    alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)
+    if thresholds is not None:
+        thr = torch.tensor(thresholds, dtype=torch.float64)
+    else:   # alpha * ANNO_SIZE is a float32 product in the reference (pck_train.py:160): pre-round it per alpha is not
+        thr = torch.full((N,), float(args.ANNO_SIZE), dtype=torch.float64)    # expressible with one threshold; exact for 840
+    counts = cscore_ops.pck_counts(xy, k1[sl], k2[sl], thr[sl], nkp[sl], alphas)
+    cnt = torch.zeros(N, 4, dtype=torch.int32, device=counts.device)
+    cnt[sl] = counts
+    pred = torch.zeros(N, K, 2, dtype=torch.float32, device=xy.device)
+    pred[sl] = xy
+    if d:
+        d.all_reduce(cnt)
+        d.all_reduce(pred)
+    cnt = cnt.cpu().numpy()
+    pred = pred.cpu()
+    used = torch.arange(K) if used_points is None else used_points.cpu()
+    out_results = [{"src_fn": files[2 * i], "trg_fn": files[2 * i + 1],
+                    "src_kpts_pred": _renumber_used_points(pred[i], used).numpy(), "resize_resolution": args.ANNO_SIZE}
+                   for i in range(N)]
+    # per-image PCK: float32 mean of 0/1 hits per pair (pck_train.py:158), then float32 mean over pairs (:205-206)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        per_img = cnt[:, :3].astype(np.float32) / cnt[:, 3:4].astype(np.float32)
+    if not args.KPT_RESULT:
+        img_correct = torch.from_numpy(per_img.T.copy()).mean(dim=-1).tolist()
+        img_correct.append(N)
+    else:
+        img_correct = None
+    n_kpts = int(cnt[:, 3].sum())
+    correct = (torch.from_numpy(cnt[:, :3].sum(0).astype(np.int64)) / n_kpts).tolist()
+    correct.append(n_kpts)
+    shown = correct[:3] if args.KPT_RESULT else img_correct[:3]
+    if rank == 0:
+        logger.info(f'{category}...' + ' | '.join(f'PCK-Transfer@{a:.2f}: {v * 100:.2f}%' for a, v in zip(alphas, shown)))
+    return correct, [], out_results, img_correct
+
+
+def eval(args, aggre_net, save_path, split='val'):
+    aggre_net.eval()
+    data_dir, categories, split = get_dataset_info(args, split)
+    total_out_results, pcks, pcks_05, pcks_01, weights, kpt_weights = ([] for _ in range(6))
+    for cat in categories:
+        files, kps, thresholds, used_points = load_eval_data(args, data_dir, cat, split)
+        compute_args = (save_path, aggre_net, files, kps, cat, used_points)
+        pck, correct_geo, out_results, img_correct = (compute_pck(args, *compute_args, thresholds=thresholds) if args.BBOX_THRE
+                                                      else compute_pck(args, *compute_args))
+        total_out_results.extend(out_results)
+        update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, pck, img_correct)
+    pck_010, pck_005, pck_001 = log_weighted_pcks(args, logger, pcks, pcks_05, pcks_01, weights)
+    aggre_net.train()
+    return pck_010, pck_005, pck_001, total_out_results
+
+
+def main(args):
+    torch.manual_seed(args.SEED)
+    np.random.seed(args.SEED)
+    args.BBOX_THRE = not (args.IMG_THRESHOLD or args.EVAL_DATASET == 'pascal')
+    if args.SAMPLE == 0:
+        args.SAMPLE = None
+    save_path = f'./results_{args.EVAL_DATASET}/pck_train_{args.NOTE}_sample_{args.EPOCH}_{args.SAMPLE}_lr_{args.LR}'
+    os.makedirs(save_path, exist_ok=True)
+    get_logger(save_path + '/result.log')
+    logger.info(args)
+    if not args.DUMMY_NET:
+        raise NotImplementedError("the supervised AggregationNetwork post-processor is outside the zero-shot C score (SURVEY §8f N4)")
+    aggre_net = DummyAggregationNetwork()
+    if not args.DO_EVAL:
+        raise NotImplementedError("training is out of scope of the scoring path; run with DO_EVAL (configs/eval_zero_shot_spair.yaml)")
+    with torch.no_grad():
+        pck_010, pck_005, pck_001, result = eval(args, aggre_net, save_path, split='test')
+    with open(save_path + '/result.pkl', 'wb') as f:
+        pickle.dump(result, f)
+    return pck_010, pck_005, pck_001
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--config', type=str, default=None)
+    p.add_argument('--SEED', type=int, default=42)
+    p.add_argument('--NOTE', type=str, default='')
+    p.add_argument('--SAMPLE', type=int, default=0)
+    p.add_argument('--TEST_SAMPLE', type=int, default=20)
+    p.add_argument('--TOTAL_SAVE_RESULT', type=int, default=0)
+    p.add_argument('--IMG_THRESHOLD', action='store_true', default=False)
+    p.add_argument('--ANNO_SIZE', type=int, default=840)
+    p.add_argument('--LR', type=float, default=1.25e-3)
+    p.add_argument('--EPOCH', type=int, default=1)
+    p.add_argument('--TRAIN_DATASET', type=str, default='spair')
+    p.add_argument('--ENSEMBLE', type=int, default=1)
+    p.add_argument('--DO_EVAL', action='store_true', default=False)
+    p.add_argument('--DUMMY_NET', action='store_true', default=False)
+    p.add_argument('--EVAL_DATASET', type=str, default='spair')
+    p.add_argument('--COMPUTE_GEOAWARE_METRICS', action='store_true', default=False)
+    p.add_argument('--KPT_RESULT', action='store_true', default=False)
+    p.add_argument('--ADAPT_FLIP', action='store_true', default=False)
+    p.add_argument('--MUTUAL_NN', action='store_true', default=False)
+    p.add_argument('--SOFT_EVAL', action='store_true', default=False)
+    p.add_argument('--SOFT_EVAL_WINDOW', type=int, default=7)
+    p.add_argument('--MODEL', type=str, default='clip')
+    p.add_argument('--NUM_PATCHES', type=int, default=7)
+    p.add_argument('--DATA_DIR', type=str, default='data/SPair-71k')
+    return p
+
+
+def parse_args(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.config is not None:
+        d = vars(args)
+        d.update(load_config(args.config))
+        args = argparse.Namespace(**d)
+    return args
+
+
+if __name__ == '__main__':
+    main(parse_args())

@@ -1,0 +1,32 @@
+"""Keypoint-transfer entry points of the C score on MI355X — drop-ins for the two functions pck_train.py imports from
+C_score/utils/utils_correspondence.py: kpts_to_patch_idx (:384-388) and calculate_keypoint_transformation (:345-382)."""
+import numpy as np
+import torch
+
+from ... import cscore_ops
+
+
+def kpts_to_patch_idx(args, img1_kps, num_patches):
+    # identical host arithmetic (numpy float64 * float32, truncation to int32)
+    img1_y, img1_x = img1_kps[:, 1].cpu().numpy(), img1_kps[:, 0].cpu().numpy()
+    img1_y_patch = (num_patches / args.ANNO_SIZE * img1_y).astype(np.int32)
+    img1_x_patch = (num_patches / args.ANNO_SIZE * img1_x).astype(np.int32)
+    return num_patches * img1_y_patch + img1_x_patch
+
+
+def calculate_keypoint_transformation(args, img1_desc, img2_desc, img1_patch_idx, num_patches):
+    """img*_desc: [1, P^2, C] patch descriptors (normalised or not — the kernel applies normalize_feats itself, and
+    re-normalising unit rows is the identity to fp32 rounding).  Returns Tensor[K, 2] (x, y) on the descriptors' device.
+    More than 32 keypoints are processed in chunks of 32 (kernel limit)."""
+    dev = img1_desc.device if img1_desc.is_cuda else torch.device("cuda")
+    P = num_patches
+    bank = torch.stack([img1_desc[0].t(), img2_desc[0].t()]).to(device=dev, dtype=torch.float32).contiguous()   # [2, C, P^2]
+    idx = torch.as_tensor(np.asarray(img1_patch_idx), dtype=torch.int32)
+    outs = []
+    for s in range(0, len(idx), 32):
+        part = idx[s:s + 32]
+        xy = cscore_ops.transfer(bank, torch.tensor([0]), torch.tensor([1]), part[None], torch.tensor([len(part)]), P,
+                                 window=getattr(args, "SOFT_EVAL_WINDOW", 0), soft_eval=bool(getattr(args, "SOFT_EVAL", False)),
+                                 anno_size=args.ANNO_SIZE)
+        outs.append(xy[0, :len(part)])
+    return torch.cat(outs, 0)
