@@ -47,7 +47,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--cpu-images", type=int, default=4)
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,6 +67,7 @@ def main():
     from law_of_vision_representation_in_mllms_amd import _lib, engine
     from law_of_vision_representation_in_mllms_amd import vit_weights as VW
 
+    _lib.load().visrep_set_gemm_variant(args.gemm_variant)
     spec = VW.SPECS[MODEL]
     weights = VW.synthetic_weights(spec, seed=1, n_layers=N_LAYERS)      # same tower replica on every rank
     eng = engine.VitEngine(spec, weights, dev)
@@ -145,7 +147,7 @@ def main():
         sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, spec.tokens, spec.heads, 0.125))
         kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1)}
         top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_128<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+        roof = {"bound": "mfma", "kernel": ("gemm_bf16_256" if args.gemm_variant == 2 else "gemm_bf16_128") + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"],
                 "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),
@@ -159,7 +161,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import vit as OV
         n = args.cpu_images
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))      # torch CPU GEMMs stop scaling (and thrash) beyond ~64 threads
         sample = px[:n].float().cpu()
         OV.tower_features(spec, weights, sample[:1], select_layer=N_LAYERS)        # warm
         c0 = time.perf_counter()
@@ -178,7 +180,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "CLIP ViT-L/14-336 vision_tower feature-extract (hidden_states[-2], 23 layers run), "
                                    f"batch {B} per GPU, random-init weights, N(0,1) pixels resident in HBM",
-                       "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)"},
+                       "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)", "gemm_variant": args.gemm_variant},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

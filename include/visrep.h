@@ -38,6 +38,11 @@ int visrep_version(void);
 /* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
 size_t visrep_last_error(char* buf, size_t n);
 
+/* Tuning knob (process-global, for A/B measurements): selects the GEMM kernel family used by every entry point below.
+ * 1 = 128x128 tiles / one barrier per K-tile; 2 = 256x256 persistent ping-pong kernel (falls back to 1 when N % 256 != 0).
+ * Returns the previous value.  Results are identical up to fp32 summation order. */
+int visrep_set_gemm_variant(int variant);
+
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
  * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from
  * llava/model/multimodal_encoder/clip_encoder.py:48) and the mm_projector Sequential

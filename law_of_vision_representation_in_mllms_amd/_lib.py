@@ -36,6 +36,7 @@ _vp, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 SIGNATURES = {
     "visrep_version": (_i, []),
     "visrep_last_error": (_sz, [C.c_char_p, _sz]),
+    "visrep_set_gemm_variant": (_i, [_i]),
     "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -62,7 +62,7 @@ enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2, ACT_GELU_TANH = 3 };
 
 VR_DEV float apply_act(float x, int act) {
     switch (act) {
-        case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));
+        case ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
         case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
         case ACT_GELU_TANH: {
             const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);

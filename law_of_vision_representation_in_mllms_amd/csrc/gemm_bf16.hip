@@ -15,6 +15,7 @@
 //   SWAP = false (V^T epilogue): a = X fragment, b = W fragment -> lane holds C[m = 4g+r][n = l&15]:
 //                four consecutive m -> one 8-byte store into the token-contiguous V^T layout.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "visrep_internal.h"
 
 namespace {
@@ -96,67 +97,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
         __syncthreads();   // waits the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
     }
 
-    // ------------------------------------------------------------------ epilogues
-    if (EPI == EPI_VT) {
-        // lane holds C[m = mb + 4*fg + r][n = nb + fr]; V^T layout: vt[n * ldc + perm16(m)], see attention.hip
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fr;
-            const float b = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + i * 16 + fg * 4;          // multiple of 4
-                if (m < p.M) {   // M is padded to a multiple of 4 by the caller's buffer (columns >= M are never read unmasked)
-                    const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-key groups 1 <-> 2
-                    u32x2 v = {pack_bf16(acc[i][j][0] + b, acc[i][j][1] + b), pack_bf16(acc[i][j][2] + b, acc[i][j][3] + b)};
-                    *reinterpret_cast<u32x2*>(p.C + (size_t)n * p.ldc + mp) = v;
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
-        if (m >= p.M) continue;
-        size_t orow = (size_t)m;
-        const float* posrow = nullptr;
-        if (EPI == EPI_PATCH) {       // m = b*P + pidx  ->  token row b*T + cls_off + pidx ; add pos[cls_off + pidx]
-            const int b = m / p.patches, pi = m - b * p.patches;
-            orow = (size_t)b * p.tokens + p.cls_off + pi;
-            posrow = p.pos + (size_t)(p.cls_off + pi) * p.N;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fg * 4;
-            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-            if (p.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
-            }
-            if (EPI == EPI_ACT) {
-                v0 = apply_act(v0, p.act); v1 = apply_act(v1, p.act); v2 = apply_act(v2, p.act); v3 = apply_act(v3, p.act);
-            }
-            if (EPI == EPI_RESID) {
-                if (p.ls) {
-                    const float4 s = *reinterpret_cast<const float4*>(p.ls + n);
-                    v0 *= s.x; v1 *= s.y; v2 *= s.z; v3 *= s.w;
-                }
-                const u32x2 r = *reinterpret_cast<const u32x2*>(p.resid + orow * p.ldc + n);
-                v0 += bf_lo(r[0]); v1 += bf_hi(r[0]); v2 += bf_lo(r[1]); v3 += bf_hi(r[1]);
-            }
-            if (EPI == EPI_PATCH) {
-                const float4 s = *reinterpret_cast<const float4*>(posrow + n);
-                v0 += s.x; v1 += s.y; v2 += s.z; v3 += s.w;
-            }
-            if (EPI == EPI_F32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = float4{v0, v1, v2, v3};
-            } else {
-                u32x2 o = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
-                *reinterpret_cast<u32x2*>(p.C + orow * p.ldc + n) = o;
-            }
-        }
-    }
+    // ------------------------------------------------------------------ epilogues (gemm_epilogue.h)
+    if (EPI == EPI_VT) gemm_epilogue_vt<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
+    else gemm_epilogue_rowmajor<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
 
 template <int EPI>
@@ -173,10 +116,13 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int g_visrep_gemm_variant = 1;
+
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
     if (a.N % BN != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N must be a multiple of 128 and K of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
+    if (g_visrep_gemm_variant == 2 && visrep_gemm_v2_supports(a)) return visrep_gemm_v2_dispatch(a, s);
     switch (a.epi) {
         case EPI_BIAS: return launch<EPI_BIAS>(a, s);
         case EPI_ACT: return launch<EPI_ACT>(a, s);

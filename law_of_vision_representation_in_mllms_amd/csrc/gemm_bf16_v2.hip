@@ -1,0 +1,231 @@
+// bf16 MFMA GEMM v2 for gfx950: 256x256 tiles, 8 waves, ping-pong wave groups, 4-deep LDS ring, persistent blocks.
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )          same contract / epilogues as gemm_bf16.hip (v1)
+//
+// Why: v1 (128x128, 4 waves, one barrier per K-tile, 2 blocks/CU) leaves the matrix pipe idle while a block's waves
+// sit in their barrier + ds_read phase (measured 36 % of the bf16 peak at K = 4096, 21-31 % at K = 1024 where the
+// pipeline fill and the epilogue are not amortised).  v2 restructures the block so that on every SIMD one wave is
+// ALWAYS in an MFMA segment while its partner wave loads:
+//
+//   * 512 threads = 8 waves = two groups of four (waves w and w+4 share a SIMD).  Group g owns rows [128g, 128g+128)
+//     of the 256x256 tile, wave wn = w&3 owns 64 columns: 128x64 per wave = 8x4 MFMA 16x16x32 accumulators.
+//   * BK = 32 K-tiles (one MFMA k-step), staged by global_load_lds into a ring of FOUR 32-KB stages (X tile 256x32 +
+//     W tile 256x32).  Loads run 2-3 K-tiles ahead of the math and are retired with COUNTED s_waitcnt vmcnt(N) -
+//     the queue is never drained in the steady state.
+//   * Each K-tile is two phases per group: {L: ds_read fragments + issue 2 LDS-DMA loads | M: 16 MFMAs}, separated
+//     by raw s_barriers.  Group 1 is skewed by one barrier, so its L segments coincide with group 0's M segments
+//     and vice versa (matrix beside memory on every SIMD, s_setprio(1) on the MFMA segment).
+//   * The block is persistent: it walks its list of output tiles and the load stream simply continues into the next
+//     tile's first K-tiles, so there is no pipeline refill between output tiles; blocks of one XCD walk a contiguous
+//     chunk of the tile space (shared A / W panels in that XCD's L2).
+//   * LDS rows are 64 B (four 16-B slots); slot ^= (4 - ((row>>2)&3))&3 makes the fragment ds_read_b128 conflict
+//     free; the swizzle is applied on the per-lane global source address of the LDS-DMA (its LDS image is linear).
+//
+// Barrier / hazard ledger (s = stream index of a K-tile, stage = s & 3; "instance" = global s_barrier count):
+//   group 0:  L0(s) | b 4s+1 | M0(s) | b 4s+2 | L1(s) | b 4s+3 | M1(s) | b 4s+4
+//   group 1:  (extra barrier = instance 1)  L0(s) | b 4s+2 | M0(s) | b 4s+3 | L1(s) | b 4s+4 | M1(s) | b 4s+5
+//   issue:    group 0: W-pair of tile s+2 in L0(s), X-pair of tile s+3 in L1(s);  group 1: X/W pairs of s+3 in L0/L1(s)
+//   RAW:      tile s+1 is first read after instance 4s+4.  Before arriving there group 0 waits vmcnt(6) (outstanding:
+//             tile s+2 = 4, X-pair of s+3 = 2) and group 1 waits vmcnt(8) (tiles s+2, s+3) -> tile s+1 has landed.
+//   WAR:      stage (s+3)&3 was last read in tile s-1 (group 1's L1(s-1), retired by its lgkmcnt(0) after instance
+//             4s); the earliest overwrite is issued after instance 4s+1.
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "visrep_internal.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 32;
+constexpr int XW_BYTES = 256 * TK * 2;          // 16 KB per operand tile
+constexpr int STAGE2 = 2 * XW_BYTES;            // 32 KB
+constexpr int NSTAGE = 4;
+constexpr int LDS2 = NSTAGE * STAGE2;           // 128 KB
+
+VR_DEV void wait_vm6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+VR_DEV void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+VR_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+VR_DEV void barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct TileWalk {           // the block's list of output tiles: chunk of its XCD, strided by the blocks of that XCD
+    int start, stride, count, ntn;
+    VR_DEV void decode(int i, int& m0, int& n0) const {
+        const int ii = i < count ? i : count - 1;        // past-the-end loads re-read the last tile (never consumed)
+        const int t = start + ii * stride;
+        m0 = (t / ntn) * TM;
+        n0 = (t % ntn) * TN;
+    }
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int ntn = p.N / TN, ntm = (p.M + TM - 1) / TM, ntiles = ntm * ntn;
+
+    // ---- persistent tile list (XCD-contiguous chunks)
+    TileWalk tw;
+    {
+        const int G = gridDim.x;
+        const int nx = G < 8 ? G : 8;                          // XCDs in use
+        const int x = blockIdx.x % nx, j = blockIdx.x / nx;   // block b runs on XCD b % 8 (speed only)
+        const int per = (G + nx - 1 - x) / nx;                // blocks on this XCD
+        const int q = ntiles / nx, r = ntiles % nx;
+        const int cstart = x * q + (x < r ? x : r), csize = q + (x < r ? 1 : 0);
+        tw.start = cstart + j;
+        tw.stride = per;
+        tw.count = j < csize ? (csize - j + per - 1) / per : 0;
+        tw.ntn = ntn;
+    }
+    if (tw.count == 0) return;                                 // uniform per block: no barrier has been executed yet
+    const int nk = p.K / TK;
+    const int S = tw.count * nk;                               // K-tiles in this block's stream
+
+    // ---- LDS-DMA source cursors.  Wave w covers rows [32w, 32w+32) of both operand tiles: 2 instructions of 16 rows.
+    const int lrow = lane >> 2;
+    const int lslot = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    struct Cur { const bf16_t* p0; const bf16_t* p1; int k, ti, idx; };
+    Cur cx, cw;
+    auto set_x = [&](Cur& c) {
+        int m0, n0; tw.decode(c.ti, m0, n0);
+        int r0 = m0 + wave * 32 + lrow, r1 = r0 + 16;
+        r0 = r0 < p.M ? r0 : p.M - 1; r1 = r1 < p.M ? r1 : p.M - 1;
+        c.p0 = p.A + (size_t)r0 * p.lda + lslot * 8; c.p1 = p.A + (size_t)r1 * p.lda + lslot * 8;
+    };
+    auto set_w = [&](Cur& c) {
+        int m0, n0; tw.decode(c.ti, m0, n0);
+        const int r0 = n0 + wave * 32 + lrow;
+        c.p0 = p.W + (size_t)r0 * p.ldw + lslot * 8; c.p1 = c.p0 + (size_t)16 * p.ldw;
+    };
+    cx.k = cw.k = 0; cx.ti = cw.ti = 0; cx.idx = cw.idx = 0;
+    set_x(cx); set_w(cw);
+    auto issue_x = [&]() {
+        char* dst = smem + (cx.idx & 3) * STAGE2 + wave * 2048;
+        glds16(cx.p0 + cx.k, dst); glds16(cx.p1 + cx.k, dst + 1024);
+        ++cx.idx; cx.k += TK;
+        if (cx.k == p.K) { cx.k = 0; ++cx.ti; set_x(cx); }
+    };
+    auto issue_w = [&]() {
+        char* dst = smem + (cw.idx & 3) * STAGE2 + XW_BYTES + wave * 2048;
+        glds16(cw.p0 + cw.k, dst); glds16(cw.p1 + cw.k, dst + 1024);
+        ++cw.idx; cw.k += TK;
+        if (cw.k == p.K) { cw.k = 0; ++cw.ti; set_w(cw); }
+    };
+
+    // ---- fragment read offset: row = base16 + (lane&15), logical slot = lane>>4
+    const int fr = lane & 15, fg = lane >> 4;
+    const int foff = fr * 64 + (((fg) ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4);
+    const int xoff = grp * 128 * 64 + foff;                    // + mi*1024
+    const int woff = XW_BYTES + wn * 64 * 64 + foff;           // + ni*1024
+
+    // ---- prologue: tiles 0,1 (+2: group 1 fully, group 0 X-pair only) — leaves both groups in steady-state counts
+    issue_x(); issue_w(); issue_x(); issue_w(); issue_x();
+    if (grp == 1) { issue_w(); wait_vm8(); } else { wait_vm6(); }
+    barrier();                                                 // tile 0 visible to every wave
+
+    auto body = [&](auto G_) {
+        constexpr int G = decltype(G_)::value;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int kt = 0, ti = 0;
+        if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
+        for (int s = 0; s < S; ++s) {
+            const char* sb = smem + (s & 3) * STAGE2;
+            bf16x8 xf[4], wf[4];
+            // ---------------- L0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + woff + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xoff + i * 1024);
+            if (G == 0) issue_w(); else issue_x();
+            barrier();
+            // ---------------- M0
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (EPI == EPI_VT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            barrier();
+            // ---------------- L1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xoff + (4 + i) * 1024);
+            if (G == 0) issue_x(); else { issue_w(); wait_vm8(); }
+            barrier();
+            // ---------------- M1
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (EPI == EPI_VT) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[j], acc[4 + i][j], 0, 0, 0);
+                    else acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[4 + i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            if (G == 0) wait_vm6();
+            if (++kt == nk) {
+                // ------------------------------------------------ epilogue of output tile ti
+                kt = 0;
+                int m0, n0; tw.decode(ti, m0, n0); ++ti;
+                const int mb = m0 + grp * 128, nb = n0 + wn * 64;
+                if (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, fg);
+                else gemm_epilogue_rowmajor<EPI, 8, 4>(p, acc, mb, nb, fr, fg);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            barrier();
+        }
+        if (G == 0) barrier();                                 // group 1 executed one extra barrier up front
+    };
+    if (grp == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+    wait_vm0();                                                // drain the (unused) run-ahead loads before exit
+}
+
+template <int EPI>
+int launch2(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    static int ncu = 256;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL(gemm_bf16_256<EPI>, dim3(grid), dim3(512), LDS2, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool visrep_gemm_v2_supports(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0; }
+
+int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_BIAS: return launch2<EPI_BIAS>(a, s);
+        case EPI_ACT: return launch2<EPI_ACT>(a, s);
+        case EPI_RESID: return launch2<EPI_RESID>(a, s);
+        case EPI_VT: return launch2<EPI_VT>(a, s);
+        case EPI_PATCH: return launch2<EPI_PATCH>(a, s);
+        case EPI_F32: return launch2<EPI_F32>(a, s);
+    }
+    return visrep_set_error(VISREP_ERR_ARG, "gemm: unknown epilogue");
+}

@@ -14,6 +14,13 @@ int visrep_set_error(int code, const char* msg) {
 
 extern "C" int visrep_version(void) { return VISREP_VERSION; }
 
+extern "C" int visrep_set_gemm_variant(int variant) {
+    if (variant != 1 && variant != 2) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1 or 2");
+    const int old = g_visrep_gemm_variant;
+    g_visrep_gemm_variant = variant;
+    return old;
+}
+
 extern "C" size_t visrep_last_error(char* buf, size_t n) {
     const size_t len = strlen(g_err);
     if (buf && n) {

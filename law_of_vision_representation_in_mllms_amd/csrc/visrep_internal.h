@@ -23,4 +23,7 @@ struct GemmArgs {
 };
 
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s);
+bool visrep_gemm_v2_supports(const GemmArgs& a);
+int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
+extern int g_visrep_gemm_variant;   // 1 = 128x128 two-barrier kernel, 2 = 256x256 ping-pong persistent kernel (when the shape allows)
 int visrep_set_error(int code, const char* msg);

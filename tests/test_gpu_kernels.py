@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=[1, 2], ids=["gemm_v1_128", "gemm_v2_256"])
+def gemm_variant(request):
+    """Run a test under both GEMM kernel families (v2 falls back to v1 when N % 256 != 0)."""
+    lib = _lib.load()
+    old = lib.visrep_set_gemm_variant(request.param)
+    yield request.param
+    lib.visrep_set_gemm_variant(old)
+
+
 def bf(x):
     return x.to(torch.bfloat16)
 
@@ -43,8 +52,8 @@ def ref_act(x, kind):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (1731, 384, 1024), (577 * 4, 1024, 256)])
-def test_gemm_bias_and_f32(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (1731, 384, 1024), (577 * 4, 1024, 256), (256 * 9 + 77, 512, 32), (70000, 256, 1024)])
+def test_gemm_bias_and_f32(M, N, K, gemm_variant):
     g = torch.Generator().manual_seed(M + N + K)
     a = bf(torch.randn(M, K, generator=g)).to(DEV)
     w = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
@@ -59,7 +68,7 @@ def test_gemm_bias_and_f32(M, N, K):
 
 
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu", "gelu_tanh"])
-def test_gemm_activation(act):
+def test_gemm_activation(act, gemm_variant):
     g = torch.Generator().manual_seed(3)
     M, N, K = 300, 256, 128
     a = bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -70,9 +79,9 @@ def test_gemm_activation(act):
     assert max_err(got, want) < 6e-3
 
 
-def test_gemm_residual_layerscale_inplace():
+def test_gemm_residual_layerscale_inplace(gemm_variant):
     g = torch.Generator().manual_seed(4)
-    M, N, K = 777, 128, 256
+    M, N, K = 777, 256, 256
     a = bf(torch.randn(M, K, generator=g)).to(DEV)
     w = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
@@ -84,6 +93,21 @@ def test_gemm_residual_layerscale_inplace():
     x2 = x.clone()
     engine.gemm(a, w, bias, _lib.EPI_RESID, resid=x2, ls=None, out=x2)       # in place, no LayerScale
     assert max_err(x2, x.float() + a.float() @ w.float().t() + bias) < 6e-3
+
+
+def test_gemm_v2_many_tiles_per_block_and_reuse(gemm_variant):
+    """More output tiles than CUs (persistent blocks walk several tiles), launched twice into the same buffers."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 256 * 40 + 3, 2048, 128          # 41 x 8 = 328 tiles of 256x256
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    want = a.float() @ w.float().t() + bias
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    for _ in range(2):
+        out.fill_(float("nan"))
+        engine.gemm(a, w, bias, _lib.EPI_F32, out=out)
+        assert max_err(out, want) < 1e-5
 
 
 def test_gemm_rejects_bad_shapes():
@@ -112,7 +136,7 @@ def ref_attention(q, k, v, B, T, H):
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 64, 2), (3, 577, 2), (5, 17, 2), (2, 257, 4), (7, 196, 2)])
-def test_attention_matches_torch(B, T, H):
+def test_attention_matches_torch(B, T, H, gemm_variant):
     g = torch.Generator().manual_seed(B * 1000 + T)
     d = H * 64
     M = B * T
@@ -148,7 +172,7 @@ def test_attention_peaked_softmax():
 
 # ------------------------------------------------------------------------------------------------ towers
 @pytest.mark.parametrize("tag", VIT_HIP_TAGS)
-def test_tower_matches_reference_golden(tag):
+def test_tower_matches_reference_golden(tag, gemm_variant):
     spec, w, px, want = load_vit_hip_case(tag)
     eng = engine.VitEngine(spec, w, DEV)
     n = spec.layers - 1                                                      # hidden_states[-2]
@@ -160,7 +184,7 @@ def test_tower_matches_reference_golden(tag):
     assert e_hip < max(2.0 * e_ref, 1e-2), (tag, e_hip, e_ref)
 
 
-def test_tower_all_hidden_states_and_batch_invariance():
+def test_tower_all_hidden_states_and_batch_invariance(gemm_variant):
     spec, w, px, _ = load_vit_hip_case("clip_quick")
     eng = engine.VitEngine(spec, w, DEV)
     hs = OV.vit_hidden_states(spec, w, px)
@@ -181,7 +205,7 @@ def test_tower_rejects_wrong_resolution():
         eng.forward(torch.zeros(1, 3, 28, 28))
 
 
-def test_vit_l14_336_full_size_parity():
+def test_vit_l14_336_full_size_parity(gemm_variant):
     """BASELINE config[1] shape: CLIP ViT-L/14-336, 23 layers, on a few images, against the fp32 CPU oracle."""
     spec = VW.SPECS["openai/clip-vit-large-patch14-336"]
     w = VW.synthetic_weights(spec, seed=1, n_layers=23)
