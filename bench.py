@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4)
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2])
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2, 3])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +147,7 @@ def main():
         sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, spec.tokens, spec.heads, 0.125))
         kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1)}
         top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
-        roof = {"bound": "mfma", "kernel": ("gemm_bf16_256" if args.gemm_variant == 2 else "gemm_bf16_128") + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"],
                 "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),

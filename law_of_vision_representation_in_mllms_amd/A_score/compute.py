@@ -44,18 +44,14 @@ def _shard(n, rank, world):
     return list(range(rank, n, world))
 
 
-def _stack(tensors, idx, device):
-    """Images of one encoder share a token count -> one [n, N, D] batch; otherwise group by shape."""
-    groups = {}
-    for i in idx:
-        groups.setdefault(tuple(tensors[i].shape), []).append(i)
-    for shape, ids in groups.items():
-        yield ids, torch.stack([tensors[i] for i in ids]).to(device)
+def _score_batch(other, ref):
+    """[n, Nt, D] x [n, Nr, D] -> [n] on the device: the HIP kernel (no CPU fallback; tests may monkeypatch this hook)."""
+    from .. import ascore_ops
+    return ascore_ops.max_cos_mean(other, ref)
 
 
 def per_image_scores(other_tensors, ref_tensors, idx, device="cuda"):
-    """[(image index, mean_t max_s cos)] for the images in idx (compute.py:54-72 for one reference)."""
-    from .. import ascore_ops
+    """{image index: mean_t max_s cos} for the images in idx (compute.py:54-72 for one reference)."""
     out = {}
     by_other = {}
     for i in idx:
@@ -63,7 +59,7 @@ def per_image_scores(other_tensors, ref_tensors, idx, device="cuda"):
     for _, ids in by_other.items():
         o = torch.stack([other_tensors[i].reshape(-1, other_tensors[i].shape[-1]) for i in ids]).to(device)
         r = torch.stack([ref_tensors[i].reshape(-1, ref_tensors[i].shape[-1]) for i in ids]).to(device)
-        s = ascore_ops.max_cos_mean(o, r).double().cpu()
+        s = _score_batch(o, r).double().cpu()
         for j, i in enumerate(ids):
             out[i] = float(s[j])
     return out

@@ -9,7 +9,7 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libvisrep_hip.so")
+LIB_PATH = os.environ.get("VISREP_LIB") or os.path.join(_PKG, "libvisrep_hip.so")   # VISREP_LIB: diagnostic builds only
 
 BF16, F32 = 0, 1
 EPI_BIAS, EPI_ACT, EPI_RESID, EPI_VT, EPI_PATCH, EPI_F32 = range(6)
@@ -37,6 +37,7 @@ SIGNATURES = {
     "visrep_version": (_i, []),
     "visrep_last_error": (_sz, [C.c_char_p, _sz]),
     "visrep_set_gemm_variant": (_i, [_i]),
+    "visrep_debug_gemm_ablation": (_i, [_i]),
     "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),

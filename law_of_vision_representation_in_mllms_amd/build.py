@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "attention.hip", "rowops.hip", "ascore.hip", "cscore.hip", "visrep_abi.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "attention.hip", "rowops.hip", "ascore.hip", "cscore.hip", "visrep_abi.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
@@ -20,6 +20,15 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_ablation_lib() -> str:
+    """Separate library with the GEMM-v2 timing ablation knobs compiled in (tools/gemm_ablate.py only)."""
+    out = os.path.join(PKG, "libvisrep_hip_ablate.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + ["-DVISREP_GEMM_ABLATE"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:

@@ -37,7 +37,7 @@ struct AttnArgs {
     float sc;                              // softmax scale * log2(e)
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_d64(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
@@ -104,40 +104,43 @@ __global__ __launch_bounds__(256) void attn_fwd_d64(const AttnArgs p) {
                 s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt2], 0, 0, 0);
             }
         }
-        // ---- scale, mask (first / last tile only), running max
+        // ---- mask (first / last tile of the image only), running max on the RAW scores; the softmax scale is folded
+        //      into the exponent: p = exp2(s*sc - m*sc) is one FMA + one v_exp per element
         const int mt = m_begin + it * KT;
-        const bool edge = (mt < tok0) || (mt + KT > tok1);
-        float mloc = -INFINITY;
+        if ((mt < tok0) || (mt + KT > tok1)) {               // wave-uniform
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
+            for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kt2][r] * p.sc;
-                if (edge) {
+                for (int r = 0; r < 16; ++r) {
                     const int key = mt + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key < tok0 || key >= tok1) v = -INFINITY;
+                    if (key < tok0 || key >= tok1) s[kt2][r] = -INFINITY;
                 }
-                s[kt2][r] = v;
-                mloc = fmaxf(mloc, v);
-            }
+        }
+        float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[0][r]), s[1][r]);     // v_max3_f32
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);             // finite: every image's first tile holds >= 1 valid key
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        const float msc = m_new * p.sc;
         float psum = 0.f;
         uint32_t pb[2][8];
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(s[kt2][r] - m_new);
-                const float p1 = __builtin_amdgcn_exp2f(s[kt2][r + 1] - m_new);
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r], p.sc, -msc));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r + 1], p.sc, -msc));
                 psum += p0 + p1;
                 pb[kt2][r >> 1] = pack_bf16(p0, p1);
             }
-        l_run = l_run * alpha + psum;
+        if (__any(m_new > m_run)) {                          // wave-uniform: most tiles leave every row's max unchanged
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += psum;
 
         // ---- O^T += V^T P^T : chunk c = 16 keys; P operand = 4 packed words of s[c>>1], regs 8*(c&1) .. +8
 #pragma unroll

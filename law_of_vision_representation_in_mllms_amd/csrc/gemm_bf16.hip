@@ -117,12 +117,22 @@ int launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_visrep_gemm_variant = 1;
+int g_visrep_gemm_dbg = 0;
 
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
     if (a.N % BN != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N must be a multiple of 128 and K of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
-    if (g_visrep_gemm_variant == 2 && visrep_gemm_v2_supports(a)) return visrep_gemm_v2_dispatch(a, s);
+    if (g_visrep_gemm_variant == 3 && visrep_gemm_v3_supports(a)) {
+        GemmArgs b = a;
+        b.dbg = g_visrep_gemm_dbg;
+        return visrep_gemm_v3_dispatch(b, s);
+    }
+    if (g_visrep_gemm_variant >= 2 && visrep_gemm_v2_supports(a)) {
+        GemmArgs b = a;
+        b.dbg = g_visrep_gemm_dbg;
+        return visrep_gemm_v2_dispatch(b, s);
+    }
     switch (a.epi) {
         case EPI_BIAS: return launch<EPI_BIAS>(a, s);
         case EPI_ACT: return launch<EPI_ACT>(a, s);

@@ -24,16 +24,27 @@
 // Barrier / hazard ledger (s = stream index of a K-tile, stage = s & 3; "instance" = global s_barrier count):
 //   group 0:  L0(s) | b 4s+1 | M0(s) | b 4s+2 | L1(s) | b 4s+3 | M1(s) | b 4s+4
 //   group 1:  (extra barrier = instance 1)  L0(s) | b 4s+2 | M0(s) | b 4s+3 | L1(s) | b 4s+4 | M1(s) | b 4s+5
+//   L segments: issue the fragment ds_reads, issue this wave's two LDS-DMA loads under the read latency, retire the
+//   reads (lgkmcnt(0)), barrier.  M segments: 16 back-to-back MFMAs, nothing else (an LDS-DMA issue costs the issuing
+//   wave ~60 cycles, which would come straight out of the matrix pipe if it sat between MFMAs - measured).
 //   issue:    group 0: W-pair of tile s+2 in L0(s), X-pair of tile s+3 in L1(s);  group 1: X/W pairs of s+3 in L0/L1(s)
-//   RAW:      tile s+1 is first read after instance 4s+4.  Before arriving there group 0 waits vmcnt(6) (outstanding:
-//             tile s+2 = 4, X-pair of s+3 = 2) and group 1 waits vmcnt(8) (tiles s+2, s+3) -> tile s+1 has landed.
-//   WAR:      stage (s+3)&3 was last read in tile s-1 (group 1's L1(s-1), retired by its lgkmcnt(0) after instance
-//             4s); the earliest overwrite is issued after instance 4s+1.
+//   RAW:      tile s+1 is first read after instance 4s+4.  Before arriving there group 0 waits vmcnt(6) at the end of
+//             M1(s) (outstanding: tile s+2 = 4, X-pair of s+3 = 2) and group 1 waits vmcnt(8) in L1(s) (tiles s+2,
+//             s+3) -> tile s+1 has landed.
+//   WAR:      stage (s+3)&3 was last read in tile s-1 (latest: group 1's L1(s-1), retired before instance 4s); the
+//             earliest overwrite is issued after instance 4s+1.
 #include <type_traits>
 
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "visrep_internal.h"
+
+// timing-only ablation (tools/gemm_ablate.py builds a separate library with -DVISREP_GEMM_ABLATE; production code has DBG == 0)
+#ifdef VISREP_GEMM_ABLATE
+#define DBG (p.dbg)
+#else
+#define DBG 0
+#endif
 
 namespace {
 
@@ -46,6 +57,31 @@ constexpr int LDS2 = NSTAGE * STAGE2;           // 128 KB
 VR_DEV void wait_vm6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 VR_DEV void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 VR_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+VR_DEV void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Fragment reads are hand-written: hipcc's waitcnt pass cannot tell an LDS read from the bytes an in-flight LDS-DMA will
+// write, so a ds_read it can see gets an s_waitcnt vmcnt(0) in front of it every K-tile, which drains the whole prefetch
+// ring.  The loads and their lgkmcnt(0) live in ONE asm statement (early-clobber outputs), so no consumer and no
+// register copy can be scheduled between issue and arrival; ordering against the DMA is the ledger above.
+VR_DEV unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+VR_DEV void lds_issue8(bf16x8 (&a)[4], bf16x8 (&b)[4], unsigned aaddr, unsigned baddr) {
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+        "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+        : "v"(aaddr), "v"(baddr));
+}
+VR_DEV void lds_issue4(bf16x8 (&a)[4], unsigned aaddr) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+        : "v"(aaddr));
+}
+// the wait names every destination read-write: nothing that consumes (or copies) them can be scheduled above it
+VR_DEV void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+VR_DEV void lds_wait4(bf16x8 (&a)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
 VR_DEV void barrier() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -129,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
     if (grp == 1) { issue_w(); wait_vm8(); } else { wait_vm6(); }
     barrier();                                                 // tile 0 visible to every wave
 
+    const unsigned lds0 = lds_addr(smem);
     auto body = [&](auto G_) {
         constexpr int G = decltype(G_)::value;
         f32x4 acc[8][4];
@@ -139,40 +176,44 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
         int kt = 0, ti = 0;
         if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
         for (int s = 0; s < S; ++s) {
-            const char* sb = smem + (s & 3) * STAGE2;
+            const unsigned sb = lds0 + (unsigned)(s & 3) * STAGE2;
             bf16x8 xf[4], wf[4];
-            // ---------------- L0
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + woff + i * 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xoff + i * 1024);
-            if (G == 0) issue_w(); else issue_x();
-            barrier();
-            // ---------------- M0
+            // ---------------- L0: W fragments (4) + X fragments of rows 0..63 (4); the wave's two LDS-DMA loads are issued
+            //                  under the LDS read latency; everything is retired before the barrier
+            if (!(DBG & 4)) lds_issue8(wf, xf, sb + woff, sb + xoff);
+            if (!(DBG & 2)) { if (G == 0) issue_w(); else issue_x(); }
+            lds_wait8(wf, xf);
+            barrier();                                         // fragments are in registers: M starts on the matrix pipe at once
+            // ---------------- M0: 16 MFMAs, nothing else
             __builtin_amdgcn_s_setprio(1);
+            if (!(DBG & 1))
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (EPI == EPI_VT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[j], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
                 }
+            }
             __builtin_amdgcn_s_setprio(0);
             barrier();
-            // ---------------- L1
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xoff + (4 + i) * 1024);
-            if (G == 0) issue_x(); else { issue_w(); wait_vm8(); }
+            // ---------------- L1: X fragments of rows 64..127 + this wave's other two LDS-DMA loads
+            if (!(DBG & 4)) lds_issue4(xf, sb + xoff + 4096);
+            if (!(DBG & 2)) { if (G == 0) issue_x(); else issue_w(); }
+            if (G == 1) wait_vm8();
+            lds_wait4(xf);
             barrier();
             // ---------------- M1
             __builtin_amdgcn_s_setprio(1);
+            if (!(DBG & 1))
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (EPI == EPI_VT) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[j], acc[4 + i][j], 0, 0, 0);
                     else acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[4 + i][j], 0, 0, 0);
                 }
+            }
             __builtin_amdgcn_s_setprio(0);
             if (G == 0) wait_vm6();
             if (++kt == nk) {

@@ -1,42 +1,61 @@
-// Shared fused epilogues of the bf16 GEMM kernels (v1 128x128 and v2 256x256).
+// Shared fused epilogues of the bf16 GEMM kernels (v1 128x128, v2 / v3 256x256).
 //
-// Accumulator layout per 16x16 MFMA fragment acc[i][j] (see gemm_bf16.hip):
-//   row-major epilogues ("swapped" operands): lane holds C[m = mb + 16 i + fr][n = nb + 16 j + 4 fg + (0..3)]
-//   V^T epilogue (plain operand order):       lane holds C[m = mb + 16 i + 4 fg + (0..3)][n = nb + 16 j + fr]
+// Accumulator layouts.  ACC = f32x4 (MFMA 16x16x32: RBLK = 16, QN = 1) or f32x16 (MFMA 32x32x16: RBLK = 32, QN = 4);
+// `fr` = lane & (RBLK-1), `hg` = lane / RBLK (0..3 resp. 0..1); register r = 4q + e:
+//   row-major epilogues ("swapped" operands):  C[m = mb + RBLK i + fr][n = nb + RBLK j + 8q + 4hg + e]
+//   V^T epilogue (plain operand order):        C[m = mb + RBLK i + 8q + 4hg + e][n = nb + RBLK j + fr]
+// so every (i, j, q) is four consecutive n (resp. m): one 8-byte bf16x4 store.
 //
-// Structure matters more than arithmetic here: every optional vector (bias, LayerScale) is loaded ONCE under a single
-// hoisted uniform branch, and residual / position rows are loaded with clamped (always valid) addresses so that no
-// load sits behind a per-element branch - hipcc otherwise emits branch + s_waitcnt vmcnt(0) per element, i.e. dozens
-// of serialized L2 round trips per tile (and, in v2, a drained LDS-DMA queue).  Only the stores are predicated.
+// Structure matters more than arithmetic here:
+//   * every optional vector (bias, LayerScale) is loaded ONCE under a single hoisted uniform branch, the activation
+//     kind and "does this wave tile touch the M edge" are decided ONCE (uniform), and residual / position rows are loaded
+//     with clamped (always valid) addresses in row groups before the group's first store - hipcc otherwise emits branch
+//     + s_waitcnt vmcnt(0) per element, i.e. dozens of serialized L2 round trips per tile;
+//   * output stores are hand-written and the hoisted vector loads are retired with a compiler-VISIBLE s_waitcnt: the
+//     persistent kernels re-enter their K loop after an epilogue, and any VMEM operation hipcc still considers pending
+//     there makes it put an s_waitcnt vmcnt(0) at the loop header - in front of every K-tile - which would drain the
+//     LDS-DMA prefetch ring each iteration (verified in the ISA).  Stores the compiler cannot see leave nothing
+//     pending; the hardware still retires them in order with the counted waits of the main loop.
 #pragma once
 #include "common.h"
 #include "visrep_internal.h"
 
-template <int EPI, int NI, int NJ, int ACT, bool EDGE>
-VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const f32x4 (&acc)[NI][NJ], int mb, int nb, int fr, int fg) {
-    float4 bv[NJ], lv[NJ];
+VR_DEV void store_b64(void* ptr, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ptr), "v"(v) : "memory"); }
+VR_DEV void store_b128(void* ptr, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
+VR_DEV void drain_visible_loads() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+
+template <typename ACC> struct AccGeom { static constexpr int QN = sizeof(ACC) / 16, RBLK = QN == 1 ? 16 : 32; };
+
+template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, typename ACC>
+VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK, NC = NJ * QN;   // NC column groups of 4 per lane
+    float4 bv[NC], lv[HAS_LS ? NC : 1];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { bv[j] = float4{0.f, 0.f, 0.f, 0.f}; lv[j] = float4{1.f, 1.f, 1.f, 1.f}; }
+    for (int c = 0; c < NC; ++c) bv[c] = float4{0.f, 0.f, 0.f, 0.f};
+    auto col = [&](int c) { return nb + (c / QN) * RBLK + (c % QN) * 8 + hg * 4; };
     if (p.bias) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + nb + j * 16 + fg * 4);
+        for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const float4*>(p.bias + col(c));
     }
-    if (EPI == EPI_RESID && p.ls) {
+    if (HAS_LS) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) lv[j] = *reinterpret_cast<const float4*>(p.ls + nb + j * 16 + fg * 4);
+        for (int c = 0; c < NC; ++c) lv[c] = *reinterpret_cast<const float4*>(p.ls + col(c));
     }
+    drain_visible_loads();
     // rows are processed in groups of RB: all residual / position loads of a group are issued before its first store
     // (in-place residual: loads and stores alias as far as the compiler knows, so source order is the only batching tool)
-    constexpr int RB = 4;
+    constexpr int INFLIGHT = (HAS_LS || QN > 1) ? 8 : 16;   // residual loads in flight per lane (register budget)
+    constexpr int RB0 = (INFLIGHT / NC) < 1 ? 1 : ((INFLIGHT / NC) > NI ? NI : (INFLIGHT / NC));
+    constexpr int RB = EPI == EPI_PATCH ? 1 : RB0;          // position rows are float4: one row at a time
 #pragma unroll
     for (int i0 = 0; i0 < NI; i0 += RB) {
         bool ok[RB];
         size_t orow[RB];
-        u32x2 rv[RB][NJ];
-        float4 pv[RB][NJ];
+        u32x2 rv[RB][NC];
+        float4 pv[RB][NC];
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
-            const int m = mb + (i0 + ii) * 16 + fr;
+            const int m = mb + (i0 + ii) * RBLK + fr;
             ok[ii] = EDGE ? (m < p.M) : true;               // interior tiles: no exec-masked region at all
             const int mc = ok[ii] ? m : p.M - 1;
             orow[ii] = (size_t)mc;
@@ -48,34 +67,35 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const f32x4 (&acc)[NI
             }
             if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) rv[ii][j] = *reinterpret_cast<const u32x2*>(p.resid + orow[ii] * p.ldc + nb + j * 16 + fg * 4);
+                for (int c = 0; c < NC; ++c) rv[ii][c] = *reinterpret_cast<const u32x2*>(p.resid + orow[ii] * p.ldc + col(c));
             }
             if (EPI == EPI_PATCH) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) pv[ii][j] = *reinterpret_cast<const float4*>(posrow + nb + j * 16 + fg * 4);
+                for (int c = 0; c < NC; ++c) pv[ii][c] = *reinterpret_cast<const float4*>(posrow + col(c));
             }
         }
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
             const int i = i0 + ii;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nb + j * 16 + fg * 4;
-                float v0 = acc[i][j][0] + bv[j].x, v1 = acc[i][j][1] + bv[j].y, v2 = acc[i][j][2] + bv[j].z, v3 = acc[i][j][3] + bv[j].w;
+            for (int c = 0; c < NC; ++c) {
+                const int j = c / QN, q = c % QN, n = col(c);
+                float v0 = acc[i][j][4 * q + 0] + bv[c].x, v1 = acc[i][j][4 * q + 1] + bv[c].y;
+                float v2 = acc[i][j][4 * q + 2] + bv[c].z, v3 = acc[i][j][4 * q + 3] + bv[c].w;
                 if (EPI == EPI_ACT) {
                     v0 = apply_act(v0, ACT); v1 = apply_act(v1, ACT); v2 = apply_act(v2, ACT); v3 = apply_act(v3, ACT);
                 }
                 if (EPI == EPI_RESID) {
-                    v0 = bf_lo(rv[ii][j][0]) + v0 * lv[j].x; v1 = bf_hi(rv[ii][j][0]) + v1 * lv[j].y;
-                    v2 = bf_lo(rv[ii][j][1]) + v2 * lv[j].z; v3 = bf_hi(rv[ii][j][1]) + v3 * lv[j].w;
+                    if (HAS_LS) { v0 *= lv[c].x; v1 *= lv[c].y; v2 *= lv[c].z; v3 *= lv[c].w; }
+                    v0 += bf_lo(rv[ii][c][0]); v1 += bf_hi(rv[ii][c][0]); v2 += bf_lo(rv[ii][c][1]); v3 += bf_hi(rv[ii][c][1]);
                 }
-                if (EPI == EPI_PATCH) { v0 += pv[ii][j].x; v1 += pv[ii][j].y; v2 += pv[ii][j].z; v3 += pv[ii][j].w; }
+                if (EPI == EPI_PATCH) { v0 += pv[ii][c].x; v1 += pv[ii][c].y; v2 += pv[ii][c].z; v3 += pv[ii][c].w; }
                 if (ok[ii]) {
                     if (EPI == EPI_F32) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + orow[ii] * p.ldc + n) = float4{v0, v1, v2, v3};
+                        store_b128(reinterpret_cast<float*>(p.C) + orow[ii] * p.ldc + n, f32x4{v0, v1, v2, v3});
                     } else {
                         u32x2 o = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
-                        *reinterpret_cast<u32x2*>(p.C + orow[ii] * p.ldc + n) = o;
+                        store_b64(p.C + orow[ii] * p.ldc + n, o);
                     }
                 }
             }
@@ -83,49 +103,58 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const f32x4 (&acc)[NI
     }
 }
 
-// the activation kind and "does this wave tile touch the M edge" are uniform runtime values: branch ONCE, outside the
-// per-element code (an interior tile then has no exec-masked region, so hipcc cannot sink the residual loads into one)
-template <int EPI, int NI, int NJ, int ACT>
-VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const f32x4 (&acc)[NI][NJ], int mb, int nb, int fr, int fg) {
-    if (mb + NI * 16 <= p.M) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false>(p, acc, mb, nb, fr, fg);
-    else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true>(p, acc, mb, nb, fr, fg);
+template <int EPI, int NI, int NJ, int ACT, typename ACC>
+VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    const bool interior = mb + NI * AccGeom<ACC>::RBLK <= p.M;
+    if (EPI == EPI_RESID && p.ls) {                          // LayerScale towers (DINOv2): its own path keeps the others lean
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true>(p, acc, mb, nb, fr, hg);
+    } else {
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false>(p, acc, mb, nb, fr, hg);
+    }
 }
 
-template <int EPI, int NI, int NJ>
-VR_DEV void gemm_epilogue_rowmajor(const GemmArgs& p, const f32x4 (&acc)[NI][NJ], int mb, int nb, int fr, int fg) {
+template <int EPI, int NI, int NJ, typename ACC>
+VR_DEV void gemm_epilogue_rowmajor(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     if (EPI == EPI_ACT) {
         switch (p.act) {
-            case ACT_QUICK_GELU: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_QUICK_GELU>(p, acc, mb, nb, fr, fg); break;
-            case ACT_GELU_ERF: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_ERF>(p, acc, mb, nb, fr, fg); break;
-            case ACT_GELU_TANH: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_TANH>(p, acc, mb, nb, fr, fg); break;
-            default: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, fg); break;
+            case ACT_QUICK_GELU: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_QUICK_GELU>(p, acc, mb, nb, fr, hg); break;
+            case ACT_GELU_ERF: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_ERF>(p, acc, mb, nb, fr, hg); break;
+            case ACT_GELU_TANH: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_TANH>(p, acc, mb, nb, fr, hg); break;
+            default: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, hg); break;
         }
     } else {
-        gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, fg);
+        gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, hg);
     }
 }
 
 // V^T scatter: vt[n * ldc + perm16(m)], four consecutive tokens per 8-byte store (layout: see attention.hip)
-template <int NI, int NJ>
-VR_DEV void gemm_epilogue_vt(const GemmArgs& p, const f32x4 (&acc)[NI][NJ], int mb, int nb, int fr, int fg) {
+template <int NI, int NJ, typename ACC>
+VR_DEV void gemm_epilogue_vt(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK;
     float bj[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bj[j] = 0.f;
     if (p.bias) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bj[j] = p.bias[nb + j * 16 + fr];
+        for (int j = 0; j < NJ; ++j) bj[j] = p.bias[nb + j * RBLK + fr];
     }
+    drain_visible_loads();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        bf16_t* col = p.C + (size_t)(nb + j * 16 + fr) * p.ldc;
+        bf16_t* colp = p.C + (size_t)(nb + j * RBLK + fr) * p.ldc;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int m = mb + i * 16 + fg * 4;                                   // multiple of 4
-            if (m < p.M) {                                                           // columns >= M are never read unmasked
-                const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-token groups 1 <-> 2
-                u32x2 v = {pack_bf16(acc[i][j][0] + bj[j], acc[i][j][1] + bj[j]), pack_bf16(acc[i][j][2] + bj[j], acc[i][j][3] + bj[j])};
-                *reinterpret_cast<u32x2*>(col + mp) = v;
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const int m = mb + i * RBLK + q * 8 + hg * 4;                       // multiple of 4
+                if (m < p.M) {                                                       // columns >= M are never read unmasked
+                    const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-token groups 1 <-> 2
+                    u32x2 v = {pack_bf16(acc[i][j][4 * q + 0] + bj[j], acc[i][j][4 * q + 1] + bj[j]),
+                               pack_bf16(acc[i][j][4 * q + 2] + bj[j], acc[i][j][4 * q + 3] + bj[j])};
+                    store_b64(colp + mp, v);
+                }
             }
-        }
     }
 }

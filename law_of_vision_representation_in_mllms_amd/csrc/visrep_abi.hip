@@ -15,9 +15,15 @@ int visrep_set_error(int code, const char* msg) {
 extern "C" int visrep_version(void) { return VISREP_VERSION; }
 
 extern "C" int visrep_set_gemm_variant(int variant) {
-    if (variant != 1 && variant != 2) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1 or 2");
+    if (variant < 1 || variant > 3) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1, 2 or 3");
     const int old = g_visrep_gemm_variant;
     g_visrep_gemm_variant = variant;
+    return old;
+}
+
+extern "C" int visrep_debug_gemm_ablation(int mask) {   // timing experiments only: results are WRONG when mask != 0
+    const int old = g_visrep_gemm_dbg;
+    g_visrep_gemm_dbg = mask;
     return old;
 }
 

@@ -401,6 +401,84 @@ def gen_vit_hip():
     print("vit_hip.npz", [(k, out[k].shape) for k in out if k.endswith(".feat")])
 
 
+# ----------------------------------------------------------------------------- mini SPair-71k tree (host loaders + eval)
+def gen_spair():
+    """A synthetic SPair-71k-shaped tree (JSON annotations only, committed under tests/golden/mini_spair) and what the
+    reference's loader / evaluator produce for it: utils_dataset.load_spair_data and pck_train.eval (zero-shot config)."""
+    import json
+    import shutil
+    sys.path.insert(0, f"{REF}/C_score")
+    _stub_modules()
+    import utils.utils_dataset as UD
+    import pck_train as PT
+    rs = np.random.RandomState(41)
+    root = f"{HERE}/mini_spair"
+    shutil.rmtree(root, ignore_errors=True)
+    cats = {"aeroplane": (4, 5, 12), "cat": (3, 4, 9)}          # images, pairs, annotated kps (of the 30 slots)
+    sizes = {}
+    for cat, (n_img, n_pairs, n_kp) in cats.items():
+        os.makedirs(f"{root}/ImageAnnotation/{cat}")
+        os.makedirs(f"{root}/PairAnnotation/test", exist_ok=True)
+        for i in range(n_img):
+            w, h = int(rs.randint(200, 640)), int(rs.randint(200, 640))
+            if i == 0:
+                h = w                                              # a square image: no padding branch
+            sizes[(cat, i)] = (w, h)
+            kps = {}
+            for k in range(30):
+                kps[str(k)] = [int(rs.randint(5, w - 5)), int(rs.randint(5, h - 5))] if (k < n_kp and rs.rand() > 0.25) else None
+            kps["0"] = [int(w // 3), int(h // 2)]
+            with open(f"{root}/ImageAnnotation/{cat}/img{i}.json", "w") as f:
+                json.dump({"kps": kps, "image_width": w, "image_height": h}, f)
+        for pi in range(n_pairs):
+            a, b = rs.choice(n_img, 2, replace=False)
+            (wa, ha), (wb, hb) = sizes[(cat, a)], sizes[(cat, b)]
+            bb = lambda w, h: [int(w * 0.1), int(h * 0.15), int(w * rs.uniform(0.6, 0.95)), int(h * rs.uniform(0.6, 0.95))]
+            with open(f"{root}/PairAnnotation/test/{pi:03d}-img{a}-img{b}:{cat}.json", "w") as f:
+                json.dump({"category": cat, "src_imname": f"img{a}.jpg", "trg_imname": f"img{b}.jpg", "src_bndbox": bb(wa, ha),
+                           "trg_bndbox": bb(wb, hb), "src_imsize": [wa, ha, 3], "trg_imsize": [wb, hb, 3]}, f)
+    out = {}
+    for cat in cats:
+        files, kps, thr, used = UD.load_spair_data(root, size=840, category=cat, split="test", subsample=0)
+        out[f"{cat}.files"] = np.array([os.path.relpath(f, root) for f in files])
+        out[f"{cat}.kps"] = kps.numpy()
+        out[f"{cat}.thr"] = np.array(thr, np.float64)
+        out[f"{cat}.used"] = used.numpy()
+    # features for every image (seeded, regenerated by the test) + the reference's zero-shot eval on them
+    P, C = 16, 32
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(f"{tmp}/data")
+        shutil.copytree(root, f"{tmp}/data/SPair-71k")
+        frs = np.random.RandomState(43)
+        for cat, (n_img, _, _) in cats.items():
+            os.makedirs(f"{tmp}/data/SPair-71k/features/{cat}")
+            base = frs.standard_normal((1, C, P, P)).astype(np.float32)
+            for i in range(n_img):
+                m = 0.7 * base + 0.3 * frs.standard_normal((1, C, P, P)).astype(np.float32)
+                torch.save(torch.from_numpy(m), f"{tmp}/data/SPair-71k/features/{cat}/img{i}_dino.pt")
+                out[f"feat.{cat}.{i}"] = m
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            PT.load_img_and_kps = lambda idx, files, kps, img_size=224, edge=False: (None, kps[idx])
+            PT.device = "cpu"
+            _gpd = PT.get_patch_descriptors
+            PT.get_patch_descriptors = lambda *a, **k: _gpd(*a, **{**k, "device": "cpu"})
+            PT.logger = sys.modules["loguru"].logger
+            args = argparse.Namespace(NUM_PATCHES=P, COMPUTE_GEOAWARE_METRICS=False, ADAPT_FLIP=False, EVAL_DATASET="spair",
+                                      TRAIN_DATASET="spair", ANNO_SIZE=840, ENSEMBLE=1, MODEL="dino", SOFT_EVAL=True,
+                                      SOFT_EVAL_WINDOW=5, KPT_RESULT=False, TOTAL_SAVE_RESULT=0, MUTUAL_NN=False, TEST_SAMPLE=0,
+                                      BBOX_THRE=True)
+            p10, p05, p01, results = PT.eval(args, PT.DummyAggregationNetwork(), tmp, split="test")
+        finally:
+            os.chdir(cwd)
+    out["eval.pck"] = np.array([p10, p05, p01], np.float64)
+    out["eval.pred"] = np.stack([r["src_kpts_pred"] for r in results]).astype(np.float32)
+    out["meta"] = np.array([P, C], np.int64)
+    np.savez_compressed(f"{HERE}/spair_host.npz", **out)
+    print("spair_host.npz  eval pck:", out["eval.pck"])
+
+
 # ----------------------------------------------------------------------------- projector
 def gen_projector():
     ph = types.ModuleType("ref_proj.perceiver_helpers")
@@ -432,7 +510,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "projector"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "projector": gen_projector}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector}[w]()

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(params=[1, 2], ids=["gemm_v1_128", "gemm_v2_256"])
+@pytest.fixture(params=[1, 2, 3], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v3_256"])
 def gemm_variant(request):
     """Run a test under both GEMM kernel families (v2 falls back to v1 when N % 256 != 0)."""
     lib = _lib.load()
@@ -52,7 +52,7 @@ def ref_act(x, kind):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (1731, 384, 1024), (577 * 4, 1024, 256), (256 * 9 + 77, 512, 32), (70000, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 192), (1731, 384, 1024), (577 * 4, 1024, 256), (256 * 9 + 77, 512, 64), (70000, 256, 1024)])
 def test_gemm_bias_and_f32(M, N, K, gemm_variant):
     g = torch.Generator().manual_seed(M + N + K)
     a = bf(torch.randn(M, K, generator=g)).to(DEV)
