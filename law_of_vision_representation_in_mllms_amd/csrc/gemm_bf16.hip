@@ -116,7 +116,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int g_visrep_gemm_variant = 1;
+int g_visrep_gemm_variant = 2;
 int g_visrep_gemm_dbg = 0;
 
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {

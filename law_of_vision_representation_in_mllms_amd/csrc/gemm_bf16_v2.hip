@@ -51,11 +51,11 @@ namespace {
 constexpr int TM = 256, TN = 256, TK = 32;
 constexpr int XW_BYTES = 256 * TK * 2;          // 16 KB per operand tile
 constexpr int STAGE2 = 2 * XW_BYTES;            // 32 KB
-constexpr int NSTAGE = 4;
+constexpr int NSTAGE = 4;                      // 128 KB ring (5 stages = all 160 KB measured identical: not latency-bound)
 constexpr int LDS2 = NSTAGE * STAGE2;           // 128 KB
 
-VR_DEV void wait_vm6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-VR_DEV void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+VR_DEV void wait_g0() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 4 * (NSTAGE - 4)) : "memory"); }
+VR_DEV void wait_g1() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 4 * (NSTAGE - 4)) : "memory"); }
 VR_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 VR_DEV void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Fragment reads are hand-written: hipcc's waitcnt pass cannot tell an LDS read from the bytes an in-flight LDS-DMA will
@@ -142,13 +142,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
     cx.k = cw.k = 0; cx.ti = cw.ti = 0; cx.idx = cw.idx = 0;
     set_x(cx); set_w(cw);
     auto issue_x = [&]() {
-        char* dst = smem + (cx.idx & 3) * STAGE2 + wave * 2048;
+        char* dst = smem + (cx.idx % NSTAGE) * STAGE2 + wave * 2048;
         glds16(cx.p0 + cx.k, dst); glds16(cx.p1 + cx.k, dst + 1024);
         ++cx.idx; cx.k += TK;
         if (cx.k == p.K) { cx.k = 0; ++cx.ti; set_x(cx); }
     };
     auto issue_w = [&]() {
-        char* dst = smem + (cw.idx & 3) * STAGE2 + XW_BYTES + wave * 2048;
+        char* dst = smem + (cw.idx % NSTAGE) * STAGE2 + XW_BYTES + wave * 2048;
         glds16(cw.p0 + cw.k, dst); glds16(cw.p1 + cw.k, dst + 1024);
         ++cw.idx; cw.k += TK;
         if (cw.k == p.K) { cw.k = 0; ++cw.ti; set_w(cw); }
@@ -161,8 +161,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
     const int woff = XW_BYTES + wn * 64 * 64 + foff;           // + ni*1024
 
     // ---- prologue: tiles 0,1 (+2: group 1 fully, group 0 X-pair only) — leaves both groups in steady-state counts
-    issue_x(); issue_w(); issue_x(); issue_w(); issue_x();
-    if (grp == 1) { issue_w(); wait_vm8(); } else { wait_vm6(); }
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 2; ++t) { issue_x(); issue_w(); }
+    issue_x();
+    if (grp == 1) { issue_w(); wait_g1(); } else { wait_g0(); }
     barrier();                                                 // tile 0 visible to every wave
 
     const unsigned lds0 = lds_addr(smem);
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
         int kt = 0, ti = 0;
         if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
         for (int s = 0; s < S; ++s) {
-            const unsigned sb = lds0 + (unsigned)(s & 3) * STAGE2;
+            const unsigned sb = lds0 + (unsigned)(s % NSTAGE) * STAGE2;
             bf16x8 xf[4], wf[4];
             // ---------------- L0: W fragments (4) + X fragments of rows 0..63 (4); the wave's two LDS-DMA loads are issued
             //                  under the LDS read latency; everything is retired before the barrier
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
             // ---------------- L1: X fragments of rows 64..127 + this wave's other two LDS-DMA loads
             if (!(DBG & 4)) lds_issue4(xf, sb + xoff + 4096);
             if (!(DBG & 2)) { if (G == 0) issue_x(); else issue_w(); }
-            if (G == 1) wait_vm8();
+            if (G == 1) wait_g1();
             lds_wait4(xf);
             barrier();
             // ---------------- M1
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
                 }
             }
             __builtin_amdgcn_s_setprio(0);
-            if (G == 0) wait_vm6();
+            if (G == 0) wait_g0();
             if (++kt == nk) {
                 // ------------------------------------------------ epilogue of output tile ti
                 kt = 0;

@@ -1,0 +1,140 @@
+"""GPU tests of the drop-in surface: tower classes, '.'-fusion + mm_projector (encode_images), feature dump, A_score.compute
+and C_score.extract_feature / pck_train on device — each against the CPU oracle on the same inputs."""
+import argparse
+import os
+import shutil
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+sys.path.insert(0, os.path.dirname(__file__))
+from test_host_cscore import G, make_tree, eval_args  # noqa: E402
+
+from law_of_vision_representation_in_mllms_amd import vit_weights as VW  # noqa: E402
+from law_of_vision_representation_in_mllms_amd.A_score import compute as AC  # noqa: E402
+from law_of_vision_representation_in_mllms_amd.C_score import extract_feature as EF  # noqa: E402
+from law_of_vision_representation_in_mllms_amd.C_score import pck_train as PT  # noqa: E402
+from law_of_vision_representation_in_mllms_amd.llava.model import llava_arch as LA  # noqa: E402
+from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import _vit_tower as VT  # noqa: E402
+from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_projector.builder import build_vision_projector  # noqa: E402
+from oracle import ascore as OA, projector as OP, vit as OV  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture
+def small_towers(monkeypatch):
+    """Registry ids keep their names but get small head_dim-64 specs so the test runs in seconds."""
+    specs = {
+        'openai/clip-vit-large-patch14': VW.tiny_spec("clip", image_size=42, patch=14, d=128, heads=2, mlp=256, layers=3),
+        'openai/clip-vit-large-patch14-336': VW.tiny_spec("clip", image_size=56, patch=14, d=128, heads=2, mlp=256, layers=3),
+        'facebook/dinov2-large': VW.tiny_spec("dinov2", image_size=42, patch=14, d=128, heads=2, mlp=256, layers=3),
+        'google/siglip-base-patch16-224': VW.tiny_spec("siglip", image_size=48, patch=16, d=128, heads=2, mlp=256, layers=3),
+    }
+    monkeypatch.setattr(VW, "SPECS", {**VW.SPECS, **specs})
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    return specs
+
+
+def tower_oracle(spec, px, select_feature):
+    w = VW.synthetic_weights(spec, seed=1)
+    return OV.tower_features(spec, w, px, -2, select_feature)
+
+
+def test_tower_classes_match_oracle(small_towers):
+    for name, builder_key, sel in [('openai/clip-vit-large-patch14', 'openai/clip-vit-large-patch14', 'patch'),
+                                   ('facebook/dinov2-large', 'facebook/dinov2-large', 'patch'),
+                                   ('google/siglip-base-patch16-224', 'google/siglip-base-patch16-224', 'cls_patch')]:
+        cfg = SimpleNamespace(mm_vision_tower=name, mm_vision_select_layer=-2, mm_vision_select_feature='patch')
+        tower = LA.build_function_mapping[builder_key](cfg)
+        spec = small_towers[name]
+        px = torch.randn(3, 3, spec.image_size, spec.image_size)
+        out = tower(px)
+        assert out.dtype == px.dtype and out.shape == (3, spec.tokens - (1 if sel == 'patch' else 0), spec.d)
+        assert rel(out, tower_oracle(spec, px, sel)) < 2e-2
+        lst = tower([px[0], px[1]])                                    # list-of-images path (clip_encoder.py:41-46)
+        assert len(lst) == 2 and rel(lst[1][0], out[1]) < 1e-2
+        assert tower.num_patches == spec.num_patches and tower.hidden_size == spec.d and tower.dummy_feature.shape == (1, spec.d)
+    tower.select_feature = "bogus"
+    with pytest.raises(ValueError, match="Unexpected select feature"):
+        tower(px)
+
+
+def test_projector_matches_reference_golden():
+    z = np.load(f"{G}/projector.npz")
+    # golden widths (48 -> 96) are not MFMA-tileable: the factory must refuse them loudly, not fall back
+    p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=48, hidden_size=96))
+    with pytest.raises(ValueError, match="multiples of 128"):
+        p(torch.zeros(2, 48).cuda())
+    p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=128, hidden_size=256))
+    x = torch.randn(2, 10, 128)
+    want = OP.mlp_gelu(x, [p[0].weight, p[2].weight], [p[0].bias, p[2].bias])
+    assert rel(p(x.cuda()), want) < 1e-2
+
+
+def test_fusion_stack_encode_images_and_feature_dump(small_towers, tmp_path):
+    cfg = SimpleNamespace(mm_vision_tower='openai/clip-vit-large-patch14.facebook/dinov2-large', mm_vision_select_layer=-2,
+                          mm_vision_select_feature='patch', mm_projector_type='mlp2x_gelu', hidden_size=256)
+    stack = LA.VisionEncoderStack(cfg)
+    assert cfg.mm_hidden_size == 256
+    px = torch.randn(2, 3, 42, 42)
+    feats = stack.encode_images([px, px])                               # one tensor per tower (llava_arch.py:278-285)
+    assert feats.shape == (2, 9, 256)
+    f_cat = torch.cat([tower_oracle(small_towers['openai/clip-vit-large-patch14'], px, 'patch'),
+                       tower_oracle(small_towers['facebook/dinov2-large'], px, 'patch')], dim=-1)
+    want = OP.mlp_gelu(f_cat, [stack.mm_projector[0].weight, stack.mm_projector[2].weight],
+                       [stack.mm_projector[0].bias, stack.mm_projector[2].bias])
+    assert rel(feats, want) < 3e-2
+    for i in range(3):
+        full = LA.save_tensor_to_folder(feats[0].cpu(), str(tmp_path / "dump"), max_tensors=3, exit_when_full=False)
+    assert full and sorted(os.listdir(tmp_path / "dump")) == ["tensor_1.pt", "tensor_2.pt", "tensor_3.pt"]
+
+
+def test_ascore_compute_on_device(tmp_path):
+    rs = np.random.RandomState(4)
+    data = {}
+    for sub, nt in dict(clip336=40, clip224=24, encA=33).items():
+        os.makedirs(tmp_path / sub)
+        data[sub] = []
+        for i in range(1, 6):
+            t = torch.from_numpy(rs.standard_normal((nt, 256)).astype(np.float32)).to(torch.bfloat16)
+            torch.save(t, tmp_path / sub / f"tensor_{i}.pt")
+            data[sub].append(t)
+    res = AC.compute(str(tmp_path), ["clip336", "encA"], n_images=5, verbose=False)
+    for enc in res:
+        want, _, _ = OA.a_score(data[enc], data["clip336"], data["clip224"])
+        assert abs(res[enc] - want) < 1e-4 * abs(want)
+    assert abs(res["clip336"] - 0.5 * (1 + OA.a_score(data["clip336"], data["clip224"], data["clip224"])[1])) < 1e-4
+
+
+def test_extract_feature_and_pck_train_on_device(small_towers, tmp_path):
+    # extract_feature: JPEG -> resize -> (x/255-.5)*2 -> tower -> [1, C, g, g] files named <img>_<suffix>.pt
+    src = tmp_path / "JPEGImages" / "cat"
+    os.makedirs(src)
+    rs = np.random.RandomState(6)
+    for i in range(3):
+        Image.fromarray(rs.randint(0, 255, (50 + i, 70, 3), dtype=np.uint8)).save(src / f"im{i}.jpg")
+    EF.configure("DINOv2", img_size=42, suffix="dino", batch=2)
+    EF.process_images(str(tmp_path / "JPEGImages"), str(tmp_path / "features"))
+    f = torch.load(tmp_path / "features" / "cat" / "im1_dino.pt")
+    assert f.shape == (1, 128, 3, 3)
+    one = EF.extract_features(str(src / "im1.jpg"))
+    assert rel(one, f) < 1e-2
+    spec = small_towers['facebook/dinov2-large']
+    px = EF._load_pixels(str(src / "im1.jpg"), 42).unsqueeze(0)
+    want = tower_oracle(spec, px, 'patch').permute(0, 2, 1).reshape(1, 128, 3, 3)
+    assert rel(f, want) < 2e-2
+    # pck_train.eval on the mini SPair tree, device kernels this time, against the reference's eval() result
+    root, z = make_tree(str(tmp_path / "spair"))
+    p10, p05, p01, results = PT.eval(eval_args(root, 16), PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+    np.testing.assert_allclose([p10, p05, p01], z["eval.pck"], atol=1e-7)
+    np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), z["eval.pred"], atol=5e-3)

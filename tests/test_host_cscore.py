@@ -1,0 +1,125 @@
+"""Host logic of the C-score drop-in on CPU: SPair-71k loader vs the reference loader's output, eval() aggregation vs the
+reference's eval() on a mini tree (tests/golden/mini_spair + spair_host.npz, produced by running the reference), pair
+sharding + all-reduce on 2 gloo ranks.  The two device entry points are replaced by oracle-backed CPU stand-ins through
+monkeypatching — the oracle is the checker, the product has no CPU fallback."""
+import argparse
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from law_of_vision_representation_in_mllms_amd import cscore_ops
+from law_of_vision_representation_in_mllms_amd.C_score import pck_train as PT
+from law_of_vision_representation_in_mllms_amd.C_score.utils import utils_dataset as UD
+from oracle import cscore as OC
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CATS = ("aeroplane", "cat")
+
+
+def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840):
+    n, kmax = patch_idx.shape
+    C = bank.shape[1]
+    out = torch.zeros(n, kmax, 2)
+    for i in range(n):
+        d1 = OC.descriptors_from_map(bank[int(img1[i])].view(1, C, P, P), P)
+        d2 = OC.descriptors_from_map(bank[int(img2[i])].view(1, C, P, P), P)
+        k = int(nkp[i])
+        out[i, :k] = OC.keypoint_transfer(d1, d2, patch_idx[i, :k].numpy(), P, anno_size, soft_eval, window, beta)
+    return out
+
+
+def cpu_pck_counts(xy, kps1, kps2, thresholds, nkp, alphas=(0.1, 0.05, 0.01)):
+    n = xy.shape[0]
+    cnt = torch.zeros(n, 4, dtype=torch.int32)
+    for i in range(n):
+        k = int(nkp[i])
+        _, nv, hits = OC.pair_pck(xy[i, :k], kps1[i, :k], kps2[i, :k], float(thresholds[i]), alphas)
+        cnt[i, :3] = hits.sum(dim=1).int()
+        cnt[i, 3] = nv
+    return cnt
+
+
+@pytest.fixture
+def cpu_ops(monkeypatch):
+    monkeypatch.setattr(cscore_ops, "transfer", cpu_transfer)
+    monkeypatch.setattr(cscore_ops, "pck_counts", cpu_pck_counts)
+
+
+def make_tree(tmp):
+    z = np.load(f"{G}/spair_host.npz")
+    root = os.path.join(tmp, "data", "SPair-71k")
+    shutil.copytree(f"{G}/mini_spair", root)
+    for key in z.files:
+        if key.startswith("feat."):
+            _, cat, i = key.split(".")
+            os.makedirs(f"{root}/features/{cat}", exist_ok=True)
+            torch.save(torch.from_numpy(z[key]), f"{root}/features/{cat}/img{i}_dino.pt")
+    return root, z
+
+
+def eval_args(root, P):
+    return argparse.Namespace(NUM_PATCHES=P, COMPUTE_GEOAWARE_METRICS=False, ADAPT_FLIP=False, EVAL_DATASET="spair",
+                              TRAIN_DATASET="spair", ANNO_SIZE=840, ENSEMBLE=1, MODEL="dino", SOFT_EVAL=True, SOFT_EVAL_WINDOW=5,
+                              KPT_RESULT=False, TOTAL_SAVE_RESULT=0, MUTUAL_NN=False, TEST_SAMPLE=0, BBOX_THRE=True, DATA_DIR=root)
+
+
+def test_spair_loader_matches_reference():
+    z = np.load(f"{G}/spair_host.npz")
+    root = f"{G}/mini_spair"
+    for cat in CATS:
+        files, kps, thr, used = UD.load_spair_data(root, size=840, category=cat, split="test", subsample=0)
+        assert [os.path.relpath(f, root) for f in files] == list(z[f"{cat}.files"])
+        assert torch.equal(kps, torch.from_numpy(z[f"{cat}.kps"]))
+        np.testing.assert_array_equal(np.asarray(thr, np.float64), z[f"{cat}.thr"])
+        np.testing.assert_array_equal(used.numpy(), z[f"{cat}.used"])
+
+
+def test_eval_matches_reference_eval(tmp_path, cpu_ops):
+    root, z = make_tree(str(tmp_path))
+    P, C = z["meta"].tolist()
+    pck_010, pck_005, pck_001, results = PT.eval(eval_args(root, P), PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+    np.testing.assert_allclose([pck_010, pck_005, pck_001], z["eval.pck"], atol=1e-7)
+    pred = np.stack([r["src_kpts_pred"] for r in results])
+    np.testing.assert_allclose(pred, z["eval.pred"], atol=2e-3)
+    assert results[0]["src_fn"].endswith(".jpg") and results[0]["resize_resolution"] == 840
+
+
+def test_unsupported_modes_fail_loudly(tmp_path, cpu_ops):
+    root, z = make_tree(str(tmp_path))
+    a = eval_args(root, 16)
+    a.ADAPT_FLIP = True
+    with pytest.raises(NotImplementedError):
+        PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+
+
+def _worker(rank, world, tmp, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cscore_ops.transfer, cscore_ops.pck_counts = cpu_transfer, cpu_pck_counts
+    root = os.path.join(tmp, "data", "SPair-71k")
+    res = PT.eval(eval_args(root, 16), PT.DummyAggregationNetwork(), tmp, split="test")
+    q.put((rank, res[:3], np.stack([r["src_kpts_pred"] for r in res[3]])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pair_sharding_equals_reference(tmp_path):
+    root, z = make_tree(str(tmp_path))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path), port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, pcks, pred in got:
+        np.testing.assert_allclose(pcks, z["eval.pck"], atol=1e-7)
+        np.testing.assert_allclose(pred, z["eval.pred"], atol=2e-3)
