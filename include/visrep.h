@@ -46,6 +46,9 @@ int visrep_set_gemm_variant(int variant);
 /* Timing-only ablation of GEMM variant 2 (bit 0: skip MFMAs, bit 1: skip the LDS-DMA loads, bit 2: skip the fragment reads):
  * results are WRONG for mask != 0; used by tools/gemm_ablate.py to attribute cycles.  Returns the previous mask. */
 int visrep_debug_gemm_ablation(int mask);
+/* Diagnostic builds (-DVISREP_GEMM_ABLATE) only: device buffer of 16 uint64 receiving per-segment cycle sums of variant 2
+ * (wave 0 and wave 4 of block 0); ignored by production builds. */
+int visrep_debug_gemm_timing_buffer(void* dev_u64x16);
 
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
  * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from

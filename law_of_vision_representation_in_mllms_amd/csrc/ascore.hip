@@ -150,6 +150,123 @@ __global__ void ascore_finalize(const float* __restrict__ partial, float* __rest
     score[img] = s / (float)Nt;
 }
 
+// ---- bf16 production path: LDS-staged MFMA Gram (same structure and LDS tile format as gemm_bf16.hip v1) --------------
+// One workgroup = 128 target rows of one image; it sweeps every 128-row tile of the reference and all of D with
+// double-buffered global_load_lds staging, keeps a running row max in the accumulator layout and writes one partial sum.
+// The [Nt, Nr] similarity never exists in memory; the target tile is re-streamed from L2 once per reference tile.
+constexpr int A_BM = 128, A_BN = 128, A_BK = 64;
+constexpr int A_TILE = A_BM * A_BK * 2, A_STAGE = 2 * A_TILE, A_LDS = 2 * A_STAGE;
+
+__global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntt = (p.Nt + A_BM - 1) / A_BM;
+    const int img = blockIdx.x / ntt, tt = blockIdx.x - img * ntt;
+    const bf16_t* other = reinterpret_cast<const bf16_t*>(p.other) + (size_t)img * p.Nt * p.D;
+    const bf16_t* ref = reinterpret_cast<const bf16_t*>(p.ref) + (size_t)img * p.Nr * p.D;
+    const float* cr = p.c_ref + (size_t)img * p.Nr;
+    const int m0 = tt * A_BM;
+    const int srow = tid >> 3;
+    const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
+    const bf16_t* ga[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = m0 + j * 32 + srow;
+        r = r < p.Nt ? r : p.Nt - 1;
+        ga[j] = other + (size_t)r * p.D + lslot * 8;
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = fr * 128 + (((kk * 4 + fg) ^ ((fr >> 1) & 7)) << 4);
+    const int aoff = wm * 64 * 128, woff = A_TILE + wn * 64 * 128;
+    float rowmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int nk = p.D / A_BK, nnt = (p.Nr + A_BN - 1) / A_BN;
+    for (int nt = 0; nt < nnt; ++nt) {
+        const int n0 = nt * A_BN;
+        const bf16_t* gr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int r = n0 + j * 32 + srow;
+            r = r < p.Nr ? r : p.Nr - 1;
+            gr[j] = ref + (size_t)r * p.D + lslot * 8;
+        }
+        auto stage = [&](int buf, int kt) {
+            char* sa = smem + buf * A_STAGE + wave * 1024;
+            char* sw = sa + A_TILE;
+            const int ko = kt * A_BK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(ga[j] + ko, sa + j * 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(gr[j] + ko, sw + j * 4096);
+        };
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const char* sb = smem + cur * A_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 xa[4], xr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(sb + aoff + i * 2048 + foff[kk]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(sb + woff + i * 2048 + foff[kk]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[j], xa[i], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // lane holds G[t = m0 + 64 wm + 16 i + fr][s = n0 + 64 wn + 16 j + 4 fg + e]: scale by c_ref[s], mask s >= Nr, row max
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sidx = n0 + wn * 64 + j * 16 + fg * 4;
+            float c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = (sidx + e < p.Nr) ? cr[sidx + e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (sidx + e < p.Nr) rowmax[i] = fmaxf(rowmax[i], acc[i][j][e] * c[e]);
+        }
+    }
+    // combine over the four 4-column groups (lanes fr + 16 fg), then over the two column waves, then sum the rows
+    float* red = reinterpret_cast<float*>(smem);                 // the staging buffers are dead now
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = rowmax[i];
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        rowmax[i] = v;
+    }
+    __syncthreads();
+    if (fg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wn * 2 + wm) * 64 + i * 16 + fr] = rowmax[i];
+    }
+    __syncthreads();
+    float v = 0.f;
+    if (tid < 128) {
+        const int t = m0 + tid;                                     // tid = 64 wm + 16 i + fr
+        if (t < p.Nt) v = fmaxf(red[(tid >> 6) * 64 + (tid & 63)], red[(2 + (tid >> 6)) * 64 + (tid & 63)]) * p.c_other[(size_t)img * p.Nt + t];
+    }
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[512 + wave] = v;
+    __syncthreads();
+    if (tid == 0) p.partial[blockIdx.x] = red[512] + red[513] + red[514] + red[515];
+}
+
 template <typename T>
 int run(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, float* scores, float* ws, hipStream_t s) {
     float* c_other = ws;
@@ -159,8 +276,15 @@ int run(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, fl
     hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((ro + 3) / 4)), dim3(256), 0, s, (const T*)other, ro, D, c_other);
     hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((rr + 3) / 4)), dim3(256), 0, s, (const T*)ref, rr, D, c_ref);
     AScoreArgs a{other, ref, c_other, c_ref, partial, n_img, Nt, Nr, D};
-    const int ntt = (Nt + 63) / 64;
-    hipLaunchKernelGGL(ascore_maxcos<T>, dim3(n_img * ntt), dim3(256), 0, s, a);
+    int ntt = (Nt + 63) / 64;
+    if (sizeof(T) == 2 && D % 64 == 0) {                       // production path: LDS-tiled MFMA kernel, 128-row target tiles
+        ntt = (Nt + A_BM - 1) / A_BM;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS); attr = true; }
+        hipLaunchKernelGGL(ascore_maxcos_tiled, dim3(n_img * ntt), dim3(256), A_LDS, s, a);
+    } else {
+        hipLaunchKernelGGL(ascore_maxcos<T>, dim3(n_img * ntt), dim3(256), 0, s, a);
+    }
     hipLaunchKernelGGL(ascore_finalize, dim3((n_img + 63) / 64), dim3(64), 0, s, partial, scores, n_img, ntt, Nt);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }

@@ -118,19 +118,19 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 int g_visrep_gemm_variant = 2;
 int g_visrep_gemm_dbg = 0;
+unsigned long long* g_visrep_gemm_dbg_buf = nullptr;
 
-int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
-    if (a.N % BN != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N must be a multiple of 128 and K of 64");
-    if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
-    if (g_visrep_gemm_variant == 3 && visrep_gemm_v3_supports(a)) {
+namespace {
+int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
+    if (variant == 3 && visrep_gemm_v3_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
         return visrep_gemm_v3_dispatch(b, s);
     }
-    if (g_visrep_gemm_variant >= 2 && visrep_gemm_v2_supports(a)) {
+    if (variant >= 2 && visrep_gemm_v2_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
+        b.dbg_buf = g_visrep_gemm_dbg_buf;
         return visrep_gemm_v2_dispatch(b, s);
     }
     switch (a.epi) {
@@ -142,4 +142,47 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
         case EPI_F32: return launch<EPI_F32>(a, s);
     }
     return visrep_set_error(VISREP_ERR_ARG, "gemm: unknown epilogue");
+}
+
+int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+}  // namespace
+
+int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
+    if (a.N % BN != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N must be a multiple of 128 and K of 64");
+    if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
+    const int variant = g_visrep_gemm_variant;
+    // Tile quantisation: the persistent 256x256 kernels run one block per CU, so T tiles cost ceil(T / CUs) tile-times.
+    // The BASELINE shapes have M = 256 * 577 (577 is prime): 2308 / 4616 / 9232 tiles = 9 / 18 / 36 full rounds + a 4..16-tile
+    // remainder that would cost a whole extra round on 252 idle CUs.  When the remainder is small, the rows of the last
+    // round are split off and run as 128x128 tiles (v1), which spread over many CUs and finish in a fraction of a round.
+    if (variant >= 2 && a.N % 256 == 0 && a.epi != EPI_PATCH) {
+        const int ncu = cu_count(), ntn = a.N / 256, ntm = (a.M + 255) / 256;
+        const long tiles = (long)ntm * ntn, rounds = tiles / ncu, rem = tiles % ncu;
+        if (rounds >= 1 && rem > 0 && rem * 4 <= ncu && (rounds * ncu) % ntn == 0) {
+            const int m1 = (int)(rounds * ncu / ntn) * 256;             // rows covered by the full rounds
+            if (m1 > 0 && m1 < a.M) {
+                GemmArgs head = a, tail = a;
+                head.M = m1;
+                tail.M = a.M - m1;
+                tail.A = a.A + (size_t)m1 * a.lda;
+                if (a.epi == EPI_VT) tail.C = a.C + m1;                  // V^T: token axis is the column axis (m1 % 16 == 0 keeps perm16)
+                else if (a.epi == EPI_F32) tail.C = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(a.C) + (size_t)m1 * a.ldc);
+                else tail.C = a.C + (size_t)m1 * a.ldc;
+                if (a.resid) tail.resid = a.resid + (size_t)m1 * a.ldc;
+                const int rc = dispatch_one(head, s, variant);
+                return rc ? rc : dispatch_one(tail, s, 1);
+            }
+        }
+    }
+    return dispatch_one(a, s, variant);
 }

@@ -46,6 +46,12 @@
 #define DBG 0
 #endif
 
+#ifdef VISREP_GEMM_ABLATE
+#define TSTAMP(i) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tsum[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 32;
@@ -176,18 +182,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int kt = 0, ti = 0;
-        if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
+#ifdef VISREP_GEMM_ABLATE
+        const bool timing = p.dbg_buf && blockIdx.x == 0 && wn == 0;
+        unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+        if (G == 1) barrier();
+#ifdef VISREP_GEMM_ABLATE
+        tlast = __builtin_readcyclecounter();
+#endif                                 // skew: group 1 runs one barrier interval behind
         for (int s = 0; s < S; ++s) {
             const unsigned sb = lds0 + (unsigned)(s % NSTAGE) * STAGE2;
             bf16x8 xf[4], wf[4];
             // ---------------- L0: W fragments (4) + X fragments of rows 0..63 (4); the wave's two LDS-DMA loads are issued
             //                  under the LDS read latency; everything is retired before the barrier
+            if (!(DBG & 24)) __builtin_amdgcn_s_setprio(1);   // the load segment gets the issue priority (measured +20 % vs prio on the MFMA segment)
             if (!(DBG & 4)) lds_issue8(wf, xf, sb + woff, sb + xoff);
             if (!(DBG & 2)) { if (G == 0) issue_w(); else issue_x(); }
             lds_wait8(wf, xf);
-            barrier();                                         // fragments are in registers: M starts on the matrix pipe at once
+            if (!(DBG & 24)) __builtin_amdgcn_s_setprio(0);
+            TSTAMP(0);
+            barrier();
+            TSTAMP(1);                                         // fragments are in registers: M starts on the matrix pipe at once
             // ---------------- M0: 16 MFMAs, nothing else
-            __builtin_amdgcn_s_setprio(1);
+            if (DBG & 16) __builtin_amdgcn_s_setprio(1);
             if (!(DBG & 1))
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -197,16 +214,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (DBG & 16) __builtin_amdgcn_s_setprio(0);
+            TSTAMP(2);
             barrier();
+            TSTAMP(3);
             // ---------------- L1: X fragments of rows 64..127 + this wave's other two LDS-DMA loads
+            if (!(DBG & 24)) __builtin_amdgcn_s_setprio(1);
             if (!(DBG & 4)) lds_issue4(xf, sb + xoff + 4096);
             if (!(DBG & 2)) { if (G == 0) issue_x(); else issue_w(); }
             if (G == 1) wait_g1();
             lds_wait4(xf);
+            if (!(DBG & 24)) __builtin_amdgcn_s_setprio(0);
+            TSTAMP(4);
             barrier();
+            TSTAMP(5);
             // ---------------- M1
-            __builtin_amdgcn_s_setprio(1);
+            if (DBG & 16) __builtin_amdgcn_s_setprio(1);
             if (!(DBG & 1))
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -216,8 +239,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
                     else acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[4 + i][j], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (DBG & 16) __builtin_amdgcn_s_setprio(0);
             if (G == 0) wait_g0();
+            TSTAMP(6);
             if (++kt == nk) {
                 // ------------------------------------------------ epilogue of output tile ti
                 kt = 0;
@@ -231,8 +255,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
                     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             barrier();
+            TSTAMP(7);
         }
         if (G == 0) barrier();                                 // group 1 executed one extra barrier up front
+#ifdef VISREP_GEMM_ABLATE
+        if (timing && lane == 0)
+            for (int i = 0; i < 8; ++i) p.dbg_buf[G * 8 + i] = tsum[i];
+#endif
     };
     if (grp == 0) body(std::integral_constant<int, 0>{});
     else body(std::integral_constant<int, 1>{});

@@ -183,13 +183,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256p(const GemmArgs p) {
             for (int h = 0; h < 2; ++h) {
                 // ---------------- L(h): 12 fragment reads of k-half h + four LDS-DMA loads (L0: W of tile s+1, L1: X of tile s+2)
                 const unsigned xa = (sx + xbase) ^ (h << 6), wa = (sw + wbase) ^ (h << 6);
+                __builtin_amdgcn_s_setprio(1);                 // the load segment gets the issue priority
                 if (!(DBG & 4)) lds_issue12(xf, wf, xa, xa ^ 32u, wa, wa ^ 32u);
                 if (!(DBG & 2)) { if (h == 0) issue_w(); else issue_x(); }
                 if (h == 1 && G == 1) wait_vm4();
                 lds_wait12(xf, wf);
+                __builtin_amdgcn_s_setprio(0);
                 barrier();
                 // ---------------- M(h): 16 MFMAs 32x32x16, nothing else
-                __builtin_amdgcn_s_setprio(1);
                 if (!(DBG & 1))
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
@@ -200,7 +201,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256p(const GemmArgs p) {
                             if (EPI == EPI_VT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i][kk], wf[j][kk], acc[i][j], 0, 0, 0);
                             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][kk], xf[i][kk], acc[i][j], 0, 0, 0);
                         }
-                __builtin_amdgcn_s_setprio(0);
                 if (h == 0) barrier();
             }
             if (G == 0) wait_vm4();

@@ -27,6 +27,11 @@ extern "C" int visrep_debug_gemm_ablation(int mask) {   // timing experiments on
     return old;
 }
 
+extern "C" int visrep_debug_gemm_timing_buffer(void* dev_u64x16) {   // ablation builds only: 16 x u64 per-segment cycle sums
+    g_visrep_gemm_dbg_buf = (unsigned long long*)dev_u64x16;
+    return 0;
+}
+
 extern "C" size_t visrep_last_error(char* buf, size_t n) {
     const size_t len = strlen(g_err);
     if (buf && n) {

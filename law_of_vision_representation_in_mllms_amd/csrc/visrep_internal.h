@@ -20,6 +20,7 @@ struct GemmArgs {
     int M, N, K, lda, ldw, ldc;
     int epi, act;
     int patches, tokens, cls_off;   // EPI_PATCH row remap
+    unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };
 
@@ -29,5 +30,6 @@ int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v3_supports(const GemmArgs& a);
 int visrep_gemm_v3_dispatch(const GemmArgs& a, hipStream_t s);
 extern int g_visrep_gemm_dbg;
+extern unsigned long long* g_visrep_gemm_dbg_buf;
 extern int g_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 3 = 256x256 persistent ping-pong kernels (when N % 256 == 0)
 int visrep_set_error(int code, const char* msg);

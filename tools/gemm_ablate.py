@@ -21,7 +21,7 @@ def t(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-names = {0: "full", 1: "no MFMA", 2: "no LDS-DMA", 4: "no ds_read", 6: "MFMA + barriers only", 3: "ds_read + barriers only", 5: "LDS-DMA + barriers only", 7: "barriers only"}
+names = {0: "full", 8: "full, no s_setprio", 16: "full, s_setprio on L segments", 1: "no MFMA", 2: "no LDS-DMA", 4: "no ds_read", 6: "MFMA + barriers only", 3: "ds_read + barriers only", 5: "LDS-DMA + barriers only", 7: "barriers only"}
 for mask, name in names.items():
     lib.visrep_debug_gemm_ablation(mask)
     a = t(lambda: engine.gemm(hm, w2, None, _lib.EPI_BIAS, out=o2))

@@ -48,7 +48,24 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, int rnd, unsi
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    bf16x8 rd[8];
     auto idle = [&]() {
+        if (V >= 4 && V != 7 || V == 7) {      // the GEMM's load segment: NR ds_read_b128 (conflict-free 64-B-row swizzle) + lgkmcnt(0)
+            const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds + wave * 8192 + (lane & 15) * 64 +
+                                  ((((lane >> 4)) ^ ((4 - (((lane & 15) >> 2) & 3)) & 3)) << 4);
+            if (V == 4 || V == 6 || V == 7)
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                             "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(rd[0]), "=&v"(rd[1]), "=&v"(rd[2]), "=&v"(rd[3]), "=&v"(rd[4]), "=&v"(rd[5]), "=&v"(rd[6]), "=&v"(rd[7]) : "v"(base));
+            else
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(rd[0]), "=&v"(rd[1]), "=&v"(rd[2]), "=&v"(rd[3]) : "v"(base));
+            if (V != 6) { a[0] = rd[0]; b[0] = rd[1]; }     // consume (keeps the reads alive); V6: reads only, MFMA operands untouched
+            else asm volatile("" ::"v"(rd[0]), "v"(rd[7]));
+        }
         if (V == 3) {
 #pragma unroll
             for (int i = 0; i < 100; ++i) filler = filler * 1.0001f + 0.5f;
@@ -58,6 +75,8 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, int rnd, unsi
         for (int it = 0; it < iters; ++it) { burst(); burst(); }
     } else if (V == 1) {
         for (int it = 0; it < iters; ++it) { burst(); bar(); burst(); bar(); }
+    } else if (V == 7) {   // load segments only, no MFMA partner: what do 8 reads cost by themselves?
+        for (int it = 0; it < iters; ++it) { idle(); bar(); bar(); idle(); bar(); bar(); }
     } else {
         if (grp == 1) bar();
         for (int it = 0; it < iters; ++it) { idle(); bar(); burst(); bar(); idle(); bar(); burst(); bar(); }
@@ -105,5 +124,9 @@ int main() {
     run<2, 0, 1>("V2 ping-pong 32x32x16 + setprio", out, 1);
     run<2, 1, 0>("V2 ping-pong 16x16x32 (32/burst)", out, 1);
     run<3, 0, 1>("V3 ping-pong + filler + setprio", out, 1);
+    run<4, 1, 1>("V4 ping-pong + 8 ds_read_b128 in L (16x16x32)", out, 1);
+    run<5, 1, 1>("V5 ping-pong + 4 ds_read_b128 in L (16x16x32)", out, 1);
+    run<4, 0, 1>("V4 ping-pong + 8 ds_read_b128 in L (32x32x16)", out, 1);
+    run<7, 1, 0>("V7 8 ds_read_b128 + 2 barriers only (no MFMA)", out, 1);
     return 0;
 }
