@@ -27,7 +27,8 @@
 //   L segments: issue the fragment ds_reads, issue this wave's two LDS-DMA loads under the read latency, retire the
 //   reads (lgkmcnt(0)), barrier.  M segments: 16 back-to-back MFMAs, nothing else (an LDS-DMA issue costs the issuing
 //   wave ~60 cycles, which would come straight out of the matrix pipe if it sat between MFMAs - measured).
-//   issue:    group 0: W-pair of tile s+2 in L0(s), X-pair of tile s+3 in L1(s);  group 1: X/W pairs of s+3 in L0/L1(s)
+//   issue:    L0 carries the 8 fragment reads of the K-tile, L1 only 4, so all four LDS-DMA loads of a wave ride in L1:
+//             group 0: W-pair of tile s+2 and X-pair of tile s+3 in L1(s);  group 1: X- and W-pair of tile s+3 in L1(s)
 //   RAW:      tile s+1 is first read after instance 4s+4.  Before arriving there group 0 waits vmcnt(6) at the end of
 //             M1(s) (outstanding: tile s+2 = 4, X-pair of s+3 = 2) and group 1 waits vmcnt(8) in L1(s) (tiles s+2,
 //             s+3) -> tile s+1 has landed.
@@ -197,7 +198,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
             //                  under the LDS read latency; everything is retired before the barrier
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(1);   // the load segment gets the issue priority (measured +20 % vs prio on the MFMA segment)
             if (!(DBG & 4)) lds_issue8(wf, xf, sb + woff, sb + xoff);
-            if (!(DBG & 2)) { if (G == 0) issue_w(); else issue_x(); }
             lds_wait8(wf, xf);
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(0);
             TSTAMP(0);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
             // ---------------- L1: X fragments of rows 64..127 + this wave's other two LDS-DMA loads
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(1);
             if (!(DBG & 4)) lds_issue4(xf, sb + xoff + 4096);
-            if (!(DBG & 2)) { if (G == 0) issue_x(); else issue_w(); }
+            if (!(DBG & 2)) { if (G == 0) { issue_w(); issue_x(); } else { issue_x(); issue_w(); } }   // all four LDS-DMA loads ride in the short segment
             if (G == 1) wait_g1();
             lds_wait4(xf);
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(0);
