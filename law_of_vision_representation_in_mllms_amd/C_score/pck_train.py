@@ -70,8 +70,12 @@ def _dist():
     return d if d.is_available() and d.is_initialized() else None
 
 
-def build_feature_bank(args, aggre_net, files, num_patches, dev):
-    """Distinct images of a category -> ([n_img, C, P^2] fp32 device bank, per-file-slot bank index)."""
+def build_feature_bank(args, aggre_net, files, num_patches, dev, models=None):
+    """Distinct images of a category -> ([n_img, C, P^2] fp32 device bank, per-file-slot bank index).
+
+    `models`: feature-file suffixes; two of them (pck_train_two.py) are concatenated on the channel axis - the raw maps,
+    the per-encoder normalisation happens in the transfer kernel (split = channels of the first one)."""
+    models = (args.MODEL,) if models is None else tuple(models)
     uniq, slot = {}, []
     for f in files:
         if f not in uniq:
@@ -79,21 +83,30 @@ def build_feature_bank(args, aggre_net, files, num_patches, dev):
         slot.append(uniq[f])
     maps = []
     for f in uniq:
-        m = torch.load(_feature_path(f, False, args.ENSEMBLE, args.MODEL), map_location="cpu")
-        maps.append(aggre_net(m).reshape(-1, num_patches ** 2).float())
+        per_model = [aggre_net(torch.load(_feature_path(f, False, args.ENSEMBLE, m), map_location="cpu")).reshape(-1, num_patches ** 2).float()
+                     for m in models]
+        maps.append(torch.cat(per_model, 0) if len(per_model) > 1 else per_model[0])
     return torch.stack(maps).to(dev), np.asarray(slot, dtype=np.int32)
 
 
 def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_points=None, thresholds=None, bank=None):
+    return _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models=(args.MODEL,))
+
+
+def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models):
     if getattr(args, "ADAPT_FLIP", False) or getattr(args, "COMPUTE_GEOAWARE_METRICS", False):
         raise NotImplementedError("ADAPT_FLIP / COMPUTE_GEOAWARE_METRICS are not built on the MI355X path yet (SURVEY §8f N4)")
     P = args.NUM_PATCHES
     N = len(files) // 2
     dev = torch.device(device)
+    split = 0
     if bank is None:
-        bank_t, slot = build_feature_bank(args, aggre_net, files, P, dev)
+        bank_t, slot = build_feature_bank(args, aggre_net, files, P, dev, models)
+        if len(models) == 2:      # channels of the first encoder: read off one of its maps
+            split = int(aggre_net(torch.load(_feature_path(files[0], False, args.ENSEMBLE, models[0]), map_location="cpu")).reshape(-1, P * P).shape[0])
     else:
-        bank_t, slot = bank
+        bank_t, slot = bank[0], bank[1]
+        split = int(bank[2]) if len(bank) > 2 else 0
     kps = kps.float()
     K = kps.shape[1]
     if K > 32:
@@ -107,7 +120,7 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
     sl = slice(lo, hi)
     xy = cscore_ops.transfer(bank_t, torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy()),
                              torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW, soft_eval=bool(args.SOFT_EVAL),
-                             anno_size=args.ANNO_SIZE)
+                             anno_size=args.ANNO_SIZE, split=split)
     alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)
     if thresholds is not None:
         thr = torch.tensor(thresholds, dtype=torch.float64)
@@ -144,15 +157,16 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
     return correct, [], out_results, img_correct
 
 
-def eval(args, aggre_net, save_path, split='val'):
+def eval(args, aggre_net, save_path, split='val', _compute=None):
+    compute_pck_fn = _compute or compute_pck
     aggre_net.eval()
     data_dir, categories, split = get_dataset_info(args, split)
     total_out_results, pcks, pcks_05, pcks_01, weights, kpt_weights = ([] for _ in range(6))
     for cat in categories:
         files, kps, thresholds, used_points = load_eval_data(args, data_dir, cat, split)
         compute_args = (save_path, aggre_net, files, kps, cat, used_points)
-        pck, correct_geo, out_results, img_correct = (compute_pck(args, *compute_args, thresholds=thresholds) if args.BBOX_THRE
-                                                      else compute_pck(args, *compute_args))
+        pck, correct_geo, out_results, img_correct = (compute_pck_fn(args, *compute_args, thresholds=thresholds) if args.BBOX_THRE
+                                                      else compute_pck_fn(args, *compute_args))
         total_out_results.extend(out_results)
         update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, pck, img_correct)
     pck_010, pck_005, pck_001 = log_weighted_pcks(args, logger, pcks, pcks_05, pcks_01, weights)
@@ -160,7 +174,7 @@ def eval(args, aggre_net, save_path, split='val'):
     return pck_010, pck_005, pck_001, total_out_results
 
 
-def main(args):
+def main(args, _eval=None):
     torch.manual_seed(args.SEED)
     np.random.seed(args.SEED)
     args.BBOX_THRE = not (args.IMG_THRESHOLD or args.EVAL_DATASET == 'pascal')
@@ -176,13 +190,13 @@ def main(args):
     if not args.DO_EVAL:
         raise NotImplementedError("training is out of scope of the scoring path; run with DO_EVAL (configs/eval_zero_shot_spair.yaml)")
     with torch.no_grad():
-        pck_010, pck_005, pck_001, result = eval(args, aggre_net, save_path, split='test')
+        pck_010, pck_005, pck_001, result = (_eval or eval)(args, aggre_net, save_path, split='test')
     with open(save_path + '/result.pkl', 'wb') as f:
         pickle.dump(result, f)
     return pck_010, pck_005, pck_001
 
 
-def build_parser():
+def build_parser(two=False):
     p = argparse.ArgumentParser()
     p.add_argument('--config', type=str, default=None)
     p.add_argument('--SEED', type=int, default=42)
@@ -205,14 +219,18 @@ def build_parser():
     p.add_argument('--MUTUAL_NN', action='store_true', default=False)
     p.add_argument('--SOFT_EVAL', action='store_true', default=False)
     p.add_argument('--SOFT_EVAL_WINDOW', type=int, default=7)
-    p.add_argument('--MODEL', type=str, default='clip')
+    if two:                                                      # pck_train_two.py:444-445
+        p.add_argument('--MODEL1', type=str, default='clip')
+        p.add_argument('--MODEL2', type=str, default='dino')
+    else:
+        p.add_argument('--MODEL', type=str, default='clip')
     p.add_argument('--NUM_PATCHES', type=int, default=7)
     p.add_argument('--DATA_DIR', type=str, default='data/SPair-71k')
     return p
 
 
-def parse_args(argv=None):
-    args = build_parser().parse_args(argv)
+def parse_args(argv=None, two=False):
+    args = build_parser(two).parse_args(argv)
     if args.config is not None:
         d = vars(args)
         d.update(load_config(args.config))

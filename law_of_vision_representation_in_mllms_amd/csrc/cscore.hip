@@ -28,7 +28,7 @@ struct CArgs {
     const int* nkp;                // [n_pairs] keypoints in this pair (<= 32)
     const float* lin;              // [P] float32(np.linspace(-1, 1, P))
     float* xy;                     // [n_pairs][kmax][2] (x, y) in the annotation frame
-    int n_pairs, kmax, P, C, window, soft;
+    int n_pairs, kmax, P, C, split, window, soft;
     float beta, stride, half;      // anno_size / P, floor(stride / 2)
 };
 
@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int PP = p.P * p.P;
     float* rows = sm;                     // [32][PP]
-    float* n1s = sm + 32 * PP;            // [32]
     const int pair = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
@@ -47,23 +46,22 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     const int sk = (lq < K) ? p.patch_idx[(size_t)pair * p.kmax + lq] : 0;
 
     // ---------------- phase A
+    // Channel range [0, split) / [split, C): two encoders concatenated on the channel axis are normalised SEPARATELY, then
+    // the concatenation is normalised again (pck_train_two.py:24-36); split == 0 is the single-encoder path of pck_train.py.
     const int ntile = (PP + 31) >> 5;
+    const bool two = p.split > 0;
+    const int c_mid = two ? p.split : p.C;
     const float* a_ptr = F1 + (size_t)hi * PP + sk;
-    float n1 = 0.f;
+    float fa = 0.f, fb = 0.f;             // per keypoint (lane lq): source-side factors of the two channel blocks
     bool first = true;
-    for (int tile = wave; tile < ntile; tile += 4) {
-        const int t = tile * 32 + lq;
-        const int tc = t < PP ? t : PP - 1;
-        const float* b_ptr = F2 + (size_t)hi * PP + tc;
-        f32x16 acc = f32x16{};
-        float n2 = 0.f;
-        int c = 0;
-        for (; c + 16 <= p.C; c += 16) {                 // 16 independent loads in flight per lane before the MFMA chain
+    auto gram = [&](int c0, int c1, const float* bp, f32x16& acc, float& n1, float& n2) {
+        int c = c0;
+        for (; c + 16 <= c1; c += 16) {                  // 16 independent loads in flight per lane before the MFMA chain
             float a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 a[u] = a_ptr[(size_t)(c + 2 * u) * PP];
-                b[u] = b_ptr[(size_t)(c + 2 * u) * PP];
+                b[u] = bp[(size_t)(c + 2 * u) * PP];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -72,24 +70,48 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
             }
         }
-        for (; c < p.C; c += 2) {
+        for (; c < c1; c += 2) {
             const float a = a_ptr[(size_t)c * PP];
-            const float b = b_ptr[(size_t)c * PP];
+            const float b = bp[(size_t)c * PP];
             n1 += a * a;
             n2 += b * b;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        if (first) {                                      // every tile re-reads the same source columns: keep the first sum
-            const float n1t = n1 + __shfl_xor(n1, 32);
-            if (wave == 0 && hi == 0) n1s[lq] = sqrtf(n1t) + 1e-10f;    // |d1[s_k]| + eps
+    };
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int t = tile * 32 + lq;
+        const int tc = t < PP ? t : PP - 1;
+        const float* b_ptr = F2 + (size_t)hi * PP + tc;
+        f32x16 acc_a = f32x16{}, acc_b = f32x16{};
+        float n1a = 0.f, n1b = 0.f, n2a = 0.f, n2b = 0.f;
+        gram(0, c_mid, b_ptr, acc_a, n1a, n2a);
+        if (two) gram(c_mid, p.C, b_ptr, acc_b, n1b, n2b);
+        if (first) {                                      // every tile re-reads the same source columns: keep the first sums
+            n1a += __shfl_xor(n1a, 32); n1b += __shfl_xor(n1b, 32);
+            const float ia = 1.0f / (sqrtf(n1a) + 1e-10f);            // 1 / (|d1_a[s_k]| + eps)
+            if (two) {
+                const float ib = 1.0f / (sqrtf(n1b) + 1e-10f);
+                const float inv = 1.0f / (sqrtf(n1a * ia * ia + n1b * ib * ib) + 1e-10f);
+                fa = ia * inv; fb = ib * inv;
+            } else {
+                fa = ia;
+            }
             first = false;
         }
-        n2 += __shfl_xor(n2, 32);
-        const float inv2 = 1.0f / (sqrtf(n2) + 1e-10f);
-        // lane holds G[k = row(r,hi)][t]; the 1/n1 factor is applied in phase B (n1s may not be visible yet)
-        if (t < PP) {
+        n2a += __shfl_xor(n2a, 32); n2b += __shfl_xor(n2b, 32);
+        float ga = 1.0f / (sqrtf(n2a) + 1e-10f), gb = 0.f;
+        if (two) {
+            gb = 1.0f / (sqrtf(n2b) + 1e-10f);
+            const float inv = 1.0f / (sqrtf(n2a * ga * ga + n2b * gb * gb) + 1e-10f);
+            ga *= inv; gb *= inv;
+        }
+        // lane holds G[k = row(r,hi)][t]; the keypoint-side factors live in lane k of this wave
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rows[((r & 3) + 8 * (r >> 2) + 4 * hi) * PP + t] = acc[r] * inv2;
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float v = acc_a[r] * ga * __shfl(fa, k);
+            if (two) v += acc_b[r] * gb * __shfl(fb, k);
+            if (t < PP) rows[k * PP + t] = v;
         }
     }
     __syncthreads();
@@ -97,13 +119,11 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     // ---------------- phase B: one wave per keypoint row
     const int w = p.window;
     for (int k = wave; k < K; k += 4) {
-        const float inv1 = 1.0f / n1s[k];
         float* row = rows + k * PP;
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int t = lane; t < PP; t += 64) {
-            const float v = row[t] * inv1;
-            row[t] = v;
+            const float v = row[t];
             if (v > bv) { bv = v; bi = t; }                        // per lane t increases -> first index kept on ties
         }
 #pragma unroll
@@ -176,13 +196,14 @@ __global__ void cscore_pck(const float* __restrict__ xy, const float* __restrict
 }  // namespace
 
 extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
-                                      const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int window, int soft_eval,
-                                      float beta, float anno_stride, float anno_half, void* stream) {
+                                      const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window,
+                                      int soft_eval, float beta, float anno_stride, float anno_half, void* stream) {
     if (n_pairs <= 0) return 0;
     if (kmax <= 0 || kmax > 32) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: kmax must be in 1..32");
     if (P <= 0 || P > 32 || C <= 0 || (C & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: need 1 <= P <= 32 and even C");
-    CArgs a{feats, img1, img2, patch_idx, nkp, lin, xy, n_pairs, kmax, P, C, window, soft_eval, beta, anno_stride, anno_half};
-    const size_t lds = sizeof(float) * ((size_t)32 * P * P + 32);
+    if (split < 0 || split >= C || (split & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: split must be even and in [0, C)");
+    CArgs a{feats, img1, img2, patch_idx, nkp, lin, xy, n_pairs, kmax, P, C, split, window, soft_eval, beta, anno_stride, anno_half};
+    const size_t lds = sizeof(float) * ((size_t)32 * P * P);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -470,8 +470,28 @@ def gen_spair():
                                       SOFT_EVAL_WINDOW=5, KPT_RESULT=False, TOTAL_SAVE_RESULT=0, MUTUAL_NN=False, TEST_SAMPLE=0,
                                       BBOX_THRE=True)
             p10, p05, p01, results = PT.eval(args, PT.DummyAggregationNetwork(), tmp, split="test")
+            # two-encoder variant (pck_train_two.py): a second map per image with a different channel count and scale
+            import pck_train_two as PT2
+            C2 = 24
+            frs2 = np.random.RandomState(44)
+            for cat, (n_img, _, _) in cats.items():
+                base = frs2.standard_normal((1, C2, P, P)).astype(np.float32)
+                for i in range(n_img):
+                    # spatially rolled per image: this encoder's best matches sit elsewhere than the first one's
+                    m = 3.0 * (0.9 * np.roll(base, (i, 2 * i), axis=(2, 3)) + 0.1 * frs2.standard_normal((1, C2, P, P)).astype(np.float32))
+                    torch.save(torch.from_numpy(m), f"{tmp}/data/SPair-71k/features/{cat}/img{i}_clip.pt")
+                    out[f"feat2.{cat}.{i}"] = m
+            PT2.load_img_and_kps = PT.load_img_and_kps
+            PT2.device = "cpu"
+            _gpd2 = PT2.get_patch_descriptors
+            PT2.get_patch_descriptors = lambda *a, **k: _gpd2(*a, **{**k, "device": "cpu"})
+            PT2.logger = sys.modules["loguru"].logger
+            args2 = argparse.Namespace(**{**vars(args), "MODEL1": "dino", "MODEL2": "clip", "DUMMY_NET": True})
+            q10, q05, q01, results2 = PT2.eval(args2, PT2.DummyAggregationNetwork(), tmp, split="test")
         finally:
             os.chdir(cwd)
+    out["eval2.pck"] = np.array([q10, q05, q01], np.float64)
+    out["eval2.pred"] = np.stack([r["src_kpts_pred"] for r in results2]).astype(np.float32)
     out["eval.pck"] = np.array([p10, p05, p01], np.float64)
     out["eval.pred"] = np.stack([r["src_kpts_pred"] for r in results]).astype(np.float32)
     out["meta"] = np.array([P, C], np.int64)

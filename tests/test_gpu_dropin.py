@@ -12,7 +12,7 @@ import torch
 from PIL import Image
 
 sys.path.insert(0, os.path.dirname(__file__))
-from test_host_cscore import G, make_tree, eval_args  # noqa: E402
+from test_host_cscore import G, make_tree, eval_args, eval_args_two  # noqa: E402
 
 from law_of_vision_representation_in_mllms_amd import vit_weights as VW  # noqa: E402
 from law_of_vision_representation_in_mllms_amd.A_score import compute as AC  # noqa: E402
@@ -138,3 +138,8 @@ def test_extract_feature_and_pck_train_on_device(small_towers, tmp_path):
     p10, p05, p01, results = PT.eval(eval_args(root, 16), PT.DummyAggregationNetwork(), str(tmp_path), split="test")
     np.testing.assert_allclose([p10, p05, p01], z["eval.pck"], atol=1e-7)
     np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), z["eval.pred"], atol=5e-3)
+    # two-encoder evaluator (pck_train_two.py) on the same tree, against the reference's own eval()
+    from law_of_vision_representation_in_mllms_amd.C_score import pck_train_two as PT2
+    q10, q05, q01, results2 = PT2.eval(eval_args_two(root, 16), PT2.DummyAggregationNetwork(), str(tmp_path), split="test")
+    np.testing.assert_allclose([q10, q05, q01], z["eval2.pck"], atol=1e-7)
+    np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results2]), z["eval2.pred"], atol=5e-3)

@@ -111,6 +111,43 @@ def test_cscore_vs_oracle_full_width(P, C):
         assert (xy[i, : nkp[i]] - want).abs().max().item() < 2e-2, i
 
 
+@pytest.mark.parametrize("P,C1,C2", [(16, 1024, 1024), (24, 1024, 1280), (16, 32, 24), (24, 1024, 2)])
+def test_cscore_two_encoder_split_vs_oracle(P, C1, C2):
+    """pck_train_two.py normalisation (per-encoder L2, concat, L2 again) fused into the Gram kernel via `split`."""
+    rs = np.random.RandomState(P + C1 + C2)
+    n_img, n_pairs, K = 5, 8, 18
+    C = C1 + C2
+    bank = rs.standard_normal((n_img, C, P * P)).astype(np.float32)
+    bank[1:] = 0.5 * bank[:1] + 0.5 * bank[1:]
+    bank[:, C1:] *= 7.5                                                   # very different raw scales per encoder
+    bank_t = torch.from_numpy(bank)
+    i1 = rs.randint(0, n_img, n_pairs).astype(np.int32)
+    i2 = rs.randint(0, n_img, n_pairs).astype(np.int32)
+    kps = np.ones((n_pairs, K, 3), np.float32)
+    kps[:, :, :2] = rs.uniform(0, 839.9, (n_pairs, K, 2))
+    nkp = rs.randint(3, K + 1, n_pairs).astype(np.int32)
+    idx = np.stack([OC.kpts_to_patch_idx(torch.from_numpy(kps[i]), P) for i in range(n_pairs)]).astype(np.int32)
+    args = (torch.from_numpy(i1), torch.from_numpy(i2), torch.from_numpy(idx), torch.from_numpy(nkp), P)
+    xy = cscore_ops.transfer(bank_t.to(DEV), *args, split=C1).cpu()
+    xy_one = cscore_ops.transfer(bank_t.to(DEV), *args).cpu()
+    differs = False
+    for i in range(n_pairs):
+        d1 = OC.normalize_feats_two(bank_t[i1[i]].t()[None], C1)
+        d2 = OC.normalize_feats_two(bank_t[i2[i]].t()[None], C1)
+        want = OC.keypoint_transfer(d1, d2, idx[i][: nkp[i]], P)
+        assert (xy[i, : nkp[i]] - want).abs().max().item() < 2e-2, i
+        differs |= (xy_one[i, : nkp[i]] - want).abs().max().item() > 1.0
+    assert differs                                                         # single-encoder normalisation is a different score
+
+
+def test_cscore_split_validation():
+    bank = torch.zeros(2, 8, 16, device=DEV)
+    a = (torch.tensor([0]), torch.tensor([1]), torch.zeros(1, 4, dtype=torch.int32), torch.tensor([4]), 4)
+    for bad in (3, 8, -2):
+        with pytest.raises(RuntimeError, match="split"):
+            cscore_ops.transfer(bank, *a, split=bad)
+
+
 def test_cscore_rejects_too_many_keypoints():
     bank = torch.zeros(2, 8, 16, device=DEV)
     with pytest.raises(RuntimeError, match="kmax"):
