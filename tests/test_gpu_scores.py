@@ -118,8 +118,10 @@ def test_cscore_two_encoder_split_vs_oracle(P, C1, C2):
     n_img, n_pairs, K = 5, 8, 18
     C = C1 + C2
     bank = rs.standard_normal((n_img, C, P * P)).astype(np.float32)
-    bank[1:] = 0.5 * bank[:1] + 0.5 * bank[1:]
-    bank[:, C1:] *= 7.5                                                   # very different raw scales per encoder
+    bank[1:, :C1] = 0.9 * bank[:1, :C1] + 0.1 * bank[1:, :C1]             # encoder 1: strong matches at the same patch
+    for i in range(1, n_img):                                             # encoder 2: weaker matches at a ROLLED patch,
+        bank[i, C1:] = 0.5 * np.roll(bank[0, C1:], 37 * i, axis=1) + 0.5 * bank[i, C1:]
+    bank[:, C1:] *= 7.5                                                   # but 56x the energy: joint L2 would follow it
     bank_t = torch.from_numpy(bank)
     i1 = rs.randint(0, n_img, n_pairs).astype(np.int32)
     i2 = rs.randint(0, n_img, n_pairs).astype(np.int32)
