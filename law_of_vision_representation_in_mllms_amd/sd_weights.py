@@ -1,0 +1,208 @@
+"""Architecture specs and parameter tables of the Stable-Diffusion feature towers.
+
+The reference loads `UNet2DConditionModel` / `AutoencoderKL` checkpoints through diffusers (`dift_sd.py:224-236`); the
+parameter names below are the diffusers state-dict names, so a local checkpoint's `unet/` and `vae/` safetensors load
+without renaming.  Only what the feature path executes is listed: the VAE *encoder* (+ quant_conv) and the UNet up to the
+up-block whose output is captured (`dift_sd.py:118-150` stops after `max(up_ft_indices)`).
+
+No network here, so `synthetic_*` produce deterministic random-init parameters of a given architecture
+(numpy RandomState: version-stable, regenerated identically on the GPU box).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class UNetSpec:
+    """UNet2DConditionModel config subset (SD1.5: stable-diffusion-v1-5/unet/config.json)."""
+    in_channels: int = 4
+    block_out: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_types: Tuple[str, ...] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D")
+    up_types: Tuple[str, ...] = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
+    layers_per_block: int = 2
+    heads: Tuple[int, ...] = (8, 8, 8, 8)          # diffusers' `attention_head_dim` is the HEAD COUNT for SD1.x
+    cross_dim: int = 768
+    groups: int = 32
+    eps: float = 1e-5
+    linear_projection: bool = False                # SD2.1: proj_in / proj_out are Linear
+
+    @property
+    def temb_dim(self):
+        return 4 * self.block_out[0]
+
+
+@dataclass(frozen=True)
+class VaeSpec:
+    """AutoencoderKL encoder half (SD1.5 vae/config.json)."""
+    in_channels: int = 3
+    block_out: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    latent_channels: int = 4
+    groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+@dataclass(frozen=True)
+class SchedulerSpec:
+    """DDIMScheduler fields `add_noise` depends on (scheduling_ddim.py:471-495)."""
+    num_train_timesteps: int = 1000
+    beta_start: float = 0.00085
+    beta_end: float = 0.012
+    beta_schedule: str = "scaled_linear"
+
+    def alphas_cumprod(self) -> torch.Tensor:
+        if self.beta_schedule == "scaled_linear":
+            betas = torch.linspace(self.beta_start ** 0.5, self.beta_end ** 0.5, self.num_train_timesteps, dtype=torch.float32) ** 2
+        elif self.beta_schedule == "linear":
+            betas = torch.linspace(self.beta_start, self.beta_end, self.num_train_timesteps, dtype=torch.float32)
+        else:
+            raise ValueError(f"{self.beta_schedule} is not implemented")
+        return torch.cumprod(1.0 - betas, dim=0)
+
+
+@dataclass(frozen=True)
+class SdSpec:
+    name: str
+    unet: UNetSpec = field(default_factory=UNetSpec)
+    vae: VaeSpec = field(default_factory=VaeSpec)
+    sched: SchedulerSpec = field(default_factory=SchedulerSpec)
+    text_len: int = 77
+
+
+SD_SPECS: Dict[str, SdSpec] = {
+    "runwayml/stable-diffusion-v1-5": SdSpec("runwayml/stable-diffusion-v1-5"),
+    "stabilityai/stable-diffusion-2-1": SdSpec(
+        "stabilityai/stable-diffusion-2-1",
+        unet=UNetSpec(heads=(5, 10, 20, 20), cross_dim=1024, linear_projection=True)),
+}
+
+
+def tiny_sd_spec(name="tiny-sd", linear_projection=False) -> SdSpec:
+    """Same topology as SD1.5, every width a multiple of 64 (the GEMM kernels' granularity), head widths 32 / 64."""
+    return SdSpec(name,
+                  unet=UNetSpec(block_out=(64, 128, 128), down_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                                up_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), heads=(2, 2, 2), cross_dim=64,
+                                linear_projection=linear_projection),
+                  vae=VaeSpec(block_out=(64, 64, 128), layers_per_block=1), text_len=11)
+
+
+# ----------------------------------------------------------------------------------------------- parameter tables
+def _resnet(p, cin, cout, temb):
+    t = [(f"{p}.norm1.weight", (cin,)), (f"{p}.norm1.bias", (cin,)),
+         (f"{p}.conv1.weight", (cout, cin, 3, 3)), (f"{p}.conv1.bias", (cout,))]
+    if temb:
+        t += [(f"{p}.time_emb_proj.weight", (cout, temb)), (f"{p}.time_emb_proj.bias", (cout,))]
+    t += [(f"{p}.norm2.weight", (cout,)), (f"{p}.norm2.bias", (cout,)),
+          (f"{p}.conv2.weight", (cout, cout, 3, 3)), (f"{p}.conv2.bias", (cout,))]
+    if cin != cout:
+        t += [(f"{p}.conv_shortcut.weight", (cout, cin, 1, 1)), (f"{p}.conv_shortcut.bias", (cout,))]
+    return t
+
+
+def _transformer(p, d, cross, linear):
+    proj = (d, d) if linear else (d, d, 1, 1)
+    b = f"{p}.transformer_blocks.0"
+    return [(f"{p}.norm.weight", (d,)), (f"{p}.norm.bias", (d,)), (f"{p}.proj_in.weight", proj), (f"{p}.proj_in.bias", (d,)),
+            (f"{b}.norm1.weight", (d,)), (f"{b}.norm1.bias", (d,)),
+            (f"{b}.attn1.to_q.weight", (d, d)), (f"{b}.attn1.to_k.weight", (d, d)), (f"{b}.attn1.to_v.weight", (d, d)),
+            (f"{b}.attn1.to_out.0.weight", (d, d)), (f"{b}.attn1.to_out.0.bias", (d,)),
+            (f"{b}.norm2.weight", (d,)), (f"{b}.norm2.bias", (d,)),
+            (f"{b}.attn2.to_q.weight", (d, d)), (f"{b}.attn2.to_k.weight", (d, cross)), (f"{b}.attn2.to_v.weight", (d, cross)),
+            (f"{b}.attn2.to_out.0.weight", (d, d)), (f"{b}.attn2.to_out.0.bias", (d,)),
+            (f"{b}.norm3.weight", (d,)), (f"{b}.norm3.bias", (d,)),
+            (f"{b}.ff.net.0.proj.weight", (8 * d, d)), (f"{b}.ff.net.0.proj.bias", (8 * d,)),
+            (f"{b}.ff.net.2.weight", (d, 4 * d)), (f"{b}.ff.net.2.bias", (d,)),
+            (f"{p}.proj_out.weight", proj), (f"{p}.proj_out.bias", (d,))]
+
+
+def up_block_plan(u: UNetSpec, i: int):
+    """(resnet input widths incl. skip, output width, has_attention, has_upsampler) of up block i (unet_2d_condition.py)."""
+    rev = tuple(reversed(u.block_out))
+    n = len(rev)
+    out, prev, inp = rev[i], rev[max(i - 1, 0)], rev[min(i + 1, n - 1)]
+    L = u.layers_per_block + 1
+    cins = [(prev if j == 0 else out) + (inp if j == L - 1 else out) for j in range(L)]
+    return cins, out, u.up_types[i].startswith("CrossAttn"), i != n - 1
+
+
+def unet_param_table(u: UNetSpec, n_up_blocks: int = 1) -> List[Tuple[str, tuple]]:
+    c0, T = u.block_out[0], u.temb_dim
+    t = [("conv_in.weight", (c0, u.in_channels, 3, 3)), ("conv_in.bias", (c0,)),
+         ("time_embedding.linear_1.weight", (T, c0)), ("time_embedding.linear_1.bias", (T,)),
+         ("time_embedding.linear_2.weight", (T, T)), ("time_embedding.linear_2.bias", (T,))]
+    cin = c0
+    for i, cout in enumerate(u.block_out):
+        for j in range(u.layers_per_block):
+            t += _resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, T)
+            if u.down_types[i].startswith("CrossAttn"):
+                t += _transformer(f"down_blocks.{i}.attentions.{j}", cout, u.cross_dim, u.linear_projection)
+        if i != len(u.block_out) - 1:
+            t += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (cout, cout, 3, 3)), (f"down_blocks.{i}.downsamplers.0.conv.bias", (cout,))]
+        cin = cout
+    cm = u.block_out[-1]
+    t += _resnet("mid_block.resnets.0", cm, cm, T) + _transformer("mid_block.attentions.0", cm, u.cross_dim, u.linear_projection)
+    t += _resnet("mid_block.resnets.1", cm, cm, T)
+    for i in range(n_up_blocks):
+        cins, out, attn, ups = up_block_plan(u, i)
+        for j, ci in enumerate(cins):
+            t += _resnet(f"up_blocks.{i}.resnets.{j}", ci, out, T)
+            if attn:
+                t += _transformer(f"up_blocks.{i}.attentions.{j}", out, u.cross_dim, u.linear_projection)
+        if ups:
+            t += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (out, out, 3, 3)), (f"up_blocks.{i}.upsamplers.0.conv.bias", (out,))]
+    return t
+
+
+def vae_param_table(v: VaeSpec) -> List[Tuple[str, tuple]]:
+    c0 = v.block_out[0]
+    t = [("encoder.conv_in.weight", (c0, v.in_channels, 3, 3)), ("encoder.conv_in.bias", (c0,))]
+    cin = c0
+    for i, cout in enumerate(v.block_out):
+        for j in range(v.layers_per_block):
+            t += _resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, 0)
+        if i != len(v.block_out) - 1:
+            t += [(f"encoder.down_blocks.{i}.downsamplers.0.conv.weight", (cout, cout, 3, 3)),
+                  (f"encoder.down_blocks.{i}.downsamplers.0.conv.bias", (cout,))]
+        cin = cout
+    cm = v.block_out[-1]
+    t += _resnet("encoder.mid_block.resnets.0", cm, cm, 0)
+    a = "encoder.mid_block.attentions.0"
+    t += [(f"{a}.group_norm.weight", (cm,)), (f"{a}.group_norm.bias", (cm,))]
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        t += [(f"{a}.{n}.weight", (cm, cm)), (f"{a}.{n}.bias", (cm,))]
+    t += _resnet("encoder.mid_block.resnets.1", cm, cm, 0)
+    z = 2 * v.latent_channels
+    t += [("encoder.conv_norm_out.weight", (cm,)), ("encoder.conv_norm_out.bias", (cm,)),
+          ("encoder.conv_out.weight", (z, cm, 3, 3)), ("encoder.conv_out.bias", (z,)),
+          ("quant_conv.weight", (z, z, 1, 1)), ("quant_conv.bias", (z,))]
+    return t
+
+
+def _synthetic(table, seed):
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shape in table:
+        if name.endswith("bias"):
+            w = rs.standard_normal(shape) * 0.05
+        elif "norm" in name:
+            w = 1.0 + 0.1 * rs.standard_normal(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            w = rs.standard_normal(shape) * (1.0 / np.sqrt(fan_in))
+        out[name] = torch.from_numpy(w.astype(np.float32))
+    return out
+
+
+def synthetic_unet(u: UNetSpec, seed: int, n_up_blocks: int = 1):
+    return _synthetic(unet_param_table(u, n_up_blocks), seed)
+
+
+def synthetic_vae(v: VaeSpec, seed: int):
+    w = _synthetic(vae_param_table(v), seed)
+    # keep the posterior log-variance moderate so exp(0.5 * logvar) * noise stays O(1) like a trained VAE's
+    z = v.latent_channels
+    w["quant_conv.bias"][z:] -= 2.0
+    return w

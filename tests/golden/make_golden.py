@@ -499,6 +499,71 @@ def gen_spair():
     print("spair_host.npz  eval pck:", out["eval.pck"])
 
 
+# ----------------------------------------------------------------------------- Stable-Diffusion feature tower
+SD_CASES = {   # tag: (linear_projection, up_ft_index, ensemble, t, batch, image side, weight seed)
+    "conv_up0": (False, 0, 1, 100, 2, 64, 11),
+    "conv_up1_ens2": (False, 1, 2, 261, 1, 64, 12),
+    "linear_up0": (True, 0, 1, 1, 2, 32, 13),
+}
+
+
+def gen_sd():
+    """Reference `MyUNet2DConditionModel` (dift_sd.py:9-155) + the vendored diffusers AutoencoderKL / DDIMScheduler the
+    reference's pipeline calls (dift_sd.py:172-181), tiny configs, weights = sd_weights.synthetic_*(seed); the two randn
+    draws are injected.  Post-processing as SDFeaturizer.forward:271-276 and DiffVisionTower.forward:84-88."""
+    sys.path.insert(0, f"{REF}/diffusers/src")
+    import diffusers
+    from diffusers import DDIMScheduler
+    from diffusers.models.autoencoders.autoencoder_kl import AutoencoderKL
+    diffusers.StableDiffusionPipeline = object          # the pipeline base classes do not import here (SURVEY §8c);
+    diffusers.StableDiffusionXLPipeline = object        # only the UNet subclass of this file is used
+    spec = importlib.util.spec_from_file_location("ref_dift_sd", f"{REF}/llava/model/multimodal_encoder/diffLVLM/src/models/dift_sd.py")
+    dift = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dift)
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    out = {"diffusers_version": np.array(diffusers.__version__)}
+    for tag, (linear, idx, ens, t, B, side, seed) in SD_CASES.items():
+        sp = SW.tiny_sd_spec(linear_projection=linear)
+        u, v = sp.unet, sp.vae
+        unet = dift.MyUNet2DConditionModel(sample_size=8, in_channels=u.in_channels, out_channels=4, block_out_channels=u.block_out,
+                                           layers_per_block=u.layers_per_block, down_block_types=u.down_types, up_block_types=u.up_types,
+                                           cross_attention_dim=u.cross_dim, attention_head_dim=u.heads, norm_num_groups=u.groups,
+                                           use_linear_projection=linear).eval()
+        wu = SW.synthetic_unet(u, seed, n_up_blocks=idx + 1)
+        r = unet.load_state_dict(wu, strict=False)
+        assert not r.unexpected_keys and all(k.startswith(("up_blocks", "conv_norm_out", "conv_out")) for k in r.missing_keys), r
+        assert not any(k.startswith(tuple(f"up_blocks.{i}." for i in range(idx + 1))) for k in r.missing_keys)
+        n = len(v.block_out)
+        vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * n, up_block_types=("UpDecoderBlock2D",) * n,
+                            block_out_channels=v.block_out, layers_per_block=v.layers_per_block, latent_channels=v.latent_channels,
+                            norm_num_groups=v.groups).eval()
+        wv = SW.synthetic_vae(v, seed + 100)
+        r = vae.load_state_dict(wv, strict=False)
+        assert not r.unexpected_keys and all(k.startswith(("decoder", "post_quant_conv")) for k in r.missing_keys), r
+        sched = DDIMScheduler(beta_start=sp.sched.beta_start, beta_end=sp.sched.beta_end, beta_schedule=sp.sched.beta_schedule,
+                              num_train_timesteps=sp.sched.num_train_timesteps)
+        rs = np.random.RandomState(seed + 200)
+        img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32))
+        pe = torch.from_numpy(rs.standard_normal((1, sp.text_len, u.cross_dim)).astype(np.float32))
+        ls = side // 2 ** (n - 1)
+        post = torch.from_numpy(rs.standard_normal((B * ens, v.latent_channels, ls, ls)).astype(np.float32))
+        ddim = torch.from_numpy(rs.standard_normal((B * ens, v.latent_channels, ls, ls)).astype(np.float32))
+        x = img.repeat_interleave(ens, dim=0)                                              # dift_sd.py:251
+        dist = vae.encode(x).latent_dist
+        latents = (dist.mean + dist.std * post) * vae.config.scaling_factor               # .sample() with the draw injected
+        tt = torch.tensor(t, dtype=torch.long)
+        noisy = sched.add_noise(latents, ddim, tt)                                         # dift_sd.py:176
+        ft = unet(noisy, timestep=tt, up_ft_indices=[idx], encoder_hidden_states=pe[0].repeat(B * ens, 1, 1))["up_ft"][idx]
+        _, c, h, w_ = ft.shape
+        ft = ft.view(B, ens, -1, h, w_).mean(1, keepdim=True).squeeze(1)                   # dift_sd.py:275 (+ squeeze for B>1)
+        feats = ft.permute(0, 2, 3, 1).reshape(B, h * w_, c)                              # diffusion_encoder.py:84-88
+        out.update({f"{tag}.img": img.numpy(), f"{tag}.prompt_embeds": pe.numpy(), f"{tag}.post_noise": post.numpy(),
+                    f"{tag}.ddim_noise": ddim.numpy(), f"{tag}.noisy_latents": noisy.numpy(), f"{tag}.mean": dist.mean.numpy(),
+                    f"{tag}.logvar": dist.logvar.numpy(), f"{tag}.features": feats.numpy()})
+        print(tag, "features", tuple(feats.shape), "rms", float(feats.pow(2).mean().sqrt()), "latent rms", float(noisy.pow(2).mean().sqrt()))
+    np.savez_compressed(f"{HERE}/sd_tiny.npz", **out)
+
+
 # ----------------------------------------------------------------------------- projector
 def gen_projector():
     ph = types.ModuleType("ref_proj.perceiver_helpers")
@@ -530,7 +595,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd}[w]()
