@@ -72,6 +72,16 @@ int visrep_layernorm(const void* x, int ldx, const float* gamma, const float* be
 int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo, int B, int T, int H, int head_dim,
                     float scale, void* stream);
 
+/* ---- general multi-head attention forward for the diffusion towers' transformer blocks (vendored diffusers
+ * attention_processor.py AttnProcessor2_0 / SlicedAttnProcessor called from attention.py:241-283 BasicTransformerBlock):
+ * self-attention (k/vt built from the same tokens, Tk = Tq) and cross-attention to the prompt (Tk = text length).
+ * q: [B*Tq, ldq] bf16, head h in columns [h*head_dim, (h+1)*head_dim); k: [B*Tk, ldk] likewise ([Tk, ldk] when
+ * kv_shared = 1: one key/value sequence - the prompt - serves every batch item); vt: [H*head_dim, ldvt] as written by
+ * VISREP_EPI_VT over the key rows, ldvt >= round_up(key rows, 64); out: [B*Tq, ldo].  head_dim in {64, 128, 192}: the
+ * weight packer zero-pads narrower heads (SD1.5: 40 / 80 / 160), which changes nothing in softmax(QK^T)V. */
+int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo, int B, int Tq,
+                         int Tk, int H, int head_dim, int kv_shared, float scale, void* stream);
+
 /* ---- patch embedding pieces (HF CLIPVisionEmbeddings / Dinov2Embeddings / SiglipVisionEmbeddings) */
 int visrep_im2col(const void* pixels, int pixel_dtype, void* cols, int B, int Himg, int Wimg, int patch, int Kpad, void* stream);
 int visrep_cls_rows(void* x, int ldx, const float* cls, const float* pos, int B, int T, int d, void* stream);
@@ -116,6 +126,45 @@ int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2,
  * fp64 [n_pairs], alphas3 = HOST pointer to 3 floats; counts int32 [n_pairs,4] = hits@a0,a1,a2, n_visible. */
 int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp, int n_pairs,
                      int kmax, const float* alphas3, int* counts, void* stream);
+
+/* ==== Convolutional-tower primitives (Stable-Diffusion feature towers) ==================================
+ * All activations are channels-last token matrices: [B*H*W, C] bf16.  A 3x3 convolution = visrep_im2col3x3 +
+ * visrep_gemm_bf16 with K = ld of the gathered matrix and weights repacked [Cout, (ky, kx, Cin)] (zero-padded to ld). */
+
+/* torch.nn.GroupNorm (+ optional SiLU) as used by diffusers resnet.py:ResnetBlock2D.forward (norm1/norm2 + nonlinearity),
+ * transformer_2d.py:141 and vae.py conv_norm_out.  x, y: [B*HW, C] bf16 (y may alias x); gamma/beta fp32 [C]; fp32
+ * statistics over (HW, C/groups) per (image, group).  workspace: visrep_groupnorm_workspace_bytes(B, groups). */
+size_t visrep_groupnorm_workspace_bytes(int B, int groups);
+int visrep_groupnorm(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups, float eps,
+                     int silu, void* workspace, void* stream);
+
+/* 3x3 patch gather for nn.Conv2d(kernel 3): y[(b, oy, ox), (ky*3+kx)*C + c] = x[b, oy*stride+ky-pad, ox*stride+kx-pad, c]
+ * (zero outside), columns [9C, ldy) zeroed.  pad_mode 0 = padding 1 on every side (resnet convs, UNet downsample
+ * stride 2: downsampling.py Downsample2D padding=1); pad_mode 1 = F.pad(x, (0,1,0,1)) then no padding (VAE encoder
+ * downsample, downsampling.py:130-133).  upsample = 1 reads the source through a nearest-neighbour 2x upsample
+ * (upsampling.py Upsample2D: F.interpolate(scale_factor=2, mode="nearest") + conv) without materialising it. */
+int visrep_im2col3x3(const void* x, void* y, int B, int H, int W, int C, int stride, int pad_mode, int upsample, int ldy, void* stream);
+
+/* activations.py GEGLU: y[m, f] = x[m, f] * gelu_erf(x[m, F + f]); x [M, >= 2F] bf16, y [M, >= F] bf16. */
+int visrep_geglu(const void* x, int ldx, void* y, int ldy, long M, int F, void* stream);
+
+/* softmax(scale * scores) per row: fp32 scores [rows, lds] -> bf16 probabilities [rows, ldp], columns [n, ldp) zeroed.
+ * Used by the single-head 512-wide VAE mid-block attention (attention_processor.py Attention, vae.py:UNetMidBlock2D). */
+int visrep_softmax_rows(const float* scores, int lds, void* probs, int ldp, int rows, int n, float scale, void* stream);
+
+/* [B, C, H, W] (dtype VISREP_BF16 | VISREP_F32) -> [B*H*W, Cpad] bf16, channels [C, Cpad) zero. */
+int visrep_nchw_to_tokens(const void* x, int dtype, void* y, int B, int C, int H, int W, int Cpad, void* stream);
+
+/* dift_sd.py:172-176: latents = (mean + exp(0.5 * clamp(logvar, -30, 20)) * post_noise) * scaling_factor
+ * (autoencoder_kl.py encode + vae.py DiagonalGaussianDistribution.sample), then DDIMScheduler.add_noise
+ * (scheduling_ddim.py:471-495): sqrt(ac) * latents + sqrt(1 - ac) * ddim_noise.  moments: fp32 [B*HW, ldm] with the mean
+ * in columns [0, Z) and the log-variance in [Z, 2Z) (quant_conv output); the two noise tensors are the reference's
+ * randn draws made explicit, fp32 [B, Z, H, W]; y: [B*HW, Cpad] bf16, channels [Z, Cpad) zero. */
+int visrep_sd_noisy_latents(const float* moments, int ldm, const float* post_noise, const float* ddim_noise, void* y, int B, int Z,
+                            int HW, int Cpad, float scaling, float alpha_cumprod, void* stream);
+
+/* dift_sd.py:275 ensemble mean: x [B, E, N] bf16 -> y [B, N] bf16 (fp32 accumulation). */
+int visrep_mean_groups(const void* x, void* y, int B, int E, long N, void* stream);
 
 #ifdef __cplusplus
 }

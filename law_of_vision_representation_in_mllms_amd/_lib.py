@@ -42,6 +42,15 @@ SIGNATURES = {
     "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "visrep_attention_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "visrep_groupnorm_workspace_bytes": (_sz, [_i, _i]),
+    "visrep_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "visrep_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "visrep_geglu": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
+    "visrep_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "visrep_nchw_to_tokens": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "visrep_sd_noisy_latents": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "visrep_mean_groups": (_i, [_vp, _vp, _i, _i, _l, _vp]),
     "visrep_im2col": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_cls_rows": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "visrep_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),

@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "attention.hip", "rowops.hip", "ascore.hip", "cscore.hip", "visrep_abi.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip", "cscore.hip", "visrep_abi.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 

@@ -1,10 +1,13 @@
-// Fused multi-head self-attention forward for ViT towers on gfx950 (head_dim 64, no mask, full softmax).
+// Fused multi-head attention forward on gfx950 (no mask, full softmax): ViT self-attention (head width 64) and the
+// UNet self- / cross-attention of the diffusion towers (head width D = 64*ND, narrower heads zero-padded by the weight
+// packer; key/value sequence of its own length Tk, optionally SHARED by all batch items - the prompt).
 //
 //   O[b, q, h, :] = softmax_k( Q[b,q,h,:] . K[b,k,h,:] * scale ) V[b,k,h,:]
 //
-// Layouts (produced by the QKV GEMM epilogues, gemm_bf16.hip):
-//   qk  : [M = B*T, 2*d] bf16 row-major, Q in columns [0,d), K in columns [d,2d), head h at h*64
-//   vt  : [d, ldvt] bf16, row n = h*64+dd, column perm16(m) over the GLOBAL token index m = b*T + t.
+// Layouts (produced by the GEMM epilogues, gemm_bf16.hip):
+//   q   : [B*Tq, ldq] bf16 row-major, head h at columns h*D;  k : [B*Tk (or Tk), ldk] likewise
+//         (ViT: one [M, 2d] buffer, Q in columns [0,d), K in columns [d,2d))
+//   vt  : [H*D, ldvt] bf16, row n = h*D+dd, column perm16(m) over the GLOBAL key index m = b*Tk + t.
 //         perm16 swaps the two middle 4-token groups of every aligned 16-token block (0,2,1,3), so that the eight
 //         keys one lane needs for a 32x32x16 MFMA k-slice are 16 contiguous bytes (see below).
 //   out : [M, d] bf16 row-major (heads concatenated), feeds the out-projection GEMM.
@@ -27,62 +30,66 @@
 namespace {
 
 constexpr int KT = 64;                    // keys per tile
-constexpr int TILE_B = KT * 64 * 2;       // 8 KB (K tile or V^T tile)
-constexpr int STAGE_B = 2 * TILE_B;
-constexpr int ATT_LDS = 2 * STAGE_B;      // 32 KB
+constexpr int TILE_B = KT * 64 * 2;       // 8 KB: one [64 keys x 64 d] K sub-tile or [64 d x 64 keys] V^T sub-tile
 
 struct AttnArgs {
-    const bf16_t* qk; const bf16_t* vt; bf16_t* out;
-    int B, T, H, M, ldqk, ldvt, ldo, d;
+    const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
+    int B, Tq, Tk, H, Mk, ldq, ldk, ldvt, ldo, kv_shared;
     float sc;                              // softmax scale * log2(e)
 };
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
+template <int ND>                          // head width D = 64 * ND
+__global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs p) {
+    constexpr int D = 64 * ND, KV_B = ND * TILE_B, STAGE_B = 2 * KV_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
-    const int nqt = (p.T + 127) >> 7;
+    const int nqt = (p.Tq + 127) >> 7;
     int id = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = id % nqt; id /= nqt;
     const int h = id % p.H;
     const int b = id / p.H;
-    const int tok0 = b * p.T, tok1 = tok0 + p.T;            // this image's global token range
+    const int tok0 = p.kv_shared ? 0 : b * p.Tk, tok1 = tok0 + p.Tk;   // this item's global key range
 
     // ---- Q fragments (B operand: col q = lane&31, k = d index 16*kk + 8*hi .. +8), kept in registers
     const int qloc = qt * 128 + wave * 32 + lq;
-    const int qrow = tok0 + (qloc < p.T ? qloc : p.T - 1);
-    bf16x8 qf[4];
+    const size_t qrow = (size_t)b * p.Tq + (qloc < p.Tq ? qloc : p.Tq - 1);
+    bf16x8 qf[4 * ND];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8*>(p.qk + (size_t)qrow * p.ldqk + h * 64 + kk * 16 + hi * 8);
+    for (int kk = 0; kk < 4 * ND; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8*>(p.q + qrow * p.ldq + h * D + kk * 16 + hi * 8);
 
     // ---- staging: 64 rows x 8 slots per tile = 2 chunks per thread per tile
     const int srow = tid >> 3;
     const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
     const int m_begin = tok0 & ~63;
     const int ntile = (((tok1 + 63) & ~63) - m_begin) >> 6;
-    const bf16_t* kbase = p.qk + p.d + h * 64 + lslot * 8;
-    const bf16_t* vbase = p.vt + (size_t)(h * 64 + srow) * p.ldvt + lslot * 8;
+    const bf16_t* kbase = p.k + h * D + lslot * 8;
+    const bf16_t* vbase = p.vt + (size_t)(h * D + srow) * p.ldvt + lslot * 8;
     auto stage = [&](int buf, int it) {
         char* sk = smem + buf * STAGE_B + wave * 1024;
-        char* sv = sk + TILE_B;
+        char* sv = sk + KV_B;
         const int mt = m_begin + it * KT;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int mk = mt + j * 32 + srow;
-            mk = mk < p.M ? mk : p.M - 1;                   // rows past the last token are masked below
-            glds16(kbase + (size_t)mk * p.ldqk, sk + j * 4096);
+            mk = mk < p.Mk ? mk : p.Mk - 1;                 // rows past the last token are masked below
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) glds16(kbase + (size_t)mk * p.ldk + nd * 64, sk + nd * TILE_B + j * 4096);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(vbase + (size_t)(j * 32) * p.ldvt + mt, sv + j * 4096);
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(vbase + (size_t)(nd * 64 + j * 32) * p.ldvt + mt, sv + nd * TILE_B + j * 4096);
     };
 
     // fragment read offsets inside a tile: row = 32*blk + lq, logical slot s -> physical s ^ ((lq>>1)&7)
     const int rsw = (lq >> 1) & 7;
     const int rbase = lq * 128;
 
-    f32x16 o[2];
-    o[0] = f32x16{}; o[1] = f32x16{};
+    f32x16 o[2 * ND];
+#pragma unroll
+    for (int dt = 0; dt < 2 * ND; ++dt) o[dt] = f32x16{};
     float m_run = -INFINITY, l_run = 0.f;
 
     stage(0, 0);
@@ -91,16 +98,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
         const int cur = it & 1;
         if (it + 1 < ntile) stage(cur ^ 1, it + 1);
         const char* sk = smem + cur * STAGE_B;
-        const char* sv = sk + TILE_B;
+        const char* sv = sk + KV_B;
 
         // ---- S^T tiles: s[kt2] = K[kt2*32.., :] . Q^T
         f32x16 s[2];
         s[0] = f32x16{}; s[1] = f32x16{};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < 4 * ND; ++kk) {
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + kt2 * 4096 + rbase + (((2 * kk + hi) ^ rsw) << 4));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + (kk >> 2) * TILE_B + kt2 * 4096 + rbase + (((2 * (kk & 3) + hi) ^ rsw) << 4));
                 s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt2], 0, 0, 0);
             }
         }
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.sc);
             l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int dt = 0; dt < 2 * ND; ++dt) o[dt][r] *= alpha;
             m_run = m_new;
         }
         l_run += psum;
@@ -151,8 +160,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
                 pf = *reinterpret_cast<bf16x8*>(&w);
             }
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + dt * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
+            for (int dt = 0; dt < 2 * ND; ++dt) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + (dt >> 1) * TILE_B + (dt & 1) * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
             }
         }
@@ -162,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
     // ---- normalise and store: lane holds O[q][d = dt*32 + 8*rg + 4*hi + (0..3)]
     l_run += __shfl_xor(l_run, 32);
     const float inv = 1.f / l_run;
-    if (qloc < p.T) {
-        bf16_t* orow = p.out + (size_t)(tok0 + qloc) * p.ldo + h * 64;
+    if (qloc < p.Tq) {
+        bf16_t* orow = p.out + ((size_t)b * p.Tq + qloc) * p.ldo + h * D;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 u32x2 v = {pack_bf16(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv),
@@ -177,18 +186,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64(const AttnArgs p) {
 
 }  // namespace
 
+extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
+                                    int B, int Tq, int Tk, int H, int head_dim, int kv_shared, float scale, void* stream) {
+    if (head_dim != 64 && head_dim != 128 && head_dim != 192)
+        return visrep_set_error(VISREP_ERR_SHAPE, "attention: head_dim must be 64, 128 or 192 (pad narrower heads with zero weights)");
+    if (B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "attention: empty problem");
+    if ((ldq % 8) || (ldk % 8) || (ldvt % 64) || (ldo % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "attention: bad leading dimension");
+    const long Mk = kv_shared ? Tk : (long)B * Tk;
+    if (ldvt < ((Mk + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "attention: ldvt must cover round_up(key rows, 64)");
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
+    a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.Mk = (int)Mk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.kv_shared = kv_shared;
+    a.sc = scale * 1.4426950408889634f;
+    const int nqt = (Tq + 127) / 128, nd = head_dim / 64;
+    const dim3 grid(nqt * H * B), block(256);
+    const size_t lds = (size_t)nd * 4 * TILE_B;             // double-buffered K + V^T tiles
+    hipStream_t st = (hipStream_t)stream;
+    if (nd == 1) hipLaunchKernelGGL(attn_fwd<1>, grid, block, lds, st, a);
+    else if (nd == 2) hipLaunchKernelGGL(attn_fwd<2>, grid, block, lds, st, a);
+    else {
+        static bool attr = false;                           // 96 KB of dynamic LDS needs the opt-in once
+        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL(attn_fwd<3>, grid, block, lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "attention: launch failed");
+}
+
 extern "C" int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo,
                                int B, int T, int H, int head_dim, float scale, void* stream) {
     if (head_dim != 64) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: only head_dim 64 is implemented");
-    if (B <= 0 || T <= 0 || H <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: empty problem");
-    if ((ldqk % 8) || (ldvt % 64) || (ldo % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: bad leading dimension");
-    const long M = (long)B * T;
-    if (ldvt < ((M + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: ldvt must cover round_up(B*T, 64)");
-    AttnArgs a;
-    a.qk = (const bf16_t*)qk; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
-    a.B = B; a.T = T; a.H = H; a.M = (int)M; a.ldqk = ldqk; a.ldvt = ldvt; a.ldo = ldo; a.d = H * 64;
-    a.sc = scale * 1.4426950408889634f;
-    const int nqt = (T + 127) / 128;
-    hipLaunchKernelGGL(attn_fwd_d64, dim3(nqt * H * B), dim3(256), ATT_LDS, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mhsa: launch failed");
+    return visrep_attention_fwd(qk, ldqk, (const bf16_t*)qk + (size_t)H * 64, ldqk, vt, ldvt, out, ldo, B, T, T, H, 64, 0, scale, stream);
 }

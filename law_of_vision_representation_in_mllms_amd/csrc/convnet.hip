@@ -1,0 +1,320 @@
+// Convolutional-tower primitives of the diffusion feature extractors (SD UNet + VAE encoder) on gfx950.
+//
+// Data layout: every activation is CHANNELS-LAST, token-major bf16 - a [B*H*W, C] matrix, the same thing the GEMM and
+// attention kernels consume.  1x1 convolutions and Linear layers are then plain GEMMs, the transformer blocks need no
+// NCHW<->token permutes (the reference does two per block, transformer_2d.py:145,170), and a 3x3 convolution is
+// gather (this file) + GEMM with K = 9*C ordered (tap, channel), weights repacked [Cout, 3, 3, Cin] once at load time.
+//
+// Everything here is HBM-bound element/gather work: 16-byte accesses, coalesced along the channel axis.
+//   groupnorm_stats / groupnorm_apply   GroupNorm(+SiLU) over (H*W, C/groups) per (image, group)     resnet.py:ResnetBlock2D
+//   im2col3x3                           3x3 patch gather: stride 1|2, symmetric or (0,1,0,1) padding, optional fused
+//                                       nearest-2x upsample of the source (upsampling.py Upsample2D, downsampling.py)
+//   geglu                               val * gelu(gate)                                              activations.py GEGLU
+//   softmax_rows                        fp32 scores -> bf16 probabilities (single-head VAE attention)
+//   nchw_to_tokens                      [B,C,H,W] fp32|bf16 -> [B*H*W, Cpad] bf16, zero-padded channels
+//   sd_noisy_latents                    posterior sample * scaling_factor, then DDIM add_noise       dift_sd.py:172-176
+//   mean_groups                         ensemble mean                                                 dift_sd.py:275
+#include "common.h"
+#include "visrep_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// stats[(b*G + g)*2 + {0,1}] += sum, sum of squares.  Block = 256 threads laid out [R row lanes][W channel-pair lanes].
+__global__ __launch_bounds__(256) void groupnorm_stats(const bf16_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int cpg,
+                                                       int rows_per_block, int W) {
+    __shared__ float acc[2 * 128];
+    const int tid = threadIdx.x, b = blockIdx.y, G = C / cpg;
+    for (int i = tid; i < 2 * G; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int tc = tid % W, tr = tid / W, R = 256 / W;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(x + (size_t)b * HW * C);
+    const int npair = C >> 1;
+    for (int c2 = tc; c2 < npair; c2 += W) {
+        float s = 0.f, ss = 0.f;
+        int r = r0 + tr;
+        for (; r + 3 * R < r1; r += 4 * R) {                   // four independent loads in flight
+            const uint32_t v0 = base[(size_t)r * npair + c2], v1 = base[(size_t)(r + R) * npair + c2];
+            const uint32_t v2 = base[(size_t)(r + 2 * R) * npair + c2], v3 = base[(size_t)(r + 3 * R) * npair + c2];
+            const float a0 = bf_lo(v0), a1 = bf_hi(v0), a2 = bf_lo(v1), a3 = bf_hi(v1);
+            const float a4 = bf_lo(v2), a5 = bf_hi(v2), a6 = bf_lo(v3), a7 = bf_hi(v3);
+            s += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+            ss += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7));
+        }
+        for (; r < r1; r += R) {
+            const uint32_t v = base[(size_t)r * npair + c2];
+            const float a0 = bf_lo(v), a1 = bf_hi(v);
+            s += a0 + a1;
+            ss += a0 * a0 + a1 * a1;
+        }
+        const int g = (2 * c2) / cpg;                          // cpg is even: both channels of a pair share a group
+        atomicAdd(&acc[2 * g], s);
+        atomicAdd(&acc[2 * g + 1], ss);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * G; i += 256) atomicAdd(&stats[(size_t)b * 2 * G + i], acc[i]);
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, long total_vec, int HW, int C, int cpg, float eps, int silu) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_vec) return;
+    const int cv8 = C >> 3;
+    const long row = idx / cv8;
+    const int c0 = (int)(idx - row * cv8) * 8;
+    const int b = (int)(row / HW), G = C / cpg;
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + row * C + c0);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(raw[e]); v[2 * e + 1] = bf_hi(raw[e]); }
+    int gprev = -1;
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c0 + e) / cpg;
+        if (g != gprev) {
+            const float s = stats[((size_t)b * G + g) * 2], ss = stats[((size_t)b * G + g) * 2 + 1];
+            mean = s * inv_n;
+            const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+            rstd = rsqrtf(var + eps);
+            gprev = g;
+        }
+        float o = (v[e] - mean) * rstd * gm[e] + bt[e];
+        if (silu) o = o * __builtin_amdgcn_rcpf(1.0f + __expf(-o));
+        v[e] = o;
+    }
+    u32x4 out = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(y + row * C + c0) = out;
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 gather
+struct Im2colArgs {
+    const bf16_t* x; bf16_t* y;
+    int B, H, W, C, Ho, Wo, stride, pad_lo, up, ldy;            // H, W: source size BEFORE the optional 2x upsample
+};
+
+__global__ __launch_bounds__(256) void im2col3x3(const Im2colArgs p, long total_vec) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_vec) return;
+    const int vec_per_row = p.ldy >> 3, cv8 = p.C >> 3;
+    const long orow = idx / vec_per_row;
+    const int v = (int)(idx - orow * vec_per_row);
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (v < 9 * cv8) {
+        const int tap = v / cv8, c0 = (v - tap * cv8) * 8;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int hw = p.Ho * p.Wo;
+        const int b = (int)(orow / hw), pix = (int)(orow - (long)b * hw);
+        const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+        int iy = oy * p.stride + ky - p.pad_lo, ix = ox * p.stride + kx - p.pad_lo;
+        const int Hl = p.H << p.up, Wl = p.W << p.up;          // logical (upsampled) source size
+        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) {
+            iy >>= p.up; ix >>= p.up;                           // nearest neighbour: floor(i / 2)
+            val = *reinterpret_cast<const u32x4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.C + c0);
+        }
+    }
+    *reinterpret_cast<u32x4*>(p.y + orow * p.ldy + (size_t)v * 8) = val;
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+__global__ __launch_bounds__(256) void geglu(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long total_vec, int F, int ldx, int ldy) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_vec) return;
+    const int fv = F >> 3;
+    const long row = idx / fv;
+    const int f0 = (int)(idx - row * fv) * 8;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(x + row * ldx + f0);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(x + row * ldx + F + f0);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
+        const float h0 = 0.5f * g0 * (1.0f + erff(g0 * 0.70710678118654752f)), h1 = 0.5f * g1 * (1.0f + erff(g1 * 0.70710678118654752f));
+        o[e] = pack_bf16(bf_lo(a[e]) * h0, bf_hi(a[e]) * h1);
+    }
+    *reinterpret_cast<u32x4*>(y + row * ldy + f0) = o;
+}
+
+// ------------------------------------------------------------------------------------------------ row softmax (fp32 -> bf16)
+__global__ __launch_bounds__(256) void softmax_rows(const float* __restrict__ s, bf16_t* __restrict__ pr, int n, int lds_, int ldp, float scale) {
+    __shared__ float red[4];
+    const float* row = s + (size_t)blockIdx.x * lds_;
+    bf16_t* out = pr + (size_t)blockIdx.x * ldp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, row[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float sc = scale * 1.4426950408889634f;
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) sum += __builtin_amdgcn_exp2f((row[i] - m) * sc);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = tid; i < ldp; i += 256) {                       // pad columns [n, ldp) are written as zeros (GEMM K padding)
+        const float v = i < n ? __builtin_amdgcn_exp2f((row[i] - m) * sc) * inv : 0.f;
+        out[i] = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout / latent helpers
+template <bool F32>
+VR_DEV float ld_elem(const void* x, long i) {
+    if (F32) return reinterpret_cast<const float*>(x)[i];
+    return __uint_as_float((uint32_t) reinterpret_cast<const bf16_t*>(x)[i] << 16);
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void nchw_to_tokens(const void* __restrict__ x, bf16_t* __restrict__ y, long total, int C, int HW, int Cpad) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // one thread per (b, pixel)
+    if (idx >= total) return;
+    const long b = idx / HW;
+    const int pix = (int)(idx - b * HW);
+    bf16_t* out = y + idx * Cpad;
+    for (int c = 0; c < Cpad; c += 2) {
+        const float v0 = c < C ? ld_elem<F32>(x, (b * C + c) * HW + pix) : 0.f;
+        const float v1 = c + 1 < C ? ld_elem<F32>(x, (b * C + c + 1) * HW + pix) : 0.f;
+        *reinterpret_cast<uint32_t*>(out + c) = pack_bf16(v0, v1);
+    }
+}
+
+__global__ __launch_bounds__(256) void sd_noisy_latents(const float* __restrict__ moments, int ldm, const float* __restrict__ post,
+                                                        const float* __restrict__ ddim, bf16_t* __restrict__ y, long total, int Z, int HW,
+                                                        int Cpad, float scaling, float sqrt_ac, float sqrt_1mac) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // one thread per (b, pixel)
+    if (idx >= total) return;
+    const long b = idx / HW;
+    const int pix = (int)(idx - b * HW);
+    const float* mrow = moments + idx * ldm;
+    bf16_t* out = y + idx * Cpad;
+    for (int c = 0; c < Cpad; c += 2) {
+        float v[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ch = c + e;
+            if (ch < Z) {
+                const float mean = mrow[ch], logvar = fminf(fmaxf(mrow[Z + ch], -30.0f), 20.0f);
+                const long ni = (b * Z + ch) * HW + pix;
+                const float lat = (mean + __expf(0.5f * logvar) * post[ni]) * scaling;
+                v[e] = sqrt_ac * lat + sqrt_1mac * ddim[ni];
+            }
+        }
+        *reinterpret_cast<uint32_t*>(out + c) = pack_bf16(v[0], v[1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_groups(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long total_pairs, long n_pairs, int E) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // one thread per output bf16 pair
+    if (idx >= total_pairs) return;
+    const long b = idx / n_pairs, i = idx - b * n_pairs;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(x) + b * E * n_pairs + i;
+    float s0 = 0.f, s1 = 0.f;
+    for (int e = 0; e < E; ++e) { const uint32_t v = src[(long)e * n_pairs]; s0 += bf_lo(v); s1 += bf_hi(v); }
+    const float inv = 1.0f / (float)E;
+    reinterpret_cast<uint32_t*>(y)[idx] = pack_bf16(s0 * inv, s1 * inv);
+}
+
+inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
+inline int launched(const char* what) {
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, what);
+}
+
+}  // namespace
+
+extern "C" size_t visrep_groupnorm_workspace_bytes(int B, int groups) { return (size_t)B * groups * 2 * sizeof(float); }
+
+extern "C" int visrep_groupnorm(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups,
+                                float eps, int silu, void* workspace, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: empty problem");
+    if (C % groups || C % 8 || groups > 128) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: C must be a multiple of groups and of 8, groups <= 128");
+    const int cpg = C / groups;
+    if (cpg & 1) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: channels per group must be even");
+    if (!workspace) return visrep_set_error(VISREP_ERR_ARG, "groupnorm: workspace missing");
+    hipStream_t st = (hipStream_t)stream;
+    float* stats = (float*)workspace;
+    if (hipMemsetAsync(stats, 0, visrep_groupnorm_workspace_bytes(B, groups), st) != hipSuccess)
+        return visrep_set_error(VISREP_ERR_LAUNCH, "groupnorm: memset failed");
+    const int npair = C / 2;
+    int W = 256;
+    if (npair <= 128) { W = 1; while (W < npair) W <<= 1; }
+    // enough blocks to fill 256 CUs a few times over, but at least 32 rows per block so LDS/global atomics stay negligible
+    int rows = (int)(((long)B * HW + 2047) / 2048);
+    rows = rows < 32 ? 32 : rows;
+    rows = rows > HW ? HW : rows;
+    const dim3 grid((HW + rows - 1) / rows, B);
+    hipLaunchKernelGGL(groupnorm_stats, grid, dim3(256), 0, st, (const bf16_t*)x, stats, HW, C, cpg, rows, W);
+    const long total = (long)B * HW * (C / 8);
+    hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float*)stats, gamma, beta,
+                       (bf16_t*)y, total, HW, C, cpg, eps, silu);
+    return launched("groupnorm: launch failed");
+}
+
+extern "C" int visrep_im2col3x3(const void* x, void* y, int B, int H, int W, int C, int stride, int pad_mode, int upsample, int ldy,
+                                void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "im2col3x3: empty problem");
+    if (C % 8 || ldy % 8 || ldy < 9 * C) return visrep_set_error(VISREP_ERR_SHAPE, "im2col3x3: C and ldy must be multiples of 8, ldy >= 9*C");
+    if ((stride != 1 && stride != 2) || (pad_mode != 0 && pad_mode != 1) || (upsample != 0 && upsample != 1))
+        return visrep_set_error(VISREP_ERR_ARG, "im2col3x3: stride 1|2, pad_mode 0 (symmetric 1) | 1 (0,1,0,1), upsample 0|1");
+    Im2colArgs a;
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.B = B; a.H = H; a.W = W; a.C = C; a.stride = stride; a.up = upsample; a.ldy = ldy;
+    a.pad_lo = pad_mode == 0 ? 1 : 0;
+    const int Hl = H << upsample, Wl = W << upsample, pad_total = pad_mode == 0 ? 2 : 1;
+    a.Ho = (Hl + pad_total - 3) / stride + 1;
+    a.Wo = (Wl + pad_total - 3) / stride + 1;
+    const long total = (long)B * a.Ho * a.Wo * (ldy / 8);
+    hipLaunchKernelGGL(im2col3x3, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, a, total);
+    return launched("im2col3x3: launch failed");
+}
+
+extern "C" int visrep_geglu(const void* x, int ldx, void* y, int ldy, long M, int F, void* stream) {
+    if (M <= 0 || F <= 0 || F % 8 || ldx % 8 || ldy % 8) return visrep_set_error(VISREP_ERR_SHAPE, "geglu: F and leading dimensions must be multiples of 8");
+    const long total = M * (F / 8);
+    hipLaunchKernelGGL(geglu, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, total, F, ldx, ldy);
+    return launched("geglu: launch failed");
+}
+
+extern "C" int visrep_softmax_rows(const float* scores, int lds_, void* probs, int ldp, int rows, int n, float scale, void* stream) {
+    if (rows <= 0 || n <= 0 || ldp < n || lds_ < n) return visrep_set_error(VISREP_ERR_SHAPE, "softmax_rows: bad shape");
+    hipLaunchKernelGGL(softmax_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, (bf16_t*)probs, n, lds_, ldp, scale);
+    return launched("softmax_rows: launch failed");
+}
+
+extern "C" int visrep_nchw_to_tokens(const void* x, int dtype, void* y, int B, int C, int H, int W, int Cpad, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || (Cpad & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "nchw_to_tokens: bad shape");
+    const long total = (long)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VISREP_F32)
+        hipLaunchKernelGGL(nchw_to_tokens<true>, dim3(blocks_for(total)), dim3(256), 0, st, x, (bf16_t*)y, total, C, H * W, Cpad);
+    else if (dtype == VISREP_BF16)
+        hipLaunchKernelGGL(nchw_to_tokens<false>, dim3(blocks_for(total)), dim3(256), 0, st, x, (bf16_t*)y, total, C, H * W, Cpad);
+    else return visrep_set_error(VISREP_ERR_ARG, "nchw_to_tokens: dtype must be bf16 (0) or f32 (1)");
+    return launched("nchw_to_tokens: launch failed");
+}
+
+extern "C" int visrep_sd_noisy_latents(const float* moments, int ldm, const float* post_noise, const float* ddim_noise, void* y, int B,
+                                       int Z, int HW, int Cpad, float scaling, float alpha_cumprod, void* stream) {
+    if (B <= 0 || Z <= 0 || HW <= 0 || Cpad < Z || (Cpad & 1) || ldm < 2 * Z) return visrep_set_error(VISREP_ERR_SHAPE, "sd_noisy_latents: bad shape");
+    if (!(alpha_cumprod > 0.f && alpha_cumprod <= 1.f)) return visrep_set_error(VISREP_ERR_ARG, "sd_noisy_latents: alpha_cumprod out of (0, 1]");
+    const long total = (long)B * HW;
+    hipLaunchKernelGGL(sd_noisy_latents, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, moments, ldm, post_noise, ddim_noise,
+                       (bf16_t*)y, total, Z, HW, Cpad, scaling, sqrtf(alpha_cumprod), sqrtf(1.0f - alpha_cumprod));
+    return launched("sd_noisy_latents: launch failed");
+}
+
+extern "C" int visrep_mean_groups(const void* x, void* y, int B, int E, long N, void* stream) {
+    if (B <= 0 || E <= 0 || N <= 0 || (N & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "mean_groups: N must be even");
+    const long total = (long)B * (N / 2);
+    hipLaunchKernelGGL(mean_groups, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, total, N / 2, E);
+    return launched("mean_groups: launch failed");
+}

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = p.N / BN;
+    const int ntn = (p.N + BN - 1) / BN;                      // N % 64 == 0: the last tile column may be half empty
     const int ntm = (p.M + BM - 1) / BM;
     const int t = xcd_remap(blockIdx.x, ntm * ntn);
     const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
         int ra = m0 + j * 32 + srow;
         ra = ra < p.M ? ra : p.M - 1;                          // clamp: rows past M are computed but never stored
         ga[j] = p.A + (size_t)ra * p.lda + lslot * 8;
-        gw[j] = p.W + (size_t)(n0 + j * 32 + srow) * p.ldw + lslot * 8;
+        int rw = n0 + j * 32 + srow;
+        rw = rw < p.N ? rw : p.N - 1;
+        gw[j] = p.W + (size_t)rw * p.ldw + lslot * 8;
     }
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE_BYTES + wave * 1024;
@@ -98,13 +100,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     }
 
     // ------------------------------------------------------------------ epilogues (gemm_epilogue.h)
+    if (n0 + wn * 64 >= p.N) return;                          // wave-uniform: the empty half of an N-edge tile
     if (EPI == EPI_VT) gemm_epilogue_vt<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
     else gemm_epilogue_rowmajor<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
 
 template <int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
-    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -158,7 +161,7 @@ int cu_count() {
 
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
-    if (a.N % BN != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N must be a multiple of 128 and K of 64");
+    if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
     const int variant = g_visrep_gemm_variant;
     // Tile quantisation: the persistent 256x256 kernels run one block per CU, so T tiles cost ceil(T / CUs) tile-times.

@@ -1,0 +1,462 @@
+"""Stable-Diffusion feature tower on MI355X: VAE encoder -> noisy latents -> truncated UNet -> up-block features.
+
+Device-side counterpart of `SDFeaturizer.forward` (llava/model/multimodal_encoder/diffLVLM/src/models/dift_sd.py:239-276,
+pipeline body :157-188, UNet subclass :9-155).  Every FLOP runs in libvisrep_hip.so; torch is used for device memory,
+weight repacking at load time and the two `randn` draws (which the reference also makes with torch).
+
+MI355X-first layout: activations are channels-last token matrices [B*H*W, C] bf16 end to end, so
+  * 1x1 convs / Linear / attention projections are plain MFMA GEMMs (csrc/gemm_bf16*.hip) with fused bias / residual,
+  * 3x3 convs are `visrep_im2col3x3` + GEMM (stride, the VAE's one-sided padding and the nearest-2x upsample are folded
+    into the gather),
+  * the transformer blocks never permute NCHW <-> tokens, and the tower's output [B, h*w, c] is the UNet's own layout
+    (the reference permutes it there, diffusion_encoder.py:84-88),
+  * the timestep embedding is a constant per (t, resnet): it is folded into each resnet's conv1 bias at `set_timestep`,
+  * `quant_conv` (1x1) is folded into the VAE's `conv_out` (3x3) at load time,
+  * cross-attention K / V^T of the prompt are computed once per prompt and shared by every image (kv_shared),
+  * heads narrower than the attention kernel's 64-wide granule (SD1.5: 40 / 80 / 160) are zero-padded in the packed
+    projection weights; softmax(QK^T)V is unchanged by zero columns.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .engine import gemm, layernorm, linear_vt
+from .sd_weights import SdSpec, up_block_plan
+
+
+def _ru(v: int, a: int) -> int:
+    return (v + a - 1) // a * a
+
+
+# ------------------------------------------------------------------------------------------------ thin op wrappers
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, groups: int, eps: float, silu: bool) -> torch.Tensor:
+    """x [B*HW, C] bf16 contiguous -> GroupNorm(+SiLU), same shape."""
+    lib = _lib.require_gpu()
+    M, C = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty(lib.visrep_groupnorm_workspace_bytes(B, groups), dtype=torch.uint8, device=x.device)
+    rc = lib.visrep_groupnorm(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), B, M // B, C, groups, float(eps), int(silu),
+                              _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, "visrep_groupnorm")
+    return y
+
+
+def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, ld: int, stride: int = 1, pad_mode: int = 0, upsample: bool = False):
+    """x [B*H*W, C] -> ([B*Ho*Wo, ld] bf16, Ho, Wo)."""
+    lib = _lib.require_gpu()
+    C = x.shape[1]
+    Hl, Wl = (H * 2, W * 2) if upsample else (H, W)
+    pad_total = 2 if pad_mode == 0 else 1
+    Ho, Wo = (Hl + pad_total - 3) // stride + 1, (Wl + pad_total - 3) // stride + 1
+    y = torch.empty(B * Ho * Wo, ld, dtype=torch.bfloat16, device=x.device)
+    rc = lib.visrep_im2col3x3(_lib.ptr(x), _lib.ptr(y), B, H, W, C, stride, pad_mode, int(upsample), ld, _lib.stream_ptr())
+    _lib.check(rc, "visrep_im2col3x3")
+    return y, Ho, Wo
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    M, F2 = x.shape
+    y = torch.empty(M, F2 // 2, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.visrep_geglu(_lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), M, F2 // 2, _lib.stream_ptr()), "visrep_geglu")
+    return y
+
+
+def attention(q, k, vt, out_cols: int, B: int, Tq: int, Tk: int, H: int, head_dim: int, scale: float, kv_shared: bool) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    out = torch.empty(B * Tq, out_cols, dtype=torch.bfloat16, device=q.device)
+    rc = lib.visrep_attention_fwd(_lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(vt), vt.stride(0), _lib.ptr(out),
+                                  out.stride(0), B, Tq, Tk, H, head_dim, int(kv_shared), float(scale), _lib.stream_ptr())
+    _lib.check(rc, "visrep_attention_fwd")
+    return out
+
+
+def softmax_rows(scores: torch.Tensor, n: int, ldp: int, scale: float) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    rows = scores.shape[0]
+    p = torch.empty(rows, ldp, dtype=torch.bfloat16, device=scores.device)
+    rc = lib.visrep_softmax_rows(_lib.ptr(scores), scores.stride(0), _lib.ptr(p), ldp, rows, n, float(scale), _lib.stream_ptr())
+    _lib.check(rc, "visrep_softmax_rows")
+    return p
+
+
+def nchw_to_tokens(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    B, C, H, W = x.shape
+    y = torch.empty(B * H * W, cpad, dtype=torch.bfloat16, device=x.device)
+    rc = lib.visrep_nchw_to_tokens(_lib.ptr(x), _lib.F32 if x.dtype == torch.float32 else _lib.BF16, _lib.ptr(y), B, C, H, W, cpad,
+                                   _lib.stream_ptr())
+    _lib.check(rc, "visrep_nchw_to_tokens")
+    return y
+
+
+def mean_groups(x: torch.Tensor, B: int, E: int) -> torch.Tensor:
+    lib = _lib.require_gpu()
+    N = x.numel() // (B * E)
+    y = torch.empty(B, N, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.visrep_mean_groups(_lib.ptr(x), _lib.ptr(y), B, E, N, _lib.stream_ptr()), "visrep_mean_groups")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ packed parameters
+class _Lin:
+    """GEMM operand: W [Np, Kp] bf16 (zero padded), bias fp32 [Np] or None; n = true output width."""
+    __slots__ = ("w", "b", "n")
+
+    def __init__(self, w, b, n):
+        self.w, self.b, self.n = w, b, n
+
+
+class SdEngine:
+    def __init__(self, spec: SdSpec, w_unet: Dict[str, torch.Tensor], w_vae: Dict[str, torch.Tensor], device=None, up_ft_index: int = 0):
+        _lib.require_gpu()
+        self.spec = spec
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.up_ft_index = up_ft_index
+        self.wu = {k: v.detach().float() for k, v in w_unet.items()}       # fp32 masters on the host (repacked below)
+        self.wv = {k: v.detach().float() for k, v in w_vae.items()}
+        u = spec.unet
+        if up_ft_index >= len(u.block_out):
+            raise ValueError("up_ft_index out of range")
+        for c in u.block_out + spec.vae.block_out:
+            if c % 64:
+                raise ValueError("block widths must be multiples of 64")
+        self.P: Dict[str, object] = {}
+        self._pack_vae()
+        self._pack_unet()
+        self._t = None
+        self._ctx = None
+        self._ac = spec.sched.alphas_cumprod()
+
+    # ---------------------------------------------------------------- packing helpers
+    def _dev(self, t, dtype):
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _lin(self, w2d: torch.Tensor, b: Optional[torch.Tensor]) -> _Lin:
+        n, k = w2d.shape
+        W = torch.zeros(_ru(n, 64), _ru(k, 64), dtype=torch.float32)
+        W[:n, :k] = w2d
+        bias = None
+        if b is not None:
+            bias = torch.zeros(_ru(n, 64), dtype=torch.float32)
+            bias[:n] = b
+            bias = self._dev(bias, torch.float32)
+        return _Lin(self._dev(W, torch.bfloat16), bias, n)
+
+    def _conv3(self, w: torch.Tensor, b: torch.Tensor) -> _Lin:
+        co, ci = w.shape[:2]
+        cp = _ru(ci, 8)
+        W = torch.zeros(co, 9, cp, dtype=torch.float32)
+        W[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)             # K order = (ky, kx, c): matches visrep_im2col3x3
+        return self._lin(W.reshape(co, 9 * cp), b)
+
+    def _norm(self, w, p):
+        return self._dev(w[f"{p}.weight"], torch.float32), self._dev(w[f"{p}.bias"], torch.float32)
+
+    def _pack_resnet(self, w, p):
+        P = self.P
+        P[f"{p}.norm1"] = self._norm(w, f"{p}.norm1")
+        P[f"{p}.norm2"] = self._norm(w, f"{p}.norm2")
+        P[f"{p}.conv1"] = self._conv3(w[f"{p}.conv1.weight"], w[f"{p}.conv1.bias"])
+        P[f"{p}.conv2"] = self._conv3(w[f"{p}.conv2.weight"], w[f"{p}.conv2.bias"])
+        if f"{p}.conv_shortcut.weight" in w:
+            sw = w[f"{p}.conv_shortcut.weight"]
+            P[f"{p}.conv_shortcut"] = self._lin(sw.reshape(sw.shape[0], -1), w[f"{p}.conv_shortcut.bias"])
+
+    @staticmethod
+    def _pad_heads_out(w2d, heads, dp):
+        """[H*dh, K] -> [H*dp, K]: output features regrouped per head, zero rows appended to each head."""
+        d, k = w2d.shape
+        dh = d // heads
+        out = torch.zeros(heads, dp, k)
+        out[:, :dh] = w2d.reshape(heads, dh, k)
+        return out.reshape(heads * dp, k)
+
+    @staticmethod
+    def _pad_heads_in(w2d, heads, dp):
+        """[N, H*dh] -> [N, H*dp]: input features regrouped per head, zero columns appended to each head."""
+        n, d = w2d.shape
+        dh = d // heads
+        out = torch.zeros(n, heads, dp)
+        out[:, :, :dh] = w2d.reshape(n, heads, dh)
+        return out.reshape(n, heads * dp)
+
+    def _pack_transformer(self, w, p, heads):
+        P = self.P
+        d = w[f"{p}.norm.weight"].shape[0]
+        dh = d // heads
+        dp = _ru(dh, 64)
+        if dp > 192:
+            raise ValueError(f"attention head width {dh} exceeds the kernel's 192")
+        P[f"{p}.meta"] = (heads, dh, dp)
+        P[f"{p}.norm"] = self._norm(w, f"{p}.norm")
+        for n in ("proj_in", "proj_out"):
+            pw = w[f"{p}.{n}.weight"]
+            P[f"{p}.{n}"] = self._lin(pw.reshape(pw.shape[0], -1), w[f"{p}.{n}.bias"])
+        b = f"{p}.transformer_blocks.0"
+        for n in ("norm1", "norm2", "norm3"):
+            P[f"{b}.{n}"] = self._norm(w, f"{b}.{n}")
+        pad_o = lambda name: self._pad_heads_out(w[name], heads, dp)
+        P[f"{b}.attn1.qk"] = self._lin(torch.cat([pad_o(f"{b}.attn1.to_q.weight"), pad_o(f"{b}.attn1.to_k.weight")], 0), None)
+        P[f"{b}.attn1.v"] = self._lin(pad_o(f"{b}.attn1.to_v.weight"), None)
+        P[f"{b}.attn1.o"] = self._lin(self._pad_heads_in(w[f"{b}.attn1.to_out.0.weight"], heads, dp), w[f"{b}.attn1.to_out.0.bias"])
+        P[f"{b}.attn2.q"] = self._lin(pad_o(f"{b}.attn2.to_q.weight"), None)
+        P[f"{b}.attn2.k"] = self._lin(pad_o(f"{b}.attn2.to_k.weight"), None)
+        P[f"{b}.attn2.v"] = self._lin(pad_o(f"{b}.attn2.to_v.weight"), None)
+        P[f"{b}.attn2.o"] = self._lin(self._pad_heads_in(w[f"{b}.attn2.to_out.0.weight"], heads, dp), w[f"{b}.attn2.to_out.0.bias"])
+        P[f"{b}.ff1"] = self._lin(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"])
+        P[f"{b}.ff2"] = self._lin(w[f"{b}.ff.net.2.weight"], w[f"{b}.ff.net.2.bias"])
+
+    def _pack_vae(self):
+        v, w = self.spec.vae, self.wv
+        self.P["vae.conv_in"] = self._conv3(w["encoder.conv_in.weight"], w["encoder.conv_in.bias"])
+        for i in range(len(v.block_out)):
+            for j in range(v.layers_per_block):
+                self._pack_resnet(w, f"encoder.down_blocks.{i}.resnets.{j}")
+            if i != len(v.block_out) - 1:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                self.P[p] = self._conv3(w[f"{p}.weight"], w[f"{p}.bias"])
+        self._pack_resnet(w, "encoder.mid_block.resnets.0")
+        self._pack_resnet(w, "encoder.mid_block.resnets.1")
+        a = "encoder.mid_block.attentions.0"
+        self.P[f"{a}.group_norm"] = self._norm(w, f"{a}.group_norm")
+        for n in ("to_q", "to_k", "to_out.0"):
+            self.P[f"{a}.{n}"] = self._lin(w[f"{a}.{n}.weight"], w[f"{a}.{n}.bias"])
+        # V is produced transposed by a role-swapped GEMM (A = Wv); its bias moves to the P.V product (rows of P sum to 1)
+        self.P[f"{a}.to_v"] = self._lin(w[f"{a}.to_v.weight"], None)
+        self.P[f"{a}.to_v.bias"] = self._dev(w[f"{a}.to_v.bias"], torch.float32)
+        self.P["encoder.conv_norm_out"] = self._norm(w, "encoder.conv_norm_out")
+        # quant_conv (1x1) o conv_out (3x3) is one 3x3 convolution: W' = Wq Wc, b' = Wq bc + bq
+        wq = w["quant_conv.weight"].reshape(w["quant_conv.weight"].shape[0], -1)
+        wc = w["encoder.conv_out.weight"]
+        wfold = torch.einsum("oz,zikl->oikl", wq, wc)
+        bfold = wq @ w["encoder.conv_out.bias"] + w["quant_conv.bias"]
+        self.P["vae.moments"] = self._conv3(wfold, bfold)
+
+    def _pack_unet(self):
+        u, w = self.spec.unet, self.wu
+        self.P["conv_in"] = self._conv3(w["conv_in.weight"], w["conv_in.bias"])
+        for i in range(len(u.block_out)):
+            for j in range(u.layers_per_block):
+                self._pack_resnet(w, f"down_blocks.{i}.resnets.{j}")
+                if u.down_types[i].startswith("CrossAttn"):
+                    self._pack_transformer(w, f"down_blocks.{i}.attentions.{j}", u.heads[i])
+            if i != len(u.block_out) - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                self.P[p] = self._conv3(w[f"{p}.weight"], w[f"{p}.bias"])
+        self._pack_resnet(w, "mid_block.resnets.0")
+        self._pack_transformer(w, "mid_block.attentions.0", u.heads[-1])
+        self._pack_resnet(w, "mid_block.resnets.1")
+        rev_heads = tuple(reversed(u.heads))
+        for i in range(self.up_ft_index + 1):
+            cins, out, attn, ups = up_block_plan(u, i)
+            for j in range(len(cins)):
+                self._pack_resnet(w, f"up_blocks.{i}.resnets.{j}")
+                if attn:
+                    self._pack_transformer(w, f"up_blocks.{i}.attentions.{j}", rev_heads[i])
+            if ups:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                self.P[p] = self._conv3(w[f"{p}.weight"], w[f"{p}.bias"])
+
+    # ---------------------------------------------------------------- per-run constants
+    def set_timestep(self, t: int):
+        """Fold time_emb_proj(silu(time_embedding(t))) into every UNet resnet's conv1 bias (resnet.py:ResnetBlock2D.forward)."""
+        if self._t == int(t):
+            return
+        u, w = self.spec.unet, self.wu
+        half = u.block_out[0] // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        e = float(t) * freqs
+        temb = torch.cat([torch.cos(e), torch.sin(e)])[None]                                   # flip_sin_to_cos, shift 0
+        temb = torch.nn.functional.silu(temb @ w["time_embedding.linear_1.weight"].t() + w["time_embedding.linear_1.bias"])
+        temb = temb @ w["time_embedding.linear_2.weight"].t() + w["time_embedding.linear_2.bias"]
+        act = torch.nn.functional.silu(temb)
+        for name in [k[: -len(".time_emb_proj.weight")] for k in w if k.endswith(".time_emb_proj.weight")]:
+            if f"{name}.conv1" not in self.P:
+                continue
+            add = (act @ w[f"{name}.time_emb_proj.weight"].t() + w[f"{name}.time_emb_proj.bias"])[0]
+            lin = self.P[f"{name}.conv1"]
+            b = torch.zeros(lin.w.shape[0], dtype=torch.float32)
+            b[: lin.n] = w[f"{name}.conv1.bias"] + add
+            lin.b = self._dev(b, torch.float32)
+        self._t = int(t)
+
+    def set_prompt(self, prompt_embeds: torch.Tensor):
+        """prompt_embeds [1, L, cross_dim] (pipe.encode_prompt output, dift_sd.py:258-263): per-layer K and V^T, computed once."""
+        ctx = prompt_embeds.reshape(-1, prompt_embeds.shape[-1]).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        self._ctx_len = ctx.shape[0]
+        self._ctx = {}
+        for key in [k for k in self.P if k.endswith(".attn2.k")]:
+            b = key[: -len(".attn2.k")]
+            self._ctx[b] = (gemm(ctx, self.P[f"{b}.attn2.k"].w), linear_vt(ctx, self.P[f"{b}.attn2.v"].w, None))
+
+    # ---------------------------------------------------------------- building blocks (token-major)
+    def _conv(self, x, B, H, W, name, stride=1, pad_mode=0, upsample=False, epi=_lib.EPI_BIAS, resid=None):
+        lin = self.P[name]
+        cols, Ho, Wo = im2col3x3(x, B, H, W, lin.w.shape[1], stride, pad_mode, upsample)
+        return gemm(cols, lin.w, lin.b, epi, resid=resid), Ho, Wo
+
+    def _resnet(self, x, B, H, W, p, groups, eps):
+        g1, b1 = self.P[f"{p}.norm1"]
+        h = groupnorm(x, g1, b1, B, groups, eps, True)
+        h, _, _ = self._conv(h, B, H, W, f"{p}.conv1")
+        g2, b2 = self.P[f"{p}.norm2"]
+        h = groupnorm(h, g2, b2, B, groups, eps, True)
+        sc = x
+        if f"{p}.conv_shortcut" in self.P:
+            s = self.P[f"{p}.conv_shortcut"]
+            sc = gemm(x, s.w, s.b)
+        out, _, _ = self._conv(h, B, H, W, f"{p}.conv2", epi=_lib.EPI_RESID, resid=sc)
+        return out
+
+    def _transformer(self, x, B, HW, p, groups):
+        P = self.P
+        heads, dh, dp = P[f"{p}.meta"]
+        hd = heads * dp
+        gn, bn = P[f"{p}.norm"]
+        h = groupnorm(x, gn, bn, B, groups, 1e-6, False)
+        pi = P[f"{p}.proj_in"]
+        h = gemm(h, pi.w, pi.b)
+        b = f"{p}.transformer_blocks.0"
+        scale = dh ** -0.5
+        n1 = layernorm(h, *P[f"{b}.norm1"], 1e-5)
+        qk = gemm(n1, P[f"{b}.attn1.qk"].w)
+        vt = linear_vt(n1, P[f"{b}.attn1.v"].w, None)
+        a = attention(qk[:, :hd], qk[:, hd:], vt, hd, B, HW, HW, heads, dp, scale, False)
+        o = P[f"{b}.attn1.o"]
+        gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
+        n2 = layernorm(h, *P[f"{b}.norm2"], 1e-5)
+        q = gemm(n2, P[f"{b}.attn2.q"].w)
+        ck, cvt = self._ctx[b]
+        a = attention(q, ck, cvt, hd, B, HW, self._ctx_len, heads, dp, scale, True)
+        o = P[f"{b}.attn2.o"]
+        gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
+        n3 = layernorm(h, *P[f"{b}.norm3"], 1e-5)
+        f1, f2 = P[f"{b}.ff1"], P[f"{b}.ff2"]
+        g = geglu(gemm(n3, f1.w, f1.b))
+        gemm(g, f2.w, f2.b, _lib.EPI_RESID, resid=h, out=h)
+        po = P[f"{p}.proj_out"]
+        return gemm(h, po.w, po.b, _lib.EPI_RESID, resid=x)
+
+    # ---------------------------------------------------------------- VAE encoder -> posterior moments (fp32)
+    def vae_moments(self, img: torch.Tensor) -> torch.Tensor:
+        """img [B,3,H,W] in [-1,1] -> fp32 [B*h*w, >= 2Z]: posterior mean | logvar per latent pixel (AutoencoderKL.encode)."""
+        v = self.spec.vae
+        B, _, H, W = img.shape
+        g = v.groups
+        x = nchw_to_tokens(img.to(self.device).contiguous(), 8)
+        h, _, _ = self._conv(x, B, H, W, "vae.conv_in")
+        for i in range(len(v.block_out)):
+            for j in range(v.layers_per_block):
+                h = self._resnet(h, B, H, W, f"encoder.down_blocks.{i}.resnets.{j}", g, 1e-6)
+            if i != len(v.block_out) - 1:
+                h, H, W = self._conv(h, B, H, W, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_mode=1)
+        h = self._resnet(h, B, H, W, "encoder.mid_block.resnets.0", g, 1e-6)
+        h = self._vae_attention(h, B, H * W)
+        h = self._resnet(h, B, H, W, "encoder.mid_block.resnets.1", g, 1e-6)
+        gn, bn = self.P["encoder.conv_norm_out"]
+        h = groupnorm(h, gn, bn, B, g, 1e-6, True)
+        lin = self.P["vae.moments"]
+        cols, _, _ = im2col3x3(h, B, H, W, lin.w.shape[1])
+        return gemm(cols, lin.w, lin.b, _lib.EPI_F32), H, W
+
+    def _vae_attention(self, x, B, T):
+        """Single-head attention over all T latent pixels, head width = C (512 for SD): materialised scores per image
+        (fp32 [T, T]) through the GEMM kernel - a 512-wide head does not fit the flash kernel's register budget."""
+        a = "encoder.mid_block.attentions.0"
+        P = self.P
+        C = x.shape[1]
+        n = groupnorm(x, *P[f"{a}.group_norm"], B, self.spec.vae.groups, 1e-6, False)
+        q = gemm(n, P[f"{a}.to_q"].w, P[f"{a}.to_q"].b)
+        k = gemm(n, P[f"{a}.to_k"].w, P[f"{a}.to_k"].b)
+        Tp = _ru(T, 64)
+        o = torch.empty(B * T, C, dtype=torch.bfloat16, device=x.device)
+        wv, bv = P[f"{a}.to_v"].w, P[f"{a}.to_v.bias"]
+        for b in range(B):
+            sl = slice(b * T, (b + 1) * T)
+            kb, nb = k[sl], n[sl]
+            if Tp != T:                                                        # GEMM N granule: zero rows, masked by softmax_rows
+                kb = torch.zeros(Tp, C, dtype=torch.bfloat16, device=x.device)
+                kb[:T] = k[sl]
+                nb = torch.zeros(Tp, C, dtype=torch.bfloat16, device=x.device)
+                nb[:T] = n[sl]
+            s = gemm(q[sl], kb, None, _lib.EPI_F32)                            # [T, Tp] fp32
+            p = softmax_rows(s, T, Tp, C ** -0.5)
+            vt = gemm(wv[:C], nb, None)                                        # V^T = Wv X^T : [C, Tp]
+            gemm(p, vt, bv, out=o[sl])
+        lo = P[f"{a}.to_out.0"]
+        return gemm(o, lo.w, lo.b, _lib.EPI_RESID, resid=x)
+
+    # ---------------------------------------------------------------- UNet up to the captured up block
+    def unet_features(self, lat: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+        """lat [B*H*W, 8] bf16 noisy latents (channels-last, zero padded) -> up_ft[up_ft_index] as [B, h*w, c] bf16."""
+        if self._t is None or self._ctx is None:
+            raise RuntimeError("set_timestep() and set_prompt() must be called before the UNet runs")
+        u = self.spec.unet
+        g, eps = u.groups, u.eps
+        h, _, _ = self._conv(lat, B, H, W, "conv_in")
+        skips = [(h, H, W)]
+        nb = len(u.block_out)
+        for i in range(nb):
+            for j in range(u.layers_per_block):
+                h = self._resnet(h, B, H, W, f"down_blocks.{i}.resnets.{j}", g, eps)
+                if u.down_types[i].startswith("CrossAttn"):
+                    h = self._transformer(h, B, H * W, f"down_blocks.{i}.attentions.{j}", g)
+                skips.append((h, H, W))
+            if i != nb - 1:
+                h, H, W = self._conv(h, B, H, W, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+                skips.append((h, H, W))
+        h = self._resnet(h, B, H, W, "mid_block.resnets.0", g, eps)
+        h = self._transformer(h, B, H * W, "mid_block.attentions.0", g)
+        h = self._resnet(h, B, H, W, "mid_block.resnets.1", g, eps)
+        for i in range(self.up_ft_index + 1):
+            cins, out, attn, ups = up_block_plan(u, i)
+            for j in range(len(cins)):
+                s, sh, sw = skips.pop()
+                assert (sh, sw) == (H, W)
+                h = torch.cat([h, s], dim=1)                                   # channel concat of two token matrices
+                h = self._resnet(h, B, H, W, f"up_blocks.{i}.resnets.{j}", g, eps)
+                if attn:
+                    h = self._transformer(h, B, H * W, f"up_blocks.{i}.attentions.{j}", g)
+            if ups:
+                h, H, W = self._conv(h, B, H, W, f"up_blocks.{i}.upsamplers.0.conv", upsample=True)
+        return h.view(B, H * W, h.shape[1])
+
+    # ---------------------------------------------------------------- SDFeaturizer.forward + DiffVisionTower.forward
+    @torch.no_grad()
+    def forward(self, img: torch.Tensor, prompt_embeds: Optional[torch.Tensor] = None, t: int = 1, ensemble_size: int = 1,
+                post_noise: Optional[torch.Tensor] = None, ddim_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """img [B,3,H,W] in [-1,1] -> [B, h*w, c] bf16 features of up block `up_ft_index`.
+
+        post_noise / ddim_noise [B*ensemble, Z, H/f, W/f] fp32: the reference's two randn draws (dift_sd.py:172,175);
+        drawn with torch.randn on the device when omitted."""
+        lib = _lib.require_gpu()
+        sp = self.spec
+        if prompt_embeds is not None:
+            self.set_prompt(prompt_embeds)
+        self.set_timestep(t)
+        B = img.shape[0]
+        x = img.to(self.device)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.repeat_interleave(ensemble_size, dim=0) if ensemble_size > 1 else x      # dift_sd.py:251
+        Be = B * ensemble_size
+        moments, h, w = self.vae_moments(x)
+        Z = sp.vae.latent_channels
+        shape = (Be, Z, h, w)
+        post = torch.randn(shape, device=self.device) if post_noise is None else post_noise.to(self.device, torch.float32).contiguous()
+        ddim = torch.randn(shape, device=self.device) if ddim_noise is None else ddim_noise.to(self.device, torch.float32).contiguous()
+        if tuple(post.shape) != shape or tuple(ddim.shape) != shape:
+            raise ValueError(f"noise tensors must have shape {shape}")
+        lat = torch.empty(Be * h * w, 8, dtype=torch.bfloat16, device=self.device)
+        rc = lib.visrep_sd_noisy_latents(_lib.ptr(moments), moments.stride(0), _lib.ptr(post), _lib.ptr(ddim), _lib.ptr(lat), Be, Z,
+                                         h * w, 8, float(sp.vae.scaling_factor), float(self._ac[int(t)]), _lib.stream_ptr())
+        _lib.check(rc, "visrep_sd_noisy_latents")
+        ft = self.unet_features(lat, Be, h, w)
+        if ensemble_size > 1:
+            ft = mean_groups(ft, B, ensemble_size).view(B, ft.shape[1], ft.shape[2])
+        return ft

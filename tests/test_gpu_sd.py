@@ -1,0 +1,190 @@
+"""GPU parity of the Stable-Diffusion feature tower: primitives against plain torch fp32, the composed
+tower against the reference-generated golden (tests/golden/sd_tiny.npz) with the bf16 CPU oracle as the error yardstick."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(__file__))
+from test_oracle_golden import SD_TAGS, load_sd_case  # noqa: E402
+
+from law_of_vision_representation_in_mllms_amd import _lib, engine, sd_engine as SE  # noqa: E402
+from law_of_vision_representation_in_mllms_amd import sd_weights as SW  # noqa: E402
+from oracle import diffusion as OD  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return ((got - want).norm() / want.norm().clamp_min(1e-12)).item()
+
+
+def tokens(x):                      # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def untokens(y, B, H, W):           # [B*H*W, C] -> [B,C,H,W]
+    return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("B,HW,C,groups,silu", [(2, 64, 64, 32, True), (3, 100, 320, 32, False), (1, 2304, 640, 32, True),
+                                                (2, 37, 192, 32, True), (1, 9216, 128, 32, True)])
+def test_groupnorm(B, HW, C, groups, silu):
+    g = torch.Generator().manual_seed(HW + C)
+    x = bf(torch.randn(B, HW, C, generator=g) * 2 + 0.7)
+    gam, bet = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    want = F.group_norm(x.float().permute(0, 2, 1), groups, gam, bet, 1e-5)
+    want = (F.silu(want) if silu else want).permute(0, 2, 1)
+    got = SE.groupnorm(x.view(B * HW, C).to(DEV), gam.to(DEV), bet.to(DEV), B, groups, 1e-5, silu).view(B, HW, C)
+    assert (got.float().cpu() - want).abs().max().item() < 4e-2
+    assert rel_err(got, want) < 5e-3
+
+
+@pytest.mark.parametrize("stride,pad_mode,up", [(1, 0, False), (2, 0, False), (2, 1, False), (1, 0, True)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 8, 64, 128), (1, 13, 10, 8, 64), (1, 24, 24, 320, 320)])
+def test_conv3x3_as_gather_plus_gemm(B, H, W, Ci, Co, stride, pad_mode, up):
+    g = torch.Generator().manual_seed(H * 100 + Ci + stride)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = torch.randn(Co, generator=g) * 0.1
+    xin = x.float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if pad_mode == 1:
+        want = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), b, stride=stride, padding=0)
+    else:
+        want = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    wp = w.float().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)
+    kp = (9 * Ci + 63) // 64 * 64
+    wpk = torch.zeros(Co, kp)
+    wpk[:, : 9 * Ci] = wp
+    cols, Ho, Wo = SE.im2col3x3(tokens(x).to(DEV), B, H, W, kp, stride, pad_mode, up)
+    assert (Ho, Wo) == tuple(want.shape[2:])
+    got = engine.gemm(cols, bf(wpk).to(DEV), b.to(DEV), _lib.EPI_F32)
+    got = untokens(got, B, Ho, Wo)
+    assert (got.cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+
+
+def test_geglu_and_mean_groups_and_softmax_rows():
+    g = torch.Generator().manual_seed(1)
+    x = bf(torch.randn(70, 512, generator=g) * 2)
+    want = x[:, :256].float() * F.gelu(x[:, 256:].float())
+    assert rel_err(SE.geglu(x.to(DEV)), want) < 4e-3
+    y = bf(torch.randn(3, 4, 50, 64, generator=g))
+    got = SE.mean_groups(y.to(DEV), 3, 4).view(3, 50, 64)
+    assert rel_err(got, y.float().mean(1)) < 4e-3
+    s = torch.randn(33, 100, generator=g) * 20
+    p = SE.softmax_rows(s.to(DEV), 100, 128, 0.25)
+    assert p.shape == (33, 128) and (p[:, 100:] == 0).all()
+    assert (p[:, :100].float().cpu() - torch.softmax(s * 0.25, -1)).abs().max().item() < 4e-3
+
+
+def test_nchw_to_tokens_and_noisy_latents():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 5, 7, generator=g)
+    for src in (x, bf(x)):
+        t = SE.nchw_to_tokens(src.to(DEV), 8).cpu().float()
+        assert torch.equal(t[:, :3], tokens(bf(src).float())) and (t[:, 3:] == 0).all()
+    sp = SW.tiny_sd_spec()
+    B, Z, h, w = 2, 4, 6, 5
+    mean, logvar = torch.randn(B, Z, h, w, generator=g), torch.randn(B, Z, h, w, generator=g) * 3 - 1
+    post, ddim = torch.randn(B, Z, h, w, generator=g), torch.randn(B, Z, h, w, generator=g)
+    mom = torch.zeros(B * h * w, 64)
+    mom[:, :Z], mom[:, Z: 2 * Z] = tokens(mean), tokens(logvar)
+    lat = torch.empty(B * h * w, 8, dtype=torch.bfloat16, device=DEV)
+    ac = float(sp.sched.alphas_cumprod()[261])
+    mom_d, post_d, ddim_d = mom.to(DEV), post.to(DEV), ddim.to(DEV)        # keep the device copies alive across the raw-pointer call
+    rc = _lib.load().visrep_sd_noisy_latents(_lib.ptr(mom_d), 64, _lib.ptr(post_d), _lib.ptr(ddim_d), _lib.ptr(lat), B, Z,
+                                              h * w, 8, sp.vae.scaling_factor, ac, _lib.stream_ptr())
+    assert rc == 0
+    want = OD.noisy_latents(sp, mean, logvar.clamp(-30, 20), post, ddim, 261)
+    got = lat.cpu().float()
+    assert (got[:, Z:] == 0).all()
+    tw = tokens(want)
+    assert ((got[:, :Z] - tw).abs() / tw.abs().clamp_min(1.0)).max().item() < 1e-2
+
+
+def ref_attn(q, k, v, B, Tq, Tk, H, dh, shared):
+    q = q.float().view(B, Tq, H, dh).transpose(1, 2)
+    k = (k.float().view(1, Tk, H, dh).expand(B, -1, -1, -1) if shared else k.float().view(B, Tk, H, dh)).transpose(1, 2)
+    v = (v.float().view(1, Tk, H, dh).expand(B, -1, -1, -1) if shared else v.float().view(B, Tk, H, dh)).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * Tq, H * dh)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,dh,shared", [(2, 144, 144, 2, 40, False), (1, 576, 576, 3, 80, False), (2, 300, 300, 2, 160, False),
+                                                 (3, 256, 77, 2, 40, True), (2, 100, 11, 4, 160, True), (2, 64, 64, 2, 64, False),
+                                                 (1, 2304, 2304, 2, 80, False)])
+def test_attention_padded_heads_and_cross(B, Tq, Tk, H, dh, shared):
+    """Head widths of SD1.5 (40 / 80 / 160) zero-padded to 64 / 128 / 192 by the weight packer; prompt K/V shared."""
+    g = torch.Generator().manual_seed(Tq + dh)
+    d = H * dh
+    dp = (dh + 63) // 64 * 64
+    din = 128                                                               # GEMM K granule; head widths come from the weights
+    xq = bf(torch.randn(B * Tq, din, generator=g)).to(DEV)
+    xk = xq if not shared and Tk == Tq else bf(torch.randn((1 if shared else B) * Tk, din, generator=g)).to(DEV)
+    wq, wk, wv = [bf(torch.randn(d, din, generator=g) * (1.3 / math.sqrt(din))) for _ in range(3)]
+    pad = SE.SdEngine._pad_heads_out
+    q = engine.gemm(xq, bf(pad(wq.float(), H, dp)).to(DEV))
+    k = engine.gemm(xk, bf(pad(wk.float(), H, dp)).to(DEV))
+    vt = engine.linear_vt(xk, bf(pad(wv.float(), H, dp)).to(DEV), None)
+    out = SE.attention(q, k, vt, H * dp, B, Tq, Tk, H, dp, dh ** -0.5, shared)
+    out = out.view(B * Tq, H, dp)[:, :, :dh].reshape(B * Tq, d)
+    assert (SE.attention(q, k, vt, H * dp, B, Tq, Tk, H, dp, dh ** -0.5, shared).view(B * Tq, H, dp)[:, :, dh:] == 0).all()
+    qr, kr, vr = bf(xq.float().cpu() @ wq.float().t()), bf(xk.float().cpu() @ wk.float().t()), bf(xk.float().cpu() @ wv.float().t())
+    want = ref_attn(qr, kr, vr, B, Tq, Tk, H, dh, shared)
+    assert rel_err(out, want) < 1e-2
+
+
+def test_attention_rejects_unsupported_head_width():
+    z = torch.zeros(64, 256, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        SE.attention(z, z, torch.zeros(256, 128, dtype=torch.bfloat16, device=DEV), 256, 1, 64, 64, 1, 256, 1.0, False)
+
+
+# ------------------------------------------------------------------------------------------------ composed tower
+@pytest.mark.parametrize("tag", SD_TAGS)
+def test_sd_tower_matches_reference_golden(tag):
+    sp, wu, wv, inp, want = load_sd_case(tag)
+    eng = SE.SdEngine(sp, wu, wv, DEV, up_ft_index=inp["up_ft_index"])
+    # stage 1: VAE posterior moments against the reference's latent_dist
+    E = inp["ensemble_size"]
+    img = inp["img"].repeat_interleave(E, dim=0)
+    mom, h, w = eng.vae_moments(img.to(DEV))
+    Z = sp.vae.latent_channels
+    B = img.shape[0]
+    mean = untokens(mom[:, :Z], B, h, w).cpu()
+    logvar = untokens(mom[:, Z: 2 * Z], B, h, w).cpu()
+    mref, lref = OD.vae_encode_moments(sp.vae, {k: bf(v) for k, v in wv.items()}, bf(img))       # bf16 reference run
+    assert rel_err(mean, inp["mean"]) < max(2.0 * rel_err(mref, inp["mean"]), 2e-2)
+    assert rel_err(logvar, inp["logvar"]) < max(2.0 * rel_err(lref, inp["logvar"]), 2e-2)
+    # stage 2: the whole SDFeaturizer.forward + DiffVisionTower.forward
+    got = eng.forward(inp["img"], inp["prompt_embeds"], t=inp["t"], ensemble_size=E, post_noise=inp["post_noise"], ddim_noise=inp["ddim_noise"])
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    ref_bf16 = OD.sd_features(sp, wu, wv, inp["img"], inp["prompt_embeds"], inp["post_noise"], inp["ddim_noise"], t=inp["t"],
+                              up_ft_index=inp["up_ft_index"], ensemble_size=E, dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert e_hip < max(2.0 * e_ref, 2e-2), (tag, e_hip, e_ref)
+
+
+def test_sd_tower_random_noise_path_and_state_errors():
+    sp, wu, wv, inp, _ = load_sd_case("conv_up0")
+    eng = SE.SdEngine(sp, wu, wv, DEV)
+    with pytest.raises(RuntimeError, match="set_prompt"):
+        eng.forward(inp["img"])
+    a = eng.forward(inp["img"], inp["prompt_embeds"], t=100)
+    assert torch.isfinite(a.float()).all() and a.shape == (2, 64, 128)
+    with pytest.raises(ValueError, match="noise tensors"):
+        eng.forward(inp["img"], t=100, post_noise=torch.zeros(1, 4, 3, 3))
