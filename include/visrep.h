@@ -78,9 +78,11 @@ int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* ou
  * q: [B*Tq, ldq] bf16, head h in columns [h*head_dim, (h+1)*head_dim); k: [B*Tk, ldk] likewise ([Tk, ldk] when
  * kv_shared = 1: one key/value sequence - the prompt - serves every batch item); vt: [H*head_dim, ldvt] as written by
  * VISREP_EPI_VT over the key rows, ldvt >= round_up(key rows, 64); out: [B*Tq, ldo].  head_dim in {64, 128, 192}: the
- * weight packer zero-pads narrower heads (SD1.5: 40 / 80 / 160), which changes nothing in softmax(QK^T)V. */
+ * weight packer zero-pads narrower heads (SD1.5: 40 / 80 / 160), which changes nothing in softmax(QK^T)V.
+ * causal = 1 masks keys after the query position (HF CLIPTextTransformer's causal mask: the prompt encoder behind
+ * pipe.encode_prompt, dift_sd.py:258-263). */
 int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo, int B, int Tq,
-                         int Tk, int H, int head_dim, int kv_shared, float scale, void* stream);
+                         int Tk, int H, int head_dim, int kv_shared, int causal, float scale, void* stream);
 
 /* ---- patch embedding pieces (HF CLIPVisionEmbeddings / Dinov2Embeddings / SiglipVisionEmbeddings) */
 int visrep_im2col(const void* pixels, int pixel_dtype, void* cols, int B, int Himg, int Wimg, int patch, int Kpad, void* stream);

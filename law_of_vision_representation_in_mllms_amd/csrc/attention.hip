@@ -2,7 +2,7 @@
 // UNet self- / cross-attention of the diffusion towers (head width D = 64*ND, narrower heads zero-padded by the weight
 // packer; key/value sequence of its own length Tk, optionally SHARED by all batch items - the prompt).
 //
-//   O[b, q, h, :] = softmax_k( Q[b,q,h,:] . K[b,k,h,:] * scale ) V[b,k,h,:]
+//   O[b, q, h, :] = softmax_k( Q[b,q,h,:] . K[b,k,h,:] * scale ) V[b,k,h,:]      (causal: keys k <= q only - CLIP text encoder)
 //
 // Layouts (produced by the GEMM epilogues, gemm_bf16.hip):
 //   q   : [B*Tq, ldq] bf16 row-major, head h at columns h*D;  k : [B*Tk (or Tk), ldk] likewise
@@ -34,7 +34,7 @@ constexpr int TILE_B = KT * 64 * 2;       // 8 KB: one [64 keys x 64 d] K sub-ti
 
 struct AttnArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
-    int B, Tq, Tk, H, Mk, ldq, ldk, ldvt, ldo, kv_shared;
+    int B, Tq, Tk, H, Mk, ldq, ldk, ldvt, ldo, kv_shared, causal;
     float sc;                              // softmax scale * log2(e)
 };
 
@@ -114,13 +114,13 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
         // ---- mask (first / last tile of the image only), running max on the RAW scores; the softmax scale is folded
         //      into the exponent: p = exp2(s*sc - m*sc) is one FMA + one v_exp per element
         const int mt = m_begin + it * KT;
-        if ((mt < tok0) || (mt + KT > tok1)) {               // wave-uniform
+        if ((mt < tok0) || (mt + KT > tok1) || p.causal) {   // wave-uniform
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = mt + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key < tok0 || key >= tok1) s[kt2][r] = -INFINITY;
+                    if (key < tok0 || key >= tok1 || (p.causal && key - tok0 > qloc)) s[kt2][r] = -INFINITY;
                 }
         }
         float mloc = fmaxf(s[0][0], s[1][0]);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 }  // namespace
 
 extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
-                                    int B, int Tq, int Tk, int H, int head_dim, int kv_shared, float scale, void* stream) {
+                                    int B, int Tq, int Tk, int H, int head_dim, int kv_shared, int causal, float scale, void* stream) {
     if (head_dim != 64 && head_dim != 128 && head_dim != 192)
         return visrep_set_error(VISREP_ERR_SHAPE, "attention: head_dim must be 64, 128 or 192 (pad narrower heads with zero weights)");
     if (B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "attention: empty problem");
@@ -196,7 +196,7 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     if (ldvt < ((Mk + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "attention: ldvt must cover round_up(key rows, 64)");
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
-    a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.Mk = (int)Mk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.kv_shared = kv_shared;
+    a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.Mk = (int)Mk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.kv_shared = kv_shared; a.causal = causal;
     a.sc = scale * 1.4426950408889634f;
     const int nqt = (Tq + 127) / 128, nd = head_dim / 64;
     const dim3 grid(nqt * H * B), block(256);
@@ -215,5 +215,5 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
 extern "C" int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo,
                                int B, int T, int H, int head_dim, float scale, void* stream) {
     if (head_dim != 64) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa: only head_dim 64 is implemented");
-    return visrep_attention_fwd(qk, ldqk, (const bf16_t*)qk + (size_t)H * 64, ldqk, vt, ldvt, out, ldo, B, T, T, H, 64, 0, scale, stream);
+    return visrep_attention_fwd(qk, ldqk, (const bf16_t*)qk + (size_t)H * 64, ldqk, vt, ldvt, out, ldo, B, T, T, H, 64, 0, 0, scale, stream);
 }

@@ -2,6 +2,7 @@
 import os
 
 from .clip_encoder import CLIPVisionTower
+from .diffLVLM.diffusion_encoder import DiffVisionTower
 from .dinov2_encoder import DinoV2VisionTower
 from .siglip_encoder import SigLipVisionTower
 
@@ -15,9 +16,8 @@ def build_vision_tower(vision_tower_cfg, **kwargs):
 
 
 def build_diffusion_vision_tower(vision_tower_cfg, **kwargs):
-    # SD-UNet / DiT / SD3 featurizers (diffLVLM/diffusion_encoder.py:44) are a later row of SURVEY.md §8 (a5):
-    # not built yet -> fail loudly instead of silently falling back to anything.
-    raise NotImplementedError("diffusion vision towers are not implemented on the MI355X path yet (SURVEY.md §8 a5)")
+    # SD1.5 / SD2.1 UNet featurizer runs on the HIP path; IMSD / SDXL / DiT / SD3 raise NotImplementedError on load
+    return DiffVisionTower(args=vision_tower_cfg)
 
 
 def build_dinov2_vision_tower(vision_tower_cfg, **kwargs):

@@ -66,11 +66,12 @@ def geglu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def attention(q, k, vt, out_cols: int, B: int, Tq: int, Tk: int, H: int, head_dim: int, scale: float, kv_shared: bool) -> torch.Tensor:
+def attention(q, k, vt, out_cols: int, B: int, Tq: int, Tk: int, H: int, head_dim: int, scale: float, kv_shared: bool,
+              causal: bool = False) -> torch.Tensor:
     lib = _lib.require_gpu()
     out = torch.empty(B * Tq, out_cols, dtype=torch.bfloat16, device=q.device)
     rc = lib.visrep_attention_fwd(_lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(vt), vt.stride(0), _lib.ptr(out),
-                                  out.stride(0), B, Tq, Tk, H, head_dim, int(kv_shared), float(scale), _lib.stream_ptr())
+                                  out.stride(0), B, Tq, Tk, H, head_dim, int(kv_shared), int(causal), float(scale), _lib.stream_ptr())
     _lib.check(rc, "visrep_attention_fwd")
     return out
 

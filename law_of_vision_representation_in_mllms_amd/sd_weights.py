@@ -206,3 +206,41 @@ def synthetic_vae(v: VaeSpec, seed: int):
     z = v.latent_channels
     w["quant_conv.bias"][z:] -= 2.0
     return w
+
+
+# ----------------------------------------------------------------------------------------------- CLIP text encoder
+@dataclass(frozen=True)
+class TextSpec:
+    """HF CLIPTextConfig subset (SD1.5 text_encoder/config.json = openai/clip-vit-large-patch14 text tower)."""
+    vocab: int = 49408
+    d: int = 768
+    mlp: int = 3072
+    layers: int = 12
+    heads: int = 12
+    max_pos: int = 77
+    act: str = "quick_gelu"
+    eps: float = 1e-5
+
+
+def text_param_table(s: TextSpec) -> List[Tuple[str, tuple]]:
+    t = [("embeddings.token_embedding.weight", (s.vocab, s.d)), ("embeddings.position_embedding.weight", (s.max_pos, s.d))]
+    for i in range(s.layers):
+        p = f"encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            t += [(f"{p}.self_attn.{n}.weight", (s.d, s.d)), (f"{p}.self_attn.{n}.bias", (s.d,))]
+        t += [(f"{p}.layer_norm1.weight", (s.d,)), (f"{p}.layer_norm1.bias", (s.d,)),
+              (f"{p}.mlp.fc1.weight", (s.mlp, s.d)), (f"{p}.mlp.fc1.bias", (s.mlp,)),
+              (f"{p}.mlp.fc2.weight", (s.d, s.mlp)), (f"{p}.mlp.fc2.bias", (s.d,)),
+              (f"{p}.layer_norm2.weight", (s.d,)), (f"{p}.layer_norm2.bias", (s.d,))]
+    return t + [("final_layer_norm.weight", (s.d,)), ("final_layer_norm.bias", (s.d,))]
+
+
+def synthetic_text(s: TextSpec, seed: int):
+    w = _synthetic(text_param_table(s), seed)
+    w["embeddings.token_embedding.weight"] *= s.d ** 0.5 * 0.5          # O(1) embeddings like a trained table after LN
+    w["embeddings.position_embedding.weight"] *= s.d ** 0.5 * 0.2
+    return w
+
+
+def tiny_text_spec(act="quick_gelu", layers=2, max_pos=16) -> TextSpec:
+    return TextSpec(vocab=99, d=128, mlp=256, layers=layers, heads=2, max_pos=max_pos, act=act)

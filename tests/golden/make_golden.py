@@ -564,6 +564,34 @@ def gen_sd():
     np.savez_compressed(f"{HERE}/sd_tiny.npz", **out)
 
 
+# ----------------------------------------------------------------------------- CLIP text encoder (prompt embeddings)
+def gen_text():
+    """HF CLIPTextModel (what pipe.encode_prompt runs, dift_sd.py:258-263), tiny random-init configs."""
+    import transformers
+    from transformers import CLIPTextConfig, CLIPTextModel
+    out = {"transformers_version": np.array(transformers.__version__)}
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    for tag, (act, layers, L, seed) in {"quick": ("quick_gelu", 2, 16, 0), "gelu": ("gelu", 3, 77, 1)}.items():
+        ts = SW.tiny_text_spec(act, layers, L)
+        cfg = CLIPTextConfig(vocab_size=ts.vocab, hidden_size=ts.d, intermediate_size=ts.mlp, num_hidden_layers=ts.layers,
+                             num_attention_heads=ts.heads, max_position_embeddings=ts.max_pos, hidden_act=ts.act, eos_token_id=98,
+                             bos_token_id=97, pad_token_id=98)
+        m = CLIPTextModel(cfg).eval()
+        w = SW.synthetic_text(ts, seed + 40)
+        pre = "text_model." if any(k.startswith("text_model.") for k in m.state_dict()) else ""     # differs across HF versions
+        r = m.load_state_dict({pre + k: v for k, v in w.items()}, strict=False)
+        assert not r.unexpected_keys and all("position_ids" in k for k in r.missing_keys), r
+        rs = np.random.RandomState(seed)
+        ids = torch.from_numpy(rs.randint(0, 97, (2, L)))
+        ids[:, 0] = 97
+        ids[0, 5:] = 98                                         # padded prompt
+        y = m(input_ids=ids).last_hidden_state
+        out[f"{tag}.ids"] = ids.numpy()
+        out[f"{tag}.y"] = y.numpy()
+        print(tag, tuple(y.shape), float(y.std()))
+    np.savez_compressed(f"{HERE}/text_tiny.npz", **out)
+
+
 # ----------------------------------------------------------------------------- projector
 def gen_projector():
     ph = types.ModuleType("ref_proj.perceiver_helpers")
@@ -595,7 +623,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text}[w]()

@@ -188,3 +188,49 @@ def test_sd_tower_random_noise_path_and_state_errors():
     assert torch.isfinite(a.float()).all() and a.shape == (2, 64, 128)
     with pytest.raises(ValueError, match="noise tensors"):
         eng.forward(inp["img"], t=100, post_noise=torch.zeros(1, 4, 3, 3))
+
+
+# ------------------------------------------------------------------------------------------------ prompt encoder
+@pytest.mark.parametrize("tag", ["quick", "gelu"])
+def test_clip_text_engine_matches_hf_golden(tag):
+    from test_oracle_golden import load_text_case
+    from law_of_vision_representation_in_mllms_amd.text_engine import ClipTextEngine
+    from oracle import text as OT
+    ts, w, ids, want = load_text_case(tag)
+    got = ClipTextEngine(ts, w, DEV).forward(ids)
+    ref_bf16 = OT.clip_text_hidden({k: bf(v) if v.is_floating_point() else v for k, v in w.items()}, ids, ts.heads, ts.act).float()
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert got.shape == want.shape and e_hip < max(2.0 * e_ref, 1e-2), (e_hip, e_ref)
+
+
+# ------------------------------------------------------------------------------------------------ full-width SD1.5
+def test_sd15_full_width_parity_and_tower_api(monkeypatch):
+    """The real SD1.5 architecture (320/640/1280/1280, heads of 40/80/160, VAE 128..512 with the 512-wide single-head
+    attention) on a small image against the fp32 CPU oracle; then the DiffVisionTower drop-in around the same engine."""
+    from types import SimpleNamespace
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import builder as B
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    args = SimpleNamespace(vision_tower='runwayml/stable-diffusion-v1-5', up_ft_index=0, t=261, prompt="a photo of a cat",
+                           ensemble_size=1, img_size=128)
+    tower = B.build_diffusion_vision_tower(args)
+    assert tower.is_loaded and tower.hidden_size == 1280 and tower.dtype == torch.bfloat16
+    feat = tower.vision_tower
+    sp = feat.spec
+    rs = np.random.RandomState(5)
+    img = torch.from_numpy(rs.uniform(-1, 1, (1, 3, 128, 128)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((1, 4, 16, 16)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((1, 4, 16, 16)).astype(np.float32))
+    pe = feat.encode_prompt(args.prompt)
+    assert pe.shape == (1, 77, 768)
+    got = feat.forward(img, args.prompt, t=261, up_ft_index=0, ensemble_size=1, post_noise=post, ddim_noise=ddim)     # [c, h, w]
+    assert got.shape == (1280, 4, 4)
+    wu = {k: v for k, v in feat._wu.items() if not k.startswith(("up_blocks.1", "up_blocks.2", "up_blocks.3"))}
+    want = OD.sd_features(sp, wu, feat._wv, img, pe.float().cpu(), post, ddim, t=261)                                 # [1, 16, 1280]
+    ref_bf16 = OD.sd_features(sp, wu, feat._wv, img, pe.float().cpu(), post, ddim, t=261, dtype=torch.bfloat16)
+    got_tok = got.permute(1, 2, 0).reshape(1, 16, 1280)
+    e_hip, e_ref = rel_err(got_tok, want), rel_err(ref_bf16, want)
+    assert e_hip < max(2.0 * e_ref, 3e-2), (e_hip, e_ref)
+    # tower.forward: tensor batch and a single [3,H,W] image, random noise drawn on the device
+    out = tower(torch.cat([img, img.flip(-1)], 0))
+    assert out.shape == (2, 16, 1280) and torch.isfinite(out.float()).all()
+    assert tower(img[0]).shape == (1, 16, 1280)
