@@ -135,8 +135,9 @@ int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, cons
 
 /* torch.nn.GroupNorm (+ optional SiLU) as used by diffusers resnet.py:ResnetBlock2D.forward (norm1/norm2 + nonlinearity),
  * transformer_2d.py:141 and vae.py conv_norm_out.  x, y: [B*HW, C] bf16 (y may alias x); gamma/beta fp32 [C]; fp32
- * statistics over (HW, C/groups) per (image, group).  workspace: visrep_groupnorm_workspace_bytes(B, groups). */
-size_t visrep_groupnorm_workspace_bytes(int B, int groups);
+ * statistics over (HW, C/groups) per (image, group), summed in a fixed order (bit-reproducible run to run).
+ * workspace: visrep_groupnorm_workspace_bytes(B, HW, groups). */
+size_t visrep_groupnorm_workspace_bytes(int B, int HW, int groups);
 int visrep_groupnorm(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups, float eps,
                      int silu, void* workspace, void* stream);
 

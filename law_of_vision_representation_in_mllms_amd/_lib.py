@@ -43,7 +43,7 @@ SIGNATURES = {
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "visrep_attention_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
-    "visrep_groupnorm_workspace_bytes": (_sz, [_i, _i]),
+    "visrep_groupnorm_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "visrep_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_geglu": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),

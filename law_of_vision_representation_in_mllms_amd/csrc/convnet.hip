@@ -20,13 +20,16 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
-// stats[(b*G + g)*2 + {0,1}] += sum, sum of squares.  Block = 256 threads laid out [R row lanes][W channel-pair lanes].
-__global__ __launch_bounds__(256) void groupnorm_stats(const bf16_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int cpg,
+// Deterministic two-level reduction (no atomics: the towers are deep enough that one flipped bf16 rounding in a statistic
+// moves the final features by 1e-2, so run-to-run reproducibility needs a fixed summation order):
+//   groupnorm_stats     block (row chunk, image): threads [R row lanes][W channel-pair lanes] -> per-thread partial sums in
+//                       LDS -> thread g adds its group's entries in a fixed order -> partial[(b*nblk + blk)*G + g] = (s, ss)
+//   groupnorm_finalize  thread (b, g): adds the nblk partials in order -> stats[b*G + g] = (mean, rstd)
+//   groupnorm_apply     one 16-byte vector per thread
+__global__ __launch_bounds__(256) void groupnorm_stats(const bf16_t* __restrict__ x, float2* __restrict__ partial, int HW, int C, int cpg,
                                                        int rows_per_block, int W) {
-    __shared__ float acc[2 * 128];
+    extern __shared__ float2 buf[];                            // [R][npair]
     const int tid = threadIdx.x, b = blockIdx.y, G = C / cpg;
-    for (int i = tid; i < 2 * G; i += 256) acc[i] = 0.f;
-    __syncthreads();
     const int tc = tid % W, tr = tid / W, R = 256 / W;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
     const uint32_t* base = reinterpret_cast<const uint32_t*>(x + (size_t)b * HW * C);
@@ -48,24 +51,47 @@ __global__ __launch_bounds__(256) void groupnorm_stats(const bf16_t* __restrict_
             s += a0 + a1;
             ss += a0 * a0 + a1 * a1;
         }
-        const int g = (2 * c2) / cpg;                          // cpg is even: both channels of a pair share a group
-        atomicAdd(&acc[2 * g], s);
-        atomicAdd(&acc[2 * g + 1], ss);
+        buf[tr * npair + c2] = float2{s, ss};
     }
     __syncthreads();
-    for (int i = tid; i < 2 * G; i += 256) atomicAdd(&stats[(size_t)b * 2 * G + i], acc[i]);
+    const int ppg = cpg >> 1;                                   // channel pairs per group (cpg is even)
+    for (int g = tid; g < G; g += 256) {
+        float s = 0.f, ss = 0.f;
+        for (int rr = 0; rr < R; ++rr)
+            for (int k = 0; k < ppg; ++k) {
+                const float2 v = buf[rr * npair + g * ppg + k];
+                s += v.x;
+                ss += v.y;
+            }
+        partial[((size_t)b * gridDim.x + blockIdx.x) * G + g] = float2{s, ss};
+    }
 }
 
-__global__ __launch_bounds__(256) void groupnorm_apply(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void groupnorm_finalize(const float2* __restrict__ partial, float2* __restrict__ stats, int BG, int G, int nblk,
+                                                          float inv_n, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;              // i = b*G + g
+    if (i >= BG) return;
+    const int b = i / G, g = i - b * G;
+    float s = 0.f, ss = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        const float2 v = partial[((size_t)b * nblk + k) * G + g];
+        s += v.x;
+        ss += v.y;
+    }
+    const float mean = s * inv_n;
+    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+    stats[i] = float2{mean, rsqrtf(var + eps)};
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply(const bf16_t* __restrict__ x, const float2* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16_t* __restrict__ y, long total_vec, int HW, int C, int cpg, float eps, int silu) {
+                                                       bf16_t* __restrict__ y, long total_vec, int HW, int C, int cpg, int silu) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total_vec) return;
     const int cv8 = C >> 3;
     const long row = idx / cv8;
     const int c0 = (int)(idx - row * cv8) * 8;
     const int b = (int)(row / HW), G = C / cpg;
-    const float inv_n = 1.0f / ((float)HW * (float)cpg);
     const u32x4 raw = *reinterpret_cast<const u32x4*>(x + row * C + c0);
     const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
@@ -75,18 +101,12 @@ __global__ __launch_bounds__(256) void groupnorm_apply(const bf16_t* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(raw[e]); v[2 * e + 1] = bf_hi(raw[e]); }
     int gprev = -1;
-    float mean = 0.f, rstd = 0.f;
+    float2 st = float2{0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = (c0 + e) / cpg;
-        if (g != gprev) {
-            const float s = stats[((size_t)b * G + g) * 2], ss = stats[((size_t)b * G + g) * 2 + 1];
-            mean = s * inv_n;
-            const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-            rstd = rsqrtf(var + eps);
-            gprev = g;
-        }
-        float o = (v[e] - mean) * rstd * gm[e] + bt[e];
+        if (g != gprev) { st = stats[(size_t)b * G + g]; gprev = g; }
+        float o = (v[e] - st.x) * st.y * gm[e] + bt[e];
         if (silu) o = o * __builtin_amdgcn_rcpf(1.0f + __expf(-o));
         v[e] = o;
     }
@@ -232,31 +252,43 @@ inline int launched(const char* what) {
 
 }  // namespace
 
-extern "C" size_t visrep_groupnorm_workspace_bytes(int B, int groups) { return (size_t)B * groups * 2 * sizeof(float); }
+namespace {
+inline int gn_rows_per_block(int B, int HW) {
+    // enough blocks to fill 256 CUs a few times over, but at least 32 rows per block
+    int rows = (int)(((long)B * HW + 2047) / 2048);
+    rows = rows < 32 ? 32 : rows;
+    return rows > HW ? HW : rows;
+}
+}  // namespace
+
+extern "C" size_t visrep_groupnorm_workspace_bytes(int B, int HW, int groups) {
+    if (B <= 0 || HW <= 0 || groups <= 0) return 0;
+    const int rows = gn_rows_per_block(B, HW), nblk = (HW + rows - 1) / rows;
+    return (size_t)B * groups * (nblk + 1) * sizeof(float2);
+}
 
 extern "C" int visrep_groupnorm(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups,
                                 float eps, int silu, void* workspace, void* stream) {
     if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: empty problem");
-    if (C % groups || C % 8 || groups > 128) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: C must be a multiple of groups and of 8, groups <= 128");
+    if (C % groups || C % 8) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: C must be a multiple of groups and of 8");
     const int cpg = C / groups;
     if (cpg & 1) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: channels per group must be even");
     if (!workspace) return visrep_set_error(VISREP_ERR_ARG, "groupnorm: workspace missing");
     hipStream_t st = (hipStream_t)stream;
-    float* stats = (float*)workspace;
-    if (hipMemsetAsync(stats, 0, visrep_groupnorm_workspace_bytes(B, groups), st) != hipSuccess)
-        return visrep_set_error(VISREP_ERR_LAUNCH, "groupnorm: memset failed");
     const int npair = C / 2;
     int W = 256;
     if (npair <= 128) { W = 1; while (W < npair) W <<= 1; }
-    // enough blocks to fill 256 CUs a few times over, but at least 32 rows per block so LDS/global atomics stay negligible
-    int rows = (int)(((long)B * HW + 2047) / 2048);
-    rows = rows < 32 ? 32 : rows;
-    rows = rows > HW ? HW : rows;
-    const dim3 grid((HW + rows - 1) / rows, B);
-    hipLaunchKernelGGL(groupnorm_stats, grid, dim3(256), 0, st, (const bf16_t*)x, stats, HW, C, cpg, rows, W);
+    const int R = 256 / W, rows = gn_rows_per_block(B, HW), nblk = (HW + rows - 1) / rows;
+    float2* stats = (float2*)workspace;
+    float2* partial = stats + (size_t)B * groups;
+    const size_t lds = (size_t)R * npair * sizeof(float2);
+    hipLaunchKernelGGL(groupnorm_stats, dim3(nblk, B), dim3(256), lds, st, (const bf16_t*)x, partial, HW, C, cpg, rows, W);
+    const int BG = B * groups;
+    hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 255) / 256), dim3(256), 0, st, (const float2*)partial, stats, BG, groups, nblk,
+                       1.0f / ((float)HW * (float)cpg), eps);
     const long total = (long)B * HW * (C / 8);
-    hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float*)stats, gamma, beta,
-                       (bf16_t*)y, total, HW, C, cpg, eps, silu);
+    hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta,
+                       (bf16_t*)y, total, HW, C, cpg, silu);
     return launched("groupnorm: launch failed");
 }
 

@@ -38,7 +38,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, 
     lib = _lib.require_gpu()
     M, C = x.shape
     y = torch.empty_like(x)
-    ws = torch.empty(lib.visrep_groupnorm_workspace_bytes(B, groups), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(lib.visrep_groupnorm_workspace_bytes(B, M // B, groups), dtype=torch.uint8, device=x.device)
     rc = lib.visrep_groupnorm(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), B, M // B, C, groups, float(eps), int(silu),
                               _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, "visrep_groupnorm")
@@ -113,7 +113,8 @@ class _Lin:
 
 
 class SdEngine:
-    def __init__(self, spec: SdSpec, w_unet: Dict[str, torch.Tensor], w_vae: Dict[str, torch.Tensor], device=None, up_ft_index: int = 0):
+    def __init__(self, spec: SdSpec, w_unet: Dict[str, torch.Tensor], w_vae: Dict[str, torch.Tensor], device=None, up_ft_index: int = 0,
+                 graph: bool = True):
         _lib.require_gpu()
         self.spec = spec
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -131,6 +132,10 @@ class SdEngine:
         self._pack_unet()
         self._t = None
         self._ctx = None
+        self._ctx_version = 0
+        self._prompt_src = None
+        self.graph = graph
+        self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
 
     # ---------------------------------------------------------------- packing helpers
@@ -285,12 +290,15 @@ class SdEngine:
             b[: lin.n] = w[f"{name}.conv1.bias"] + add
             lin.b = self._dev(b, torch.float32)
         self._t = int(t)
+        self._graphs.clear()                         # conv1 biases were re-allocated: captured pointers are stale
 
     def set_prompt(self, prompt_embeds: torch.Tensor):
         """prompt_embeds [1, L, cross_dim] (pipe.encode_prompt output, dift_sd.py:258-263): per-layer K and V^T, computed once."""
         ctx = prompt_embeds.reshape(-1, prompt_embeds.shape[-1]).to(device=self.device, dtype=torch.bfloat16).contiguous()
         self._ctx_len = ctx.shape[0]
         self._ctx = {}
+        self._ctx_version += 1                      # captured graphs hold pointers to the previous prompt's K / V^T
+        self._graphs.clear()
         for key in [k for k in self.P if k.endswith(".attn2.k")]:
             b = key[: -len(".attn2.k")]
             self._ctx[b] = (gemm(ctx, self.P[f"{b}.attn2.k"].w), linear_vt(ctx, self.P[f"{b}.attn2.v"].w, None))
@@ -428,31 +436,12 @@ class SdEngine:
         return h.view(B, H * W, h.shape[1])
 
     # ---------------------------------------------------------------- SDFeaturizer.forward + DiffVisionTower.forward
-    @torch.no_grad()
-    def forward(self, img: torch.Tensor, prompt_embeds: Optional[torch.Tensor] = None, t: int = 1, ensemble_size: int = 1,
-                post_noise: Optional[torch.Tensor] = None, ddim_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """img [B,3,H,W] in [-1,1] -> [B, h*w, c] bf16 features of up block `up_ft_index`.
-
-        post_noise / ddim_noise [B*ensemble, Z, H/f, W/f] fp32: the reference's two randn draws (dift_sd.py:172,175);
-        drawn with torch.randn on the device when omitted."""
+    def _forward_impl(self, x, post, ddim, t, B, ensemble_size):
         lib = _lib.require_gpu()
         sp = self.spec
-        if prompt_embeds is not None:
-            self.set_prompt(prompt_embeds)
-        self.set_timestep(t)
-        B = img.shape[0]
-        x = img.to(self.device)
-        if x.dtype not in (torch.float32, torch.bfloat16):
-            x = x.float()
-        x = x.repeat_interleave(ensemble_size, dim=0) if ensemble_size > 1 else x      # dift_sd.py:251
         Be = B * ensemble_size
         moments, h, w = self.vae_moments(x)
         Z = sp.vae.latent_channels
-        shape = (Be, Z, h, w)
-        post = torch.randn(shape, device=self.device) if post_noise is None else post_noise.to(self.device, torch.float32).contiguous()
-        ddim = torch.randn(shape, device=self.device) if ddim_noise is None else ddim_noise.to(self.device, torch.float32).contiguous()
-        if tuple(post.shape) != shape or tuple(ddim.shape) != shape:
-            raise ValueError(f"noise tensors must have shape {shape}")
         lat = torch.empty(Be * h * w, 8, dtype=torch.bfloat16, device=self.device)
         rc = lib.visrep_sd_noisy_latents(_lib.ptr(moments), moments.stride(0), _lib.ptr(post), _lib.ptr(ddim), _lib.ptr(lat), Be, Z,
                                          h * w, 8, float(sp.vae.scaling_factor), float(self._ac[int(t)]), _lib.stream_ptr())
@@ -461,3 +450,51 @@ class SdEngine:
         if ensemble_size > 1:
             ft = mean_groups(ft, B, ensemble_size).view(B, ft.shape[1], ft.shape[2])
         return ft
+
+    @torch.no_grad()
+    def forward(self, img: torch.Tensor, prompt_embeds: Optional[torch.Tensor] = None, t: int = 1, ensemble_size: int = 1,
+                post_noise: Optional[torch.Tensor] = None, ddim_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """img [B,3,H,W] in [-1,1] -> [B, h*w, c] bf16 features of up block `up_ft_index`.
+
+        post_noise / ddim_noise [B*ensemble, Z, H/f, W/f] fp32: the reference's two randn draws (dift_sd.py:172,175);
+        drawn with torch.randn on the device when omitted.
+
+        The ~400 launches of one forward are captured once per (batch, resolution, t, ensemble) into a HIP graph and
+        replayed (`graph=False` at construction disables it): at batch 1 the eager forward is launch-bound."""
+        sp = self.spec
+        if prompt_embeds is not None and prompt_embeds is not self._prompt_src:     # same tensor object = same prompt: keep K / V^T
+            self.set_prompt(prompt_embeds)
+            self._prompt_src = prompt_embeds
+        self.set_timestep(t)
+        if self._ctx is None:
+            raise RuntimeError("set_timestep() and set_prompt() must be called before the UNet runs")
+        B = img.shape[0]
+        x = img.to(self.device)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = (x.repeat_interleave(ensemble_size, dim=0) if ensemble_size > 1 else x).contiguous()      # dift_sd.py:251
+        Be = B * ensemble_size
+        f = 2 ** (len(sp.vae.block_out) - 1)
+        shape = (Be, sp.vae.latent_channels, x.shape[2] // f, x.shape[3] // f)
+        post = torch.randn(shape, device=self.device) if post_noise is None else post_noise.to(self.device, torch.float32).contiguous()
+        ddim = torch.randn(shape, device=self.device) if ddim_noise is None else ddim_noise.to(self.device, torch.float32).contiguous()
+        if tuple(post.shape) != shape or tuple(ddim.shape) != shape:
+            raise ValueError(f"noise tensors must have shape {shape}")
+        if not self.graph:
+            return self._forward_impl(x, post, ddim, t, B, ensemble_size)
+        key = (tuple(x.shape), x.dtype, int(t), ensemble_size, self._ctx_version)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._forward_impl(x, post, ddim, t, B, ensemble_size)                  # eager warm-up: lazy inits happen outside capture
+            sx, sp_, sd_ = x.clone(), post.clone(), ddim.clone()
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g):
+                out = self._forward_impl(sx, sp_, sd_, t, B, ensemble_size)
+            if len(self._graphs) >= 4:                                              # bound the memory pinned by captured pools
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = (g, sx, sp_, sd_, out)
+        g, sx, sp_, sd_, out = ent
+        sx.copy_(x); sp_.copy_(post); sd_.copy_(ddim)
+        g.replay()
+        return out.clone()

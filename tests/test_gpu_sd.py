@@ -179,6 +179,23 @@ def test_sd_tower_matches_reference_golden(tag):
     assert e_hip < max(2.0 * e_ref, 2e-2), (tag, e_hip, e_ref)
 
 
+def test_sd_tower_graph_replay_equals_eager():
+    sp, wu, wv, inp, _ = load_sd_case("conv_up1_ens2")
+    kw = dict(t=inp["t"], ensemble_size=inp["ensemble_size"], post_noise=inp["post_noise"], ddim_noise=inp["ddim_noise"])
+    eager = SE.SdEngine(sp, wu, wv, DEV, up_ft_index=1, graph=False).forward(inp["img"], inp["prompt_embeds"], **kw)
+    eng = SE.SdEngine(sp, wu, wv, DEV, up_ft_index=1, graph=True)
+    pe = inp["prompt_embeds"]
+    first = eng.forward(inp["img"], pe, **kw)                    # warm-up + capture + replay
+    assert len(eng._graphs) == 1
+    again = eng.forward(inp["img"], pe, **kw)                    # replay only
+    other = eng.forward(inp["img"].flip(-1), pe, **kw)           # same graph, new input
+    assert len(eng._graphs) == 1
+    assert torch.equal(first, eager) and torch.equal(again, eager)            # every reduction has a fixed order: bit-reproducible
+    assert rel_err(other, eager) > 0.05
+    eng.forward(inp["img"], pe, **{**kw, "t": 5})                # a new timestep re-folds the conv1 biases: graphs dropped
+    assert len(eng._graphs) == 1 and list(eng._graphs)[0][2] == 5
+
+
 def test_sd_tower_random_noise_path_and_state_errors():
     sp, wu, wv, inp, _ = load_sd_case("conv_up0")
     eng = SE.SdEngine(sp, wu, wv, DEV)

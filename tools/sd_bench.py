@@ -42,5 +42,8 @@ ms_vae, (mom, h, w) = timed(lambda: eng.vae_moments(img), reps)
 lat = torch.randn(B * h * w, 8, device=dev).to(torch.bfloat16)
 ms_unet, ft = timed(lambda: eng.unet_features(lat, B, h, w), reps)
 ms_all, out = timed(lambda: eng.forward(img, t=261), reps)
+eng.graph = False
+ms_eager, _ = timed(lambda: eng.forward(img, t=261), reps)
+print(f"eager forward {ms_eager:.1f} ms vs graph {ms_all:.1f} ms")
 print(f"B={B} side={side}: vae {ms_vae:.1f} ms, unet {ms_unet:.1f} ms, forward {ms_all:.1f} ms -> {B / ms_all * 1e3:.2f} img/s; "
       f"out {tuple(out.shape)} finite={bool(torch.isfinite(out.float()).all())} peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
