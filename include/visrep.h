@@ -50,6 +50,12 @@ int visrep_debug_gemm_ablation(int mask);
  * (wave 0 and wave 4 of block 0); ignored by production builds. */
 int visrep_debug_gemm_timing_buffer(void* dev_u64x16);
 
+/* ---- optional device scratch owned by the caller (e.g. one torch tensor kept alive for the process).  With it,
+ * visrep_gemm_bf16 splits the K loop of problems that have few output tiles but a deep reduction (the diffusion towers'
+ * 3x3 convolutions at 12x12 / 24x24 resolution) across CUs and reduces the fp32 partial planes in slice order, i.e.
+ * deterministically.  Not thread-safe against concurrent GEMMs on other streams: one scratch per process.  (NULL, 0) detaches. */
+int visrep_set_scratch(void* ptr, size_t bytes);
+
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
  * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from
  * llava/model/multimodal_encoder/clip_encoder.py:48) and the mm_projector Sequential

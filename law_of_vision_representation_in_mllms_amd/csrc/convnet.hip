@@ -69,18 +69,23 @@ __global__ __launch_bounds__(256) void groupnorm_stats(const bf16_t* __restrict_
 
 __global__ __launch_bounds__(256) void groupnorm_finalize(const float2* __restrict__ partial, float2* __restrict__ stats, int BG, int G, int nblk,
                                                           float inv_n, float eps) {
-    const int i = blockIdx.x * 256 + threadIdx.x;              // i = b*G + g
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);         // one wave per (b, g): i = b*G + g
     if (i >= BG) return;
     const int b = i / G, g = i - b * G;
     float s = 0.f, ss = 0.f;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = lane; k < nblk; k += 64) {                    // lane-strided, then a fixed butterfly: order never changes
         const float2 v = partial[((size_t)b * nblk + k) * G + g];
         s += v.x;
         ss += v.y;
     }
-    const float mean = s * inv_n;
-    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-    stats[i] = float2{mean, rsqrtf(var + eps)};
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const float mean = s * inv_n;
+        const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+        stats[i] = float2{mean, rsqrtf(var + eps)};
+    }
 }
 
 __global__ __launch_bounds__(256) void groupnorm_apply(const bf16_t* __restrict__ x, const float2* __restrict__ stats,
@@ -284,7 +289,7 @@ extern "C" int visrep_groupnorm(const void* x, const float* gamma, const float* 
     const size_t lds = (size_t)R * npair * sizeof(float2);
     hipLaunchKernelGGL(groupnorm_stats, dim3(nblk, B), dim3(256), lds, st, (const bf16_t*)x, partial, HW, C, cpg, rows, W);
     const int BG = B * groups;
-    hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 255) / 256), dim3(256), 0, st, (const float2*)partial, stats, BG, groups, nblk,
+    hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 3) / 4), dim3(256), 0, st, (const float2*)partial, stats, BG, groups, nblk,
                        1.0f / ((float)HW * (float)cpg), eps);
     const long total = (long)B * HW * (C / 8);
     hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta,

@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     const int t = xcd_remap(blockIdx.x, ntm * ntn);
     const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
 
+    // split-K: slice blockIdx.y covers K columns [y*kslice, (y+1)*kslice) and writes its own fp32 [M, ldc] plane
+    const int kbase = p.kslice ? (int)blockIdx.y * p.kslice : 0;
     // ---- staging addresses: 16-B chunk c = j*256 + tid, row = c>>3 = j*32 + (tid>>3), physical slot = tid&7
     const int srow = tid >> 3;
     const int lslot = (tid & 7) ^ ((srow >> 1) & 7);          // logical slot this lane must fetch (swizzle on the source)
@@ -44,10 +46,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     for (int j = 0; j < 4; ++j) {
         int ra = m0 + j * 32 + srow;
         ra = ra < p.M ? ra : p.M - 1;                          // clamp: rows past M are computed but never stored
-        ga[j] = p.A + (size_t)ra * p.lda + lslot * 8;
+        ga[j] = p.A + (size_t)ra * p.lda + kbase + lslot * 8;
         int rw = n0 + j * 32 + srow;
         rw = rw < p.N ? rw : p.N - 1;
-        gw[j] = p.W + (size_t)rw * p.ldw + lslot * 8;
+        gw[j] = p.W + (size_t)rw * p.ldw + kbase + lslot * 8;
     }
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE_BYTES + wave * 1024;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = (p.kslice ? p.kslice : p.K) / BK;
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -101,6 +103,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
 
     // ------------------------------------------------------------------ epilogues (gemm_epilogue.h)
     if (n0 + wn * 64 >= p.N) return;                          // wave-uniform: the empty half of an N-edge tile
+    if (EPI == EPI_F32 && p.kslice) {
+        GemmArgs q = p;
+        q.C = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * p.M * p.ldc);
+        gemm_epilogue_rowmajor<EPI, 4, 4>(q, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
+        return;
+    }
     if (EPI == EPI_VT) gemm_epilogue_vt<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
     else gemm_epilogue_rowmajor<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
@@ -113,13 +121,48 @@ int launch(const GemmArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_128<EPI>, dim3(ntm * ntn), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL(gemm_bf16_128<EPI>, dim3(ntm * ntn, a.kslice ? a.K / a.kslice : 1), dim3(256), LDS_BYTES, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+}
+
+// ---- split-K reduction: out = epilogue( sum_s part[s] ), slices added in index order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ part, int S, const GemmArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // one thread per 4 consecutive n
+    const int nv = p.N >> 2;
+    if (idx >= (long)p.M * nv) return;
+    const int m = (int)(idx / nv), n = (int)(idx - (long)m * nv) * 4;
+    const size_t plane = (size_t)p.M * p.N;
+    float4 acc = *reinterpret_cast<const float4*>(part + (size_t)m * p.N + n);
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(part + s * plane + (size_t)m * p.N + n);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    if (p.epi == EPI_ACT) { acc.x = apply_act(acc.x, p.act); acc.y = apply_act(acc.y, p.act); acc.z = apply_act(acc.z, p.act); acc.w = apply_act(acc.w, p.act); }
+    if (p.epi == EPI_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = acc;
+        return;
+    }
+    if (p.epi == EPI_RESID) {
+        if (p.ls) {
+            const float4 l = *reinterpret_cast<const float4*>(p.ls + n);
+            acc.x *= l.x; acc.y *= l.y; acc.z *= l.z; acc.w *= l.w;
+        }
+        const u32x2 r = *reinterpret_cast<const u32x2*>(p.resid + (size_t)m * p.ldc + n);
+        acc.x += bf_lo(r[0]); acc.y += bf_hi(r[0]); acc.z += bf_lo(r[1]); acc.w += bf_hi(r[1]);
+    }
+    u32x2 o = {pack_bf16(acc.x, acc.y), pack_bf16(acc.z, acc.w)};
+    *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
 }
 
 }  // namespace
 
 int g_visrep_gemm_variant = 2;
+void* g_visrep_scratch = nullptr;
+size_t g_visrep_scratch_bytes = 0;
 int g_visrep_gemm_dbg = 0;
 unsigned long long* g_visrep_gemm_dbg_buf = nullptr;
 
@@ -164,6 +207,31 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
     const int variant = g_visrep_gemm_variant;
+    // Few output tiles but a deep reduction (3x3 convolutions of the diffusion towers at 12x12 / 24x24 resolution:
+    // M = 144 .. 576, K = 9 * 1280 .. 9 * 2560): a handful of CUs would walk K serially.  Split K over blockIdx.y into fp32
+    // planes in the caller's scratch (visrep_set_scratch) and reduce them in slice order with the epilogue fused.
+    if (g_visrep_scratch && a.epi != EPI_VT && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0) {
+        const int ncu = cu_count();
+        const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+        if (tiles * 2 <= ncu) {
+            const int kt = a.K / BK;
+            int S = (int)(ncu / tiles);
+            if (S > kt / 4) S = kt / 4;                                   // at least 4 K-tiles per slice
+            while (S > 1 && kt % S) --S;
+            if (S > 1 && (size_t)S * a.M * a.N * sizeof(float) <= g_visrep_scratch_bytes) {
+                GemmArgs part = a;
+                part.C = reinterpret_cast<bf16_t*>(g_visrep_scratch);
+                part.ldc = a.N;
+                part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr;
+                part.kslice = a.K / S;
+                const int rc = launch<EPI_F32>(part, s);
+                if (rc) return rc;
+                const long nthreads = (long)a.M * (a.N / 4);
+                hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+                return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "gemm: split-K reduce launch failed");
+            }
+        }
+    }
     // Tile quantisation: the persistent 256x256 kernels run one block per CU, so T tiles cost ceil(T / CUs) tile-times.
     // The BASELINE shapes have M = 256 * 577 (577 is prime): 2308 / 4616 / 9232 tiles = 9 / 18 / 36 full rounds + a 4..16-tile
     // remainder that would cost a whole extra round on 252 idle CUs.  When the remainder is small, the rows of the last

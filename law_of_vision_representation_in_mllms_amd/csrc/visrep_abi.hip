@@ -42,6 +42,14 @@ extern "C" size_t visrep_last_error(char* buf, size_t n) {
     return len;
 }
 
+extern "C" int visrep_set_scratch(void* ptr, size_t bytes) {
+    if ((ptr == nullptr) != (bytes == 0)) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pass (ptr, bytes) or (NULL, 0)");
+    if ((size_t)ptr & 15) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pointer must be 16-byte aligned");
+    g_visrep_scratch = ptr;
+    g_visrep_scratch_bytes = bytes;
+    return 0;
+}
+
 extern "C" int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
                                 int K, int epilogue, int act, const void* resid, const float* ls, void* stream) {
     if (!A || !W || !C) return visrep_set_error(VISREP_ERR_ARG, "gemm: null pointer");

@@ -20,6 +20,7 @@ struct GemmArgs {
     int M, N, K, lda, ldw, ldc;
     int epi, act;
     int patches, tokens, cls_off;   // EPI_PATCH row remap
+    int kslice;                     // split-K (v1, EPI_F32 only): blockIdx.y = slice, K elements per slice; 0 = no split
     unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };
@@ -33,3 +34,5 @@ extern int g_visrep_gemm_dbg;
 extern unsigned long long* g_visrep_gemm_dbg_buf;
 extern int g_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 3 = 256x256 persistent ping-pong kernels (when N % 256 == 0)
 int visrep_set_error(int code, const char* msg);
+extern void* g_visrep_scratch;       // caller-owned device scratch (visrep_set_scratch): split-K partial sums
+extern size_t g_visrep_scratch_bytes;

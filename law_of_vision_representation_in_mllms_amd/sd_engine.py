@@ -32,6 +32,18 @@ def _ru(v: int, a: int) -> int:
     return (v + a - 1) // a * a
 
 
+_SCRATCH = {}
+
+
+def ensure_scratch(device, nbytes: int = 32 << 20) -> None:
+    """One process-wide split-K scratch for visrep_gemm_bf16 (visrep_set_scratch): S * M * N * 4 bytes <= 16.8 MB by
+    construction of the split rule (S * tiles <= 256 CUs, 128x128 tiles)."""
+    if "buf" not in _SCRATCH:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(_lib.require_gpu().visrep_set_scratch(_lib.ptr(buf), nbytes), "visrep_set_scratch")
+        _SCRATCH["buf"] = buf
+
+
 # ------------------------------------------------------------------------------------------------ thin op wrappers
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, groups: int, eps: float, silu: bool) -> torch.Tensor:
     """x [B*HW, C] bf16 contiguous -> GroupNorm(+SiLU), same shape."""
@@ -127,6 +139,7 @@ class SdEngine:
         for c in u.block_out + spec.vae.block_out:
             if c % 64:
                 raise ValueError("block widths must be multiples of 64")
+        ensure_scratch(self.device)
         self.P: Dict[str, object] = {}
         self._pack_vae()
         self._pack_unet()

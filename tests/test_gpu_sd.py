@@ -77,6 +77,33 @@ def test_conv3x3_as_gather_plus_gemm(B, H, W, Ci, Co, stride, pad_mode, up):
     assert (got.cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(144, 1280, 11520), (576, 320, 2880), (64, 128, 1024), (300, 1280, 23040)])
+def test_gemm_split_k_small_m_deep_k(M, N, K):
+    """Few tiles, deep reduction: with the scratch attached the K loop is split over CUs and reduced in slice order."""
+    g = torch.Generator().manual_seed(M + K)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias, ls = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    x = bf(torch.randn(M, N, generator=g)).to(DEV)
+    lib = _lib.load()
+    assert lib.visrep_set_scratch(None, 0) == 0
+    SE._SCRATCH.clear()
+    plain = [engine.gemm(a, w, bias, _lib.EPI_F32), engine.gemm(a, w, bias, _lib.EPI_ACT, act="gelu"),
+             engine.gemm(a, w, bias, _lib.EPI_RESID, resid=x, ls=ls), engine.gemm(a, w, None, _lib.EPI_BIAS)]
+    SE.ensure_scratch(torch.device(DEV))
+    split = [engine.gemm(a, w, bias, _lib.EPI_F32), engine.gemm(a, w, bias, _lib.EPI_ACT, act="gelu"),
+             engine.gemm(a, w, bias, _lib.EPI_RESID, resid=x, ls=ls), engine.gemm(a, w, None, _lib.EPI_BIAS)]
+    want = a.float() @ w.float().t() + bias
+    assert (split[0] - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    for p, q in zip(plain, split):
+        assert rel_err(q, p) < 4e-3
+    x2 = x.clone()
+    engine.gemm(a, w, bias, _lib.EPI_RESID, resid=x2, out=x2)                 # in place
+    assert rel_err(x2, x.float() + want) < 4e-3
+    again = engine.gemm(a, w, bias, _lib.EPI_F32)
+    assert torch.equal(again, split[0])                                       # slice order is fixed: bit-reproducible
+
+
 def test_geglu_and_mean_groups_and_softmax_rows():
     g = torch.Generator().manual_seed(1)
     x = bf(torch.randn(70, 512, generator=g) * 2)
