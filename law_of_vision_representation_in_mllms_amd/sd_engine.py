@@ -133,16 +133,11 @@ class SdEngine:
         self.up_ft_index = up_ft_index
         self.wu = {k: v.detach().float() for k, v in w_unet.items()}       # fp32 masters on the host (repacked below)
         self.wv = {k: v.detach().float() for k, v in w_vae.items()}
-        u = spec.unet
-        if up_ft_index >= len(u.block_out):
-            raise ValueError("up_ft_index out of range")
-        for c in u.block_out + spec.vae.block_out:
-            if c % 64:
-                raise ValueError("block widths must be multiples of 64")
+        self._check_spec()
         ensure_scratch(self.device)
         self.P: Dict[str, object] = {}
         self._pack_vae()
-        self._pack_unet()
+        self._pack_core()
         self._t = None
         self._ctx = None
         self._ctx_version = 0
@@ -150,6 +145,20 @@ class SdEngine:
         self.graph = graph
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
+
+    def _check_spec(self):
+        u = self.spec.unet
+        if not 0 <= self.up_ft_index < len(u.block_out):
+            raise ValueError("up_ft_index out of range")
+        for c in u.block_out + self.spec.vae.block_out:
+            if c % 64:
+                raise ValueError("block widths must be multiples of 64")
+
+    def _pack_core(self):
+        self._pack_unet()
+
+    def core_features(self, lat, B, H, W):
+        return self.unet_features(lat, B, H, W)
 
     # ---------------------------------------------------------------- packing helpers
     def _dev(self, t, dtype):
@@ -459,7 +468,7 @@ class SdEngine:
         rc = lib.visrep_sd_noisy_latents(_lib.ptr(moments), moments.stride(0), _lib.ptr(post), _lib.ptr(ddim), _lib.ptr(lat), Be, Z,
                                          h * w, 8, float(sp.vae.scaling_factor), float(self._ac[int(t)]), _lib.stream_ptr())
         _lib.check(rc, "visrep_sd_noisy_latents")
-        ft = self.unet_features(lat, Be, h, w)
+        ft = self.core_features(lat, Be, h, w)
         if ensemble_size > 1:
             ft = mean_groups(ft, B, ensemble_size).view(B, ft.shape[1], ft.shape[2])
         return ft

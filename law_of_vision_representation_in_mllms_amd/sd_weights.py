@@ -187,7 +187,7 @@ def _synthetic(table, seed):
     for name, shape in table:
         if name.endswith("bias"):
             w = rs.standard_normal(shape) * 0.05
-        elif "norm" in name:
+        elif "norm" in name.split(".")[-2]:          # affine of a normalisation layer (not e.g. `norm1.linear.weight`)
             w = 1.0 + 0.1 * rs.standard_normal(shape)
         else:
             fan_in = int(np.prod(shape[1:]))
@@ -244,3 +244,64 @@ def synthetic_text(s: TextSpec, seed: int):
 
 def tiny_text_spec(act="quick_gelu", layers=2, max_pos=16) -> TextSpec:
     return TextSpec(vocab=99, d=128, mlp=256, layers=layers, heads=2, max_pos=max_pos, act=act)
+
+
+# ----------------------------------------------------------------------------------------------- DiT (facebook/DiT-XL-2-512)
+@dataclass(frozen=True)
+class DiTCoreSpec:
+    """DiTTransformer2DModel config subset (dit_transformer_2d.py:72-90; DiT-XL/2: 28 layers, 16 heads x 72)."""
+    heads: int = 16
+    head_dim: int = 72
+    in_channels: int = 4
+    layers: int = 28
+    sample_size: int = 64          # latent side the sincos table is built for (512-px checkpoint)
+    patch: int = 2
+    eps: float = 1e-5
+    num_classes: int = 1000
+
+    @property
+    def d(self):
+        return self.heads * self.head_dim
+
+
+@dataclass(frozen=True)
+class DiTSpec:
+    name: str
+    core: DiTCoreSpec = field(default_factory=DiTCoreSpec)
+    vae: VaeSpec = field(default_factory=VaeSpec)
+    # DiT-XL-2-512/scheduler/scheduler_config.json: linear betas 1e-4 .. 0.02
+    sched: SchedulerSpec = field(default_factory=lambda: SchedulerSpec(beta_start=0.0001, beta_end=0.02, beta_schedule="linear"))
+
+
+DIT_SPECS: Dict[str, DiTSpec] = {"facebook/DiT-XL-2-512": DiTSpec("facebook/DiT-XL-2-512")}
+
+
+def tiny_dit_spec() -> DiTSpec:
+    """The real head width (72, zero-padded to 128 on the device) at a model width that is a multiple of 64."""
+    return DiTSpec("tiny-dit", core=DiTCoreSpec(heads=8, head_dim=72, layers=2, sample_size=8, num_classes=10),
+                   vae=VaeSpec(block_out=(64, 64, 128), layers_per_block=1))
+
+
+def dit_param_table(c: DiTCoreSpec, n_layers: int = None) -> List[Tuple[str, tuple]]:
+    D = c.d
+    t = [("pos_embed.proj.weight", (D, c.in_channels, c.patch, c.patch)), ("pos_embed.proj.bias", (D,))]
+    for i in range(c.layers if n_layers is None else n_layers):
+        p = f"transformer_blocks.{i}"
+        e = f"{p}.norm1.emb"
+        t += [(f"{e}.timestep_embedder.linear_1.weight", (D, 256)), (f"{e}.timestep_embedder.linear_1.bias", (D,)),
+              (f"{e}.timestep_embedder.linear_2.weight", (D, D)), (f"{e}.timestep_embedder.linear_2.bias", (D,)),
+              (f"{e}.class_embedder.embedding_table.weight", (c.num_classes + 1, D)),       # dropped by the reference's override
+              (f"{p}.norm1.linear.weight", (6 * D, D)), (f"{p}.norm1.linear.bias", (6 * D,))]
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            t += [(f"{p}.attn1.{n}.weight", (D, D)), (f"{p}.attn1.{n}.bias", (D,))]
+        t += [(f"{p}.ff.net.0.proj.weight", (4 * D, D)), (f"{p}.ff.net.0.proj.bias", (4 * D,)),
+              (f"{p}.ff.net.2.weight", (D, 4 * D)), (f"{p}.ff.net.2.bias", (D,))]
+    return t
+
+
+def synthetic_dit(c: DiTCoreSpec, seed: int, n_layers: int = None):
+    w = _synthetic(dit_param_table(c, n_layers), seed)
+    for k in w:                       # adaLN modulation: O(0.3) shifts / scales / gates instead of O(1) so depth stays tame
+        if k.endswith("norm1.linear.weight"):
+            w[k] *= 0.3
+    return w

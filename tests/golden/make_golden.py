@@ -564,6 +564,61 @@ def gen_sd():
     np.savez_compressed(f"{HERE}/sd_tiny.npz", **out)
 
 
+# ----------------------------------------------------------------------------- DiT feature tower
+def gen_dit():
+    """Reference `MyDiTTransformer2DModel` + `replace_combined_timestep_label_embeddings` (dift_dit.py:9-124,146-156) over the
+    vendored diffusers DiT blocks, vendored AutoencoderKL / DDIMScheduler.add_noise as in `OneStepDiTPipeline.__call__`
+    (:133-142), then the unfold of `DiTFeaturizer.forward` (:190-195) and DiffVisionTower.forward's permute."""
+    sys.path.insert(0, f"{REF}/diffusers/src")
+    import diffusers
+    from diffusers import DDIMScheduler
+    from diffusers.models.autoencoders.autoencoder_kl import AutoencoderKL
+    diffusers.DiTPipeline = object
+    spec = importlib.util.spec_from_file_location("ref_dift_dit", f"{REF}/llava/model/multimodal_encoder/diffLVLM/src/models/dift_dit.py")
+    dift = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dift)
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    out = {"diffusers_version": np.array(diffusers.__version__)}
+    for tag, (idx, t, B, side, seed) in {"last": (-1, 261, 2, 64, 31), "first_other_res": (0, 50, 1, 32, 32)}.items():
+        sp = SW.tiny_dit_spec()
+        c, v = sp.core, sp.vae
+        dit = dift.MyDiTTransformer2DModel(num_attention_heads=c.heads, attention_head_dim=c.head_dim, in_channels=c.in_channels,
+                                           num_layers=c.layers, sample_size=c.sample_size, patch_size=c.patch,
+                                           num_embeds_ada_norm=c.num_classes, norm_eps=c.eps).eval()
+        dift.replace_combined_timestep_label_embeddings(dit)
+        wd = SW.synthetic_dit(c, seed)
+        r = dit.load_state_dict(wd, strict=False)
+        assert not r.unexpected_keys and all(k.startswith(("proj_out", "norm_out")) for k in r.missing_keys), r
+        n = len(v.block_out)
+        vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * n, up_block_types=("UpDecoderBlock2D",) * n,
+                            block_out_channels=v.block_out, layers_per_block=v.layers_per_block, latent_channels=v.latent_channels,
+                            norm_num_groups=v.groups).eval()
+        wv = SW.synthetic_vae(v, seed + 100)
+        r = vae.load_state_dict(wv, strict=False)
+        assert not r.unexpected_keys and all(k.startswith(("decoder", "post_quant_conv")) for k in r.missing_keys), r
+        sched = DDIMScheduler(beta_start=sp.sched.beta_start, beta_end=sp.sched.beta_end, beta_schedule=sp.sched.beta_schedule,
+                              num_train_timesteps=sp.sched.num_train_timesteps)
+        rs = np.random.RandomState(seed + 200)
+        img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32))
+        ls = side // 2 ** (n - 1)
+        post = torch.from_numpy(rs.standard_normal((B, v.latent_channels, ls, ls)).astype(np.float32))
+        ddim = torch.from_numpy(rs.standard_normal((B, v.latent_channels, ls, ls)).astype(np.float32))
+        dist = vae.encode(img).latent_dist
+        latents = (dist.mean + dist.std * post) * vae.config.scaling_factor
+        tt = torch.full((B,), t, dtype=torch.long)                                           # dift_dit.py:139
+        noisy = sched.add_noise(latents, ddim, tt)
+        ft = dit(noisy, up_ft_indices=[idx], timestep=tt)["up_ft"][idx]                       # [B, N, D]
+        h = w_ = int(ft.shape[-2] ** 0.5)                                                    # dift_dit.py:191-195
+        ft = ft.transpose(2, 1).reshape(B, -1, h, w_)
+        ft = ft.unfold(3, 2, 2).unfold(2, 2, 2)
+        ft = ft.reshape(B, -1, h // 2, w_ // 2, 4).permute(0, 4, 1, 2, 3).reshape(B, -1, h // 2, w_ // 2)
+        feats = ft.permute(0, 2, 3, 1).reshape(B, (h // 2) * (w_ // 2), -1)                   # diffusion_encoder.py:84-88
+        out.update({f"{tag}.img": img.numpy(), f"{tag}.post_noise": post.numpy(), f"{tag}.ddim_noise": ddim.numpy(),
+                    f"{tag}.noisy_latents": noisy.numpy(), f"{tag}.features": feats.numpy()})
+        print(tag, "features", tuple(feats.shape), "rms", float(feats.pow(2).mean().sqrt()))
+    np.savez_compressed(f"{HERE}/dit_tiny.npz", **out)
+
+
 # ----------------------------------------------------------------------------- CLIP text encoder (prompt embeddings)
 def gen_text():
     """HF CLIPTextModel (what pipe.encode_prompt runs, dift_sd.py:258-263), tiny random-init configs."""
@@ -623,7 +678,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit}[w]()

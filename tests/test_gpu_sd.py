@@ -278,3 +278,54 @@ def test_sd15_full_width_parity_and_tower_api(monkeypatch):
     out = tower(torch.cat([img, img.flip(-1)], 0))
     assert out.shape == (2, 16, 1280) and torch.isfinite(out.float()).all()
     assert tower(img[0]).shape == (1, 16, 1280)
+
+
+# ------------------------------------------------------------------------------------------------ DiT tower
+@pytest.mark.parametrize("tag", ["last", "first_other_res"])
+def test_dit_tower_matches_reference_golden(tag):
+    from test_oracle_golden import load_dit_case
+    from law_of_vision_representation_in_mllms_amd.dit_engine import DiTEngine
+    from oracle import dit as ODT
+    sp, wd, wv, inp, want = load_dit_case(tag)
+    eng = DiTEngine(sp, wd, wv, DEV, up_ft_index=inp["up_ft_index"])
+    kw = dict(t=inp["t"], post_noise=inp["post_noise"], ddim_noise=inp["ddim_noise"])
+    got = eng.forward(inp["img"], **kw)
+    ref_bf16 = ODT.dit_features(sp, wd, wv, inp["img"], inp["post_noise"], inp["ddim_noise"], t=inp["t"], up_ft_index=inp["up_ft_index"],
+                                dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert got.shape == want.shape and e_hip < max(2.0 * e_ref, 2e-2), (tag, e_hip, e_ref)
+    assert torch.equal(eng.forward(inp["img"], **kw), got)                           # graph replay, bit-reproducible
+    with pytest.raises(ValueError, match="ensemble"):
+        eng.forward(inp["img"], ensemble_size=2, **kw)
+
+
+def test_dit_xl2_full_width_parity_and_tower_api(monkeypatch):
+    """DiT-XL/2 widths (16 heads x 72 -> padded to 128, d = 1152, ff 4608) for the first 3 blocks on a 128-px image against the
+    fp32 CPU oracle, then the DiffVisionTower drop-in (4608-channel tokens)."""
+    from types import SimpleNamespace
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.dit_engine import DiTEngine
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM import diffusion_encoder as DE
+    from oracle import dit as ODT
+    sp = SW.DIT_SPECS["facebook/DiT-XL-2-512"]
+    wd, wv = SW.synthetic_dit(sp.core, 31, n_layers=3), SW.synthetic_vae(sp.vae, 32)
+    rs = np.random.RandomState(8)
+    img = torch.from_numpy(rs.uniform(-1, 1, (2, 3, 128, 128)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((2, 4, 16, 16)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((2, 4, 16, 16)).astype(np.float32))
+    got = DiTEngine(sp, wd, wv, DEV, up_ft_index=2).forward(img, t=261, post_noise=post, ddim_noise=ddim)
+    assert got.shape == (2, 16, 4608)
+    want = ODT.dit_features(sp, wd, wv, img, post, ddim, t=261, up_ft_index=2)
+    ref_bf16 = ODT.dit_features(sp, wd, wv, img, post, ddim, t=261, up_ft_index=2, dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert e_hip < max(2.0 * e_ref, 2e-2), (e_hip, e_ref)
+    # drop-in tower around a featurizer with these (3-block) weights
+    class Feat(DE.DiTFeaturizer):
+        def __init__(self, sd_id):
+            self.sd_id, self.device, self.spec, self._wd, self._wv = sd_id, torch.device(DEV), sp, wd, wv
+            self._engines, self.dtype = {}, torch.bfloat16
+    monkeypatch.setitem(DE.build_featurelizer_mapping, 'facebook/DiT-XL-2-512', Feat)
+    tower = DE.DiffVisionTower(SimpleNamespace(vision_tower='facebook/DiT-XL-2-512', up_ft_index=2, t=261, prompt="", ensemble_size=1, img_size=128))
+    assert tower.hidden_size == 4608
+    out = tower(img)
+    assert out.shape == (2, 16, 4608) and torch.isfinite(out.float()).all()

@@ -177,3 +177,26 @@ def test_text_oracle_matches_hf(tag):
     ts, w, ids, want = load_text_case(tag)
     got = OT.clip_text_hidden(w, ids, heads=ts.heads, act=ts.act)
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ DiT feature tower
+DIT_TAGS = {"last": (-1, 261, 31), "first_other_res": (0, 50, 32)}
+
+
+def load_dit_case(tag):
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    idx, t, seed = DIT_TAGS[tag]
+    z = np.load(os.path.join(G, "dit_tiny.npz"))
+    sp = SW.tiny_dit_spec()
+    inp = {k: torch.from_numpy(z[f"{tag}.{k}"]) for k in ("img", "post_noise", "ddim_noise", "noisy_latents")}
+    inp.update(t=t, up_ft_index=idx)
+    return sp, SW.synthetic_dit(sp.core, seed), SW.synthetic_vae(sp.vae, seed + 100), inp, torch.from_numpy(z[f"{tag}.features"])
+
+
+@pytest.mark.parametrize("tag", list(DIT_TAGS))
+def test_dit_oracle_matches_reference(tag):
+    from oracle import dit as ODT
+    sp, wd, wv, inp, want = load_dit_case(tag)
+    got = ODT.dit_features(sp, wd, wv, inp["img"], inp["post_noise"], inp["ddim_noise"], t=inp["t"], up_ft_index=inp["up_ft_index"])
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-3, atol=3e-4)
