@@ -164,6 +164,11 @@ int visrep_softmax_rows(const float* scores, int lds, void* probs, int ldp, int 
 /* [B, C, H, W] (dtype VISREP_BF16 | VISREP_F32) -> [B*H*W, Cpad] bf16, channels [C, Cpad) zero. */
 int visrep_nchw_to_tokens(const void* x, int dtype, void* y, int B, int C, int H, int W, int Cpad, void* stream);
 
+/* F.interpolate(x, size=(OH, OW), mode="bilinear") (align_corners=False, no antialias) over `planes` = B*C contiguous
+ * [H, W] planes (dtype VISREP_BF16 | VISREP_F32) -> bf16 [planes, OH, OW].  The image-variation featurizer resizes the
+ * input to 224x224 for its CLIP image encoder this way (dift_imsd.py:215-216). */
+int visrep_resize_bilinear(const void* x, int dtype, void* y, int planes, int H, int W, int OH, int OW, void* stream);
+
 /* dift_sd.py:172-176: latents = (mean + exp(0.5 * clamp(logvar, -30, 20)) * post_noise) * scaling_factor
  * (autoencoder_kl.py encode + vae.py DiagonalGaussianDistribution.sample), then DDIMScheduler.add_noise
  * (scheduling_ddim.py:471-495): sqrt(ac) * latents + sqrt(1 - ac) * ddim_noise.  moments: fp32 [B*HW, ldm] with the mean

@@ -250,6 +250,27 @@ __global__ __launch_bounds__(256) void mean_groups(const bf16_t* __restrict__ x,
     reinterpret_cast<uint32_t*>(y)[idx] = pack_bf16(s0 * inv, s1 * inv);
 }
 
+// F.interpolate(mode="bilinear", align_corners=False, antialias=False) on NCHW planes, fp32|bf16 in -> bf16 out
+template <bool F32>
+__global__ __launch_bounds__(256) void resize_bilinear(const void* __restrict__ x, bf16_t* __restrict__ y, long total, int H, int W, int OH, int OW,
+                                                       float sh, float sw) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // one thread per output element
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const long r = idx / OW;
+    const int oy = (int)(r % OH);
+    const long plane = r / OH;                                 // b * C + c
+    const float sy = fmaxf(sh * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(sw * (ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - y0, lx = sx - x0;
+    const long base = plane * H * W;
+    const float v00 = ld_elem<F32>(x, base + (long)y0 * W + x0), v01 = ld_elem<F32>(x, base + (long)y0 * W + x1);
+    const float v10 = ld_elem<F32>(x, base + (long)y1 * W + x0), v11 = ld_elem<F32>(x, base + (long)y1 * W + x1);
+    const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    y[idx] = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu);
+}
+
 inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 inline int launched(const char* what) {
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, what);
@@ -337,6 +358,19 @@ extern "C" int visrep_nchw_to_tokens(const void* x, int dtype, void* y, int B, i
         hipLaunchKernelGGL(nchw_to_tokens<false>, dim3(blocks_for(total)), dim3(256), 0, st, x, (bf16_t*)y, total, C, H * W, Cpad);
     else return visrep_set_error(VISREP_ERR_ARG, "nchw_to_tokens: dtype must be bf16 (0) or f32 (1)");
     return launched("nchw_to_tokens: launch failed");
+}
+
+extern "C" int visrep_resize_bilinear(const void* x, int dtype, void* y, int planes, int H, int W, int OH, int OW, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "resize_bilinear: empty problem");
+    const long total = (long)planes * OH * OW;
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VISREP_F32)
+        hipLaunchKernelGGL(resize_bilinear<true>, dim3(blocks_for(total)), dim3(256), 0, st, x, (bf16_t*)y, total, H, W, OH, OW, sh, sw);
+    else if (dtype == VISREP_BF16)
+        hipLaunchKernelGGL(resize_bilinear<false>, dim3(blocks_for(total)), dim3(256), 0, st, x, (bf16_t*)y, total, H, W, OH, OW, sh, sw);
+    else return visrep_set_error(VISREP_ERR_ARG, "resize_bilinear: dtype must be bf16 (0) or f32 (1)");
+    return launched("resize_bilinear: launch failed");
 }
 
 extern "C" int visrep_sd_noisy_latents(const float* moments, int ldm, const float* post_noise, const float* ddim_noise, void* y, int B,

@@ -2,8 +2,8 @@
 
 Same registry tables, constructor arguments (`args.{up_ft_index, t, prompt, vision_tower, ensemble_size, img_size}`),
 `DiffImageProcessor.preprocess` and `forward(images)` contract ([B, h*w, C] features).  The SD-UNet featurizer
-(SD1.5 / SD2.1) and the DiT featurizer run on the HIP path; the image-variation, SDXL and SD3 featurizers are not built and
-fail loudly.
+(SD1.5 / SD2.1), the image-variation featurizer and the DiT featurizer run on the HIP path; the SDXL and SD3 featurizers
+are not built and fail loudly.
 """
 from typing import Optional
 
@@ -12,16 +12,16 @@ import torch
 import torch.nn as nn
 
 from .src.models.dift_dit import DiTFeaturizer
+from .src.models.dift_imsd import IMSDFeaturizer
 from .src.models.dift_sd import SDFeaturizer
 
 
 def _not_built(name):
     def make(*a, **k):
-        raise NotImplementedError(f"{name} is not built on the MI355X path yet (SURVEY.md §8 a5: SD-UNet and DiT featurizers only)")
+        raise NotImplementedError(f"{name} is not built on the MI355X path yet (SURVEY.md §8 a5: SD-UNet, image-variation and DiT featurizers only)")
     return make
 
 
-IMSDFeaturizer = _not_built("IMSDFeaturizer (dift_imsd.py)")
 SD3Featurizer = _not_built("SD3Featurizer (dift_sd3.py)")
 
 build_featurelizer_mapping = {'lambdalabs/sd-image-variations-diffusers': IMSDFeaturizer,

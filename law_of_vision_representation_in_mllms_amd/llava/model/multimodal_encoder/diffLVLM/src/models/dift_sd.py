@@ -49,11 +49,11 @@ def _tuple(v, n):
     return tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
 
 
-def spec_from_checkpoint(name, root) -> tuple:
+def spec_from_checkpoint(name, root, need_text=True) -> tuple:
     u = _json(os.path.join(root, "unet", "config.json"))
     v = _json(os.path.join(root, "vae", "config.json"))
     s = _json(os.path.join(root, "scheduler", "scheduler_config.json"))
-    t = _json(os.path.join(root, "text_encoder", "config.json"))
+    t = _json(os.path.join(root, "text_encoder", "config.json")) if need_text else None
     nb = len(u["block_out_channels"])
     if u.get("addition_embed_type") or u.get("class_embed_type"):
         raise NotImplementedError("UNets with added-condition / class embeddings (SDXL) are not built on the MI355X path")
@@ -65,6 +65,8 @@ def spec_from_checkpoint(name, root) -> tuple:
                   latent_channels=v["latent_channels"], groups=v["norm_num_groups"], scaling_factor=v.get("scaling_factor", 0.18215))
     sched = SchedulerSpec(num_train_timesteps=s["num_train_timesteps"], beta_start=s["beta_start"], beta_end=s["beta_end"],
                           beta_schedule=s["beta_schedule"])
+    if t is None:
+        return SdSpec(name, unet, vae, sched, text_len=1), None
     text = TextSpec(vocab=t["vocab_size"], d=t["hidden_size"], mlp=t["intermediate_size"], layers=t["num_hidden_layers"],
                     heads=t["num_attention_heads"], max_pos=t["max_position_embeddings"], act=t.get("hidden_act", "quick_gelu"),
                     eps=t.get("layer_norm_eps", 1e-5))
@@ -133,12 +135,9 @@ class SDFeaturizer:
         B = img_tensor.shape[0]
         tokens = eng.forward(img_tensor, self.encode_prompt(prompt), t=t, ensemble_size=ensemble_size, post_noise=post_noise,
                              ddim_noise=ddim_noise)                                                   # [B, h*w, c]
-        h = int(round(tokens.shape[1] ** 0.5)) if img_tensor.shape[2] == img_tensor.shape[3] else None
-        if h is None:
-            f = 2 ** (len(self.spec.vae.block_out) - 1)
-            lh, lw = img_tensor.shape[2] // f, img_tensor.shape[3] // f
-            scale = (lh * lw / tokens.shape[1]) ** 0.5
-            h = int(round(lh / scale))
+        f = 2 ** (len(self.spec.vae.block_out) - 1)
+        lh, lw = img_tensor.shape[2] // f, img_tensor.shape[3] // f
+        h = int(round((tokens.shape[1] * lh / lw) ** 0.5))
         w = tokens.shape[1] // h
         unet_ft = tokens.view(B, 1, h, w, tokens.shape[2]).permute(0, 1, 4, 2, 3)                     # a view: no NCHW copy is made
         return unet_ft.squeeze()

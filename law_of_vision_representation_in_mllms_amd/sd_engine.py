@@ -142,6 +142,7 @@ class SdEngine:
         self._ctx = None
         self._ctx_version = 0
         self._prompt_src = None
+        self._dyn_ctx = None
         self.graph = graph
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
@@ -362,8 +363,13 @@ class SdEngine:
         gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
         n2 = layernorm(h, *P[f"{b}.norm2"], 1e-5)
         q = gemm(n2, P[f"{b}.attn2.q"].w)
-        ck, cvt = self._ctx[b]
-        a = attention(q, ck, cvt, hd, B, HW, self._ctx_len, heads, dp, scale, True)
+        if self._dyn_ctx is not None:                       # per-image context (image-variation tower): K / V^T per forward
+            ctx, L = self._dyn_ctx
+            ck, cvt = gemm(ctx, P[f"{b}.attn2.k"].w), linear_vt(ctx, P[f"{b}.attn2.v"].w, None)
+            a = attention(q, ck, cvt, hd, B, HW, L, heads, dp, scale, False)
+        else:
+            ck, cvt = self._ctx[b]
+            a = attention(q, ck, cvt, hd, B, HW, self._ctx_len, heads, dp, scale, True)
         o = P[f"{b}.attn2.o"]
         gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
         n3 = layernorm(h, *P[f"{b}.norm3"], 1e-5)
@@ -425,7 +431,7 @@ class SdEngine:
     # ---------------------------------------------------------------- UNet up to the captured up block
     def unet_features(self, lat: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
         """lat [B*H*W, 8] bf16 noisy latents (channels-last, zero padded) -> up_ft[up_ft_index] as [B, h*w, c] bf16."""
-        if self._t is None or self._ctx is None:
+        if self._t is None or (self._ctx is None and self._dyn_ctx is None):
             raise RuntimeError("set_timestep() and set_prompt() must be called before the UNet runs")
         u = self.spec.unet
         g, eps = u.groups, u.eps
@@ -458,8 +464,9 @@ class SdEngine:
         return h.view(B, H * W, h.shape[1])
 
     # ---------------------------------------------------------------- SDFeaturizer.forward + DiffVisionTower.forward
-    def _forward_impl(self, x, post, ddim, t, B, ensemble_size):
+    def _forward_impl(self, x, post, ddim, t, B, ensemble_size, ctx=None):
         lib = _lib.require_gpu()
+        self._dyn_ctx = None if ctx is None else (ctx.view(-1, ctx.shape[-1]), ctx.shape[1])
         sp = self.spec
         Be = B * ensemble_size
         moments, h, w = self.vae_moments(x)
@@ -475,8 +482,12 @@ class SdEngine:
 
     @torch.no_grad()
     def forward(self, img: torch.Tensor, prompt_embeds: Optional[torch.Tensor] = None, t: int = 1, ensemble_size: int = 1,
-                post_noise: Optional[torch.Tensor] = None, ddim_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                post_noise: Optional[torch.Tensor] = None, ddim_noise: Optional[torch.Tensor] = None,
+                image_context: Optional[torch.Tensor] = None) -> torch.Tensor:
         """img [B,3,H,W] in [-1,1] -> [B, h*w, c] bf16 features of up block `up_ft_index`.
+
+        image_context [B*ensemble, L, cross_dim]: a DIFFERENT cross-attention context per image instead of one shared
+        prompt (the image-variation featurizer feeds each image's CLIP embedding, dift_imsd.py:217-225).
 
         post_noise / ddim_noise [B*ensemble, Z, H/f, W/f] fp32: the reference's two randn draws (dift_sd.py:172,175);
         drawn with torch.randn on the device when omitted.
@@ -488,7 +499,7 @@ class SdEngine:
             self.set_prompt(prompt_embeds)
             self._prompt_src = prompt_embeds
         self.set_timestep(t)
-        if self._ctx is None:
+        if self._ctx is None and image_context is None:
             raise RuntimeError("set_timestep() and set_prompt() must be called before the UNet runs")
         B = img.shape[0]
         x = img.to(self.device)
@@ -502,21 +513,28 @@ class SdEngine:
         ddim = torch.randn(shape, device=self.device) if ddim_noise is None else ddim_noise.to(self.device, torch.float32).contiguous()
         if tuple(post.shape) != shape or tuple(ddim.shape) != shape:
             raise ValueError(f"noise tensors must have shape {shape}")
+        ctx = None
+        if image_context is not None:
+            ctx = image_context.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            if ctx.dim() != 3 or ctx.shape[0] != Be or ctx.shape[2] != sp.unet.cross_dim:
+                raise ValueError(f"image_context must be [{Be}, L, {sp.unet.cross_dim}]")
         if not self.graph:
-            return self._forward_impl(x, post, ddim, t, B, ensemble_size)
-        key = (tuple(x.shape), x.dtype, int(t), ensemble_size, self._ctx_version)
+            return self._forward_impl(x, post, ddim, t, B, ensemble_size, ctx)
+        key = (tuple(x.shape), x.dtype, int(t), ensemble_size, self._ctx_version if ctx is None else ("image", ctx.shape[1]))
         ent = self._graphs.get(key)
         if ent is None:
-            self._forward_impl(x, post, ddim, t, B, ensemble_size)                  # eager warm-up: lazy inits happen outside capture
-            sx, sp_, sd_ = x.clone(), post.clone(), ddim.clone()
+            self._forward_impl(x, post, ddim, t, B, ensemble_size, ctx)             # eager warm-up: lazy inits happen outside capture
+            sx, sp_, sd_, sc_ = x.clone(), post.clone(), ddim.clone(), None if ctx is None else ctx.clone()
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g):
-                out = self._forward_impl(sx, sp_, sd_, t, B, ensemble_size)
+                out = self._forward_impl(sx, sp_, sd_, t, B, ensemble_size, sc_)
             if len(self._graphs) >= 4:                                              # bound the memory pinned by captured pools
                 self._graphs.pop(next(iter(self._graphs)))
-            ent = self._graphs[key] = (g, sx, sp_, sd_, out)
-        g, sx, sp_, sd_, out = ent
+            ent = self._graphs[key] = (g, sx, sp_, sd_, sc_, out)
+        g, sx, sp_, sd_, sc_, out = ent
         sx.copy_(x); sp_.copy_(post); sd_.copy_(ddim)
+        if sc_ is not None:
+            sc_.copy_(ctx)
         g.replay()
         return out.clone()

@@ -177,3 +177,20 @@ def sd_features(spec, w_unet, w_vae, img, prompt_embeds, post_noise, ddim_noise,
     _, c, h, wd = ft.shape
     ft = ft.view(B, ensemble_size, c, h, wd).mean(1)
     return ft.permute(0, 2, 3, 1).reshape(B, h * wd, c).float()
+
+
+def imsd_features(spec, w_unet, w_vae, img, image_embeds, post_noise, ddim_noise, t=1, up_ft_index=0, ensemble_size=1,
+                  dtype=torch.float32):
+    """IMSDFeaturizer.forward (dift_imsd.py:199-229): as sd_features, but the cross-attention context is each image's own
+    CLIP image embedding [B, 1, cross_dim] (computed by oracle/vit.py clip_image_embeds on the bilinearly resized image)."""
+    cast = lambda d: {k: x.to(dtype) for k, x in d.items()}
+    w_unet, w_vae = cast(w_unet), cast(w_vae)
+    B = img.shape[0]
+    x = img.repeat_interleave(ensemble_size, dim=0).to(dtype)
+    mean, logvar = vae_encode_moments(spec.vae, w_vae, x)
+    lat = noisy_latents(spec, mean, logvar, post_noise.to(dtype), ddim_noise.to(dtype), t)
+    ctx = image_embeds.to(dtype).repeat_interleave(ensemble_size, dim=0)
+    ft = unet_up_features(spec.unet, w_unet, lat, t, ctx, (up_ft_index,))[up_ft_index]
+    _, c, h, wd = ft.shape
+    ft = ft.view(B, ensemble_size, c, h, wd).mean(1)
+    return ft.permute(0, 2, 3, 1).reshape(B, h * wd, c).float()

@@ -103,3 +103,13 @@ def tower_features(spec, w, pixels, select_layer=-2, select_feature="patch", dty
     elif select_feature != "cls_patch":
         raise ValueError(f"Unexpected select feature: {select_feature}")
     return f
+
+
+def clip_image_embeds(spec, w, post_ln_g, post_ln_b, projection, pixels, dtype=torch.float32):
+    """HF CLIPVisionModelWithProjection(pixels).image_embeds (modeling_clip.py CLIPVisionTransformer.forward pooled_output
+    = post_layernorm(last_hidden_state[:, 0]); then visual_projection, no bias) - the image-variation pipeline's
+    `_encode_image` (vendored pipeline_stable_diffusion_image_variation.py:133-141)."""
+    hs = vit_hidden_states(spec, w, pixels, dtype=dtype)
+    cls = hs[-1][:, 0].to(dtype)
+    n = torch.nn.functional.layer_norm(cls, (spec.d,), post_ln_g.to(dtype), post_ln_b.to(dtype), spec.eps)
+    return n @ projection.to(dtype).t()

@@ -564,6 +564,77 @@ def gen_sd():
     np.savez_compressed(f"{HERE}/sd_tiny.npz", **out)
 
 
+# ----------------------------------------------------------------------------- image-variation feature tower
+IMSD_CASE = dict(up=0, ens=2, t=261, B=2, side=64, seed=51)
+
+
+def imsd_image_encoder_spec():
+    from law_of_vision_representation_in_mllms_amd import vit_weights as VW
+    return VW.tiny_spec("clip", image_size=224, patch=56, d=128, layers=2, heads=2, mlp=256)
+
+
+def gen_imsd():
+    """Reference `IMSDFeaturizer.forward` (dift_imsd.py:199-229) restated over its own pieces: its MyUNet2DConditionModel,
+    F.interpolate(size=(224,224), mode='bilinear'), HF CLIPVisionModelWithProjection(...).image_embeds.unsqueeze(1)
+    (vendored pipeline `_encode_image`), vendored AutoencoderKL / DDIMScheduler; tiny configs, randn draws injected."""
+    sys.path.insert(0, f"{REF}/diffusers/src")
+    import diffusers
+    import torch.nn.functional as F
+    from diffusers import DDIMScheduler
+    from diffusers.models.autoencoders.autoencoder_kl import AutoencoderKL
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    diffusers.StableDiffusionImageVariationPipeline = object
+    spec = importlib.util.spec_from_file_location("ref_dift_imsd", f"{REF}/llava/model/multimodal_encoder/diffLVLM/src/models/dift_imsd.py")
+    dift = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dift)
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM.src.models.dift_imsd import synthetic_image_encoder
+    c = IMSD_CASE
+    sp = SW.tiny_sd_spec()
+    u, v = sp.unet, sp.vae
+    unet = dift.MyUNet2DConditionModel(sample_size=8, in_channels=u.in_channels, out_channels=4, block_out_channels=u.block_out,
+                                       layers_per_block=u.layers_per_block, down_block_types=u.down_types, up_block_types=u.up_types,
+                                       cross_attention_dim=u.cross_dim, attention_head_dim=u.heads, norm_num_groups=u.groups).eval()
+    r = unet.load_state_dict(SW.synthetic_unet(u, c["seed"], n_up_blocks=c["up"] + 1), strict=False)
+    assert not r.unexpected_keys
+    n = len(v.block_out)
+    vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * n, up_block_types=("UpDecoderBlock2D",) * n,
+                        block_out_channels=v.block_out, layers_per_block=v.layers_per_block, latent_channels=v.latent_channels,
+                        norm_num_groups=v.groups).eval()
+    assert not vae.load_state_dict(SW.synthetic_vae(v, c["seed"] + 100), strict=False).unexpected_keys
+    vs = imsd_image_encoder_spec()
+    cfg = CLIPVisionConfig(hidden_size=vs.d, intermediate_size=vs.mlp, num_hidden_layers=vs.layers, num_attention_heads=vs.heads,
+                           image_size=vs.image_size, patch_size=vs.patch, hidden_act=vs.act, layer_norm_eps=vs.eps, projection_dim=u.cross_dim)
+    enc = CLIPVisionModelWithProjection(cfg).eval()
+    w, g, b, p = synthetic_image_encoder(vs, u.cross_dim, c["seed"] + 300)
+    sd = _hf_state_from_packed(vs, w, enc.state_dict())
+    pre = "vision_model." if any(k.startswith("vision_model.") for k in sd) else ""
+    sd[pre + "post_layernorm.weight"], sd[pre + "post_layernorm.bias"], sd["visual_projection.weight"] = g, b, p
+    enc.load_state_dict(sd)
+    sched = DDIMScheduler(beta_start=sp.sched.beta_start, beta_end=sp.sched.beta_end, beta_schedule=sp.sched.beta_schedule,
+                          num_train_timesteps=sp.sched.num_train_timesteps)
+    rs = np.random.RandomState(c["seed"] + 200)
+    B, ens, side = c["B"], c["ens"], c["side"]
+    img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32))
+    ls = side // 2 ** (n - 1)
+    post = torch.from_numpy(rs.standard_normal((B * ens, v.latent_channels, ls, ls)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((B * ens, v.latent_channels, ls, ls)).astype(np.float32))
+    x = img.repeat_interleave(ens, dim=0).float()                                             # dift_imsd.py:212-213
+    prompt = F.interpolate(x, size=(224, 224), mode="bilinear")                              # :215
+    embeds = enc(prompt).image_embeds.unsqueeze(1)                                            # pipeline _encode_image
+    dist = vae.encode(x).latent_dist
+    latents = (dist.mean + dist.std * post) * vae.config.scaling_factor
+    tt = torch.tensor(c["t"], dtype=torch.long)
+    noisy = sched.add_noise(latents, ddim, tt)
+    ft = unet(noisy, timestep=tt, up_ft_indices=[c["up"]], encoder_hidden_states=embeds)["up_ft"][c["up"]]
+    _, ch, h, w_ = ft.shape
+    ft = ft.view(B, ens, -1, h, w_).mean(1, keepdim=True).squeeze(1)
+    feats = ft.permute(0, 2, 3, 1).reshape(B, h * w_, ch)
+    np.savez_compressed(f"{HERE}/imsd_tiny.npz", img=img.numpy(), post_noise=post.numpy(), ddim_noise=ddim.numpy(),
+                        image_embeds=embeds[::ens, 0].numpy(), features=feats.numpy())
+    print("imsd features", tuple(feats.shape), "rms", float(feats.pow(2).mean().sqrt()), "embeds rms", float(embeds.pow(2).mean().sqrt()))
+
+
 # ----------------------------------------------------------------------------- DiT feature tower
 def gen_dit():
     """Reference `MyDiTTransformer2DModel` + `replace_combined_timestep_label_embeddings` (dift_dit.py:9-124,146-156) over the
@@ -678,7 +749,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd}[w]()

@@ -200,3 +200,27 @@ def test_dit_oracle_matches_reference(tag):
     got = ODT.dit_features(sp, wd, wv, inp["img"], inp["post_noise"], inp["ddim_noise"], t=inp["t"], up_ft_index=inp["up_ft_index"])
     assert got.shape == want.shape
     torch.testing.assert_close(got, want, rtol=1e-3, atol=3e-4)
+
+
+# ------------------------------------------------------------------------------------------------ image-variation tower
+def load_imsd_case():
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW, vit_weights as VW
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM.src.models.dift_imsd import synthetic_image_encoder
+    z = np.load(os.path.join(G, "imsd_tiny.npz"))
+    sp = SW.tiny_sd_spec()
+    vs = VW.tiny_spec("clip", image_size=224, patch=56, d=128, layers=2, heads=2, mlp=256)
+    enc = synthetic_image_encoder(vs, sp.unet.cross_dim, 51 + 300)
+    inp = {k: torch.from_numpy(z[k]) for k in ("img", "post_noise", "ddim_noise", "image_embeds")}
+    inp.update(t=261, up_ft_index=0, ensemble_size=2)
+    return sp, SW.synthetic_unet(sp.unet, 51, 1), SW.synthetic_vae(sp.vae, 151), vs, enc, inp, torch.from_numpy(z["features"])
+
+
+def test_imsd_oracle_matches_reference():
+    import torch.nn.functional as F
+    from oracle import diffusion as OD
+    sp, wu, wv, vs, (w, g, b, p), inp, want = load_imsd_case()
+    px = F.interpolate(inp["img"], size=(224, 224), mode="bilinear")
+    emb = OV.clip_image_embeds(vs, w, g, b, p, px)
+    torch.testing.assert_close(emb, inp["image_embeds"], rtol=1e-4, atol=1e-4)
+    got = OD.imsd_features(sp, wu, wv, inp["img"], emb.unsqueeze(1), inp["post_noise"], inp["ddim_noise"], t=261, up_ft_index=0, ensemble_size=2)
+    torch.testing.assert_close(got, want, rtol=1e-3, atol=3e-4)
