@@ -214,31 +214,32 @@ class SdEngine:
         out[:, :, :dh] = w2d.reshape(n, heads, dh)
         return out.reshape(n, heads * dp)
 
-    def _pack_transformer(self, w, p, heads):
+    def _pack_transformer(self, w, p, heads, depth=1):
         P = self.P
         d = w[f"{p}.norm.weight"].shape[0]
         dh = d // heads
         dp = _ru(dh, 64)
         if dp > 192:
             raise ValueError(f"attention head width {dh} exceeds the kernel's 192")
-        P[f"{p}.meta"] = (heads, dh, dp)
+        P[f"{p}.meta"] = (heads, dh, dp, depth)
         P[f"{p}.norm"] = self._norm(w, f"{p}.norm")
         for n in ("proj_in", "proj_out"):
             pw = w[f"{p}.{n}.weight"]
             P[f"{p}.{n}"] = self._lin(pw.reshape(pw.shape[0], -1), w[f"{p}.{n}.bias"])
-        b = f"{p}.transformer_blocks.0"
-        for n in ("norm1", "norm2", "norm3"):
-            P[f"{b}.{n}"] = self._norm(w, f"{b}.{n}")
         pad_o = lambda name: self._pad_heads_out(w[name], heads, dp)
-        P[f"{b}.attn1.qk"] = self._lin(torch.cat([pad_o(f"{b}.attn1.to_q.weight"), pad_o(f"{b}.attn1.to_k.weight")], 0), None)
-        P[f"{b}.attn1.v"] = self._lin(pad_o(f"{b}.attn1.to_v.weight"), None)
-        P[f"{b}.attn1.o"] = self._lin(self._pad_heads_in(w[f"{b}.attn1.to_out.0.weight"], heads, dp), w[f"{b}.attn1.to_out.0.bias"])
-        P[f"{b}.attn2.q"] = self._lin(pad_o(f"{b}.attn2.to_q.weight"), None)
-        P[f"{b}.attn2.k"] = self._lin(pad_o(f"{b}.attn2.to_k.weight"), None)
-        P[f"{b}.attn2.v"] = self._lin(pad_o(f"{b}.attn2.to_v.weight"), None)
-        P[f"{b}.attn2.o"] = self._lin(self._pad_heads_in(w[f"{b}.attn2.to_out.0.weight"], heads, dp), w[f"{b}.attn2.to_out.0.bias"])
-        P[f"{b}.ff1"] = self._lin(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"])
-        P[f"{b}.ff2"] = self._lin(w[f"{b}.ff.net.2.weight"], w[f"{b}.ff.net.2.bias"])
+        for k in range(depth):
+            b = f"{p}.transformer_blocks.{k}"
+            for n in ("norm1", "norm2", "norm3"):
+                P[f"{b}.{n}"] = self._norm(w, f"{b}.{n}")
+            P[f"{b}.attn1.qk"] = self._lin(torch.cat([pad_o(f"{b}.attn1.to_q.weight"), pad_o(f"{b}.attn1.to_k.weight")], 0), None)
+            P[f"{b}.attn1.v"] = self._lin(pad_o(f"{b}.attn1.to_v.weight"), None)
+            P[f"{b}.attn1.o"] = self._lin(self._pad_heads_in(w[f"{b}.attn1.to_out.0.weight"], heads, dp), w[f"{b}.attn1.to_out.0.bias"])
+            P[f"{b}.attn2.q"] = self._lin(pad_o(f"{b}.attn2.to_q.weight"), None)
+            P[f"{b}.attn2.k"] = self._lin(pad_o(f"{b}.attn2.to_k.weight"), None)
+            P[f"{b}.attn2.v"] = self._lin(pad_o(f"{b}.attn2.to_v.weight"), None)
+            P[f"{b}.attn2.o"] = self._lin(self._pad_heads_in(w[f"{b}.attn2.to_out.0.weight"], heads, dp), w[f"{b}.attn2.to_out.0.bias"])
+            P[f"{b}.ff1"] = self._lin(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"])
+            P[f"{b}.ff2"] = self._lin(w[f"{b}.ff.net.2.weight"], w[f"{b}.ff.net.2.bias"])
 
     def _pack_vae(self):
         v, w = self.spec.vae, self.wv
@@ -273,12 +274,12 @@ class SdEngine:
             for j in range(u.layers_per_block):
                 self._pack_resnet(w, f"down_blocks.{i}.resnets.{j}")
                 if u.down_types[i].startswith("CrossAttn"):
-                    self._pack_transformer(w, f"down_blocks.{i}.attentions.{j}", u.heads[i])
+                    self._pack_transformer(w, f"down_blocks.{i}.attentions.{j}", u.heads[i], u.depth(i))
             if i != len(u.block_out) - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 self.P[p] = self._conv3(w[f"{p}.weight"], w[f"{p}.bias"])
         self._pack_resnet(w, "mid_block.resnets.0")
-        self._pack_transformer(w, "mid_block.attentions.0", u.heads[-1])
+        self._pack_transformer(w, "mid_block.attentions.0", u.heads[-1], u.depth(len(u.block_out) - 1))
         self._pack_resnet(w, "mid_block.resnets.1")
         rev_heads = tuple(reversed(u.heads))
         for i in range(self.up_ft_index + 1):
@@ -286,7 +287,7 @@ class SdEngine:
             for j in range(len(cins)):
                 self._pack_resnet(w, f"up_blocks.{i}.resnets.{j}")
                 if attn:
-                    self._pack_transformer(w, f"up_blocks.{i}.attentions.{j}", rev_heads[i])
+                    self._pack_transformer(w, f"up_blocks.{i}.attentions.{j}", rev_heads[i], u.depth(len(u.block_out) - 1 - i))
             if ups:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 self.P[p] = self._conv3(w[f"{p}.weight"], w[f"{p}.bias"])
@@ -347,35 +348,36 @@ class SdEngine:
 
     def _transformer(self, x, B, HW, p, groups):
         P = self.P
-        heads, dh, dp = P[f"{p}.meta"]
+        heads, dh, dp, depth = P[f"{p}.meta"]
         hd = heads * dp
         gn, bn = P[f"{p}.norm"]
         h = groupnorm(x, gn, bn, B, groups, 1e-6, False)
         pi = P[f"{p}.proj_in"]
         h = gemm(h, pi.w, pi.b)
-        b = f"{p}.transformer_blocks.0"
         scale = dh ** -0.5
-        n1 = layernorm(h, *P[f"{b}.norm1"], 1e-5)
-        qk = gemm(n1, P[f"{b}.attn1.qk"].w)
-        vt = linear_vt(n1, P[f"{b}.attn1.v"].w, None)
-        a = attention(qk[:, :hd], qk[:, hd:], vt, hd, B, HW, HW, heads, dp, scale, False)
-        o = P[f"{b}.attn1.o"]
-        gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
-        n2 = layernorm(h, *P[f"{b}.norm2"], 1e-5)
-        q = gemm(n2, P[f"{b}.attn2.q"].w)
-        if self._dyn_ctx is not None:                       # per-image context (image-variation tower): K / V^T per forward
-            ctx, L = self._dyn_ctx
-            ck, cvt = gemm(ctx, P[f"{b}.attn2.k"].w), linear_vt(ctx, P[f"{b}.attn2.v"].w, None)
-            a = attention(q, ck, cvt, hd, B, HW, L, heads, dp, scale, False)
-        else:
-            ck, cvt = self._ctx[b]
-            a = attention(q, ck, cvt, hd, B, HW, self._ctx_len, heads, dp, scale, True)
-        o = P[f"{b}.attn2.o"]
-        gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
-        n3 = layernorm(h, *P[f"{b}.norm3"], 1e-5)
-        f1, f2 = P[f"{b}.ff1"], P[f"{b}.ff2"]
-        g = geglu(gemm(n3, f1.w, f1.b))
-        gemm(g, f2.w, f2.b, _lib.EPI_RESID, resid=h, out=h)
+        for k in range(depth):
+            b = f"{p}.transformer_blocks.{k}"
+            n1 = layernorm(h, *P[f"{b}.norm1"], 1e-5)
+            qk = gemm(n1, P[f"{b}.attn1.qk"].w)
+            vt = linear_vt(n1, P[f"{b}.attn1.v"].w, None)
+            a = attention(qk[:, :hd], qk[:, hd:], vt, hd, B, HW, HW, heads, dp, scale, False)
+            o = P[f"{b}.attn1.o"]
+            gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
+            n2 = layernorm(h, *P[f"{b}.norm2"], 1e-5)
+            q = gemm(n2, P[f"{b}.attn2.q"].w)
+            if self._dyn_ctx is not None:                       # per-image context (image-variation tower): K / V^T per forward
+                ctx, L = self._dyn_ctx
+                ck, cvt = gemm(ctx, P[f"{b}.attn2.k"].w), linear_vt(ctx, P[f"{b}.attn2.v"].w, None)
+                a = attention(q, ck, cvt, hd, B, HW, L, heads, dp, scale, False)
+            else:
+                ck, cvt = self._ctx[b]
+                a = attention(q, ck, cvt, hd, B, HW, self._ctx_len, heads, dp, scale, True)
+            o = P[f"{b}.attn2.o"]
+            gemm(a, o.w, o.b, _lib.EPI_RESID, resid=h, out=h)
+            n3 = layernorm(h, *P[f"{b}.norm3"], 1e-5)
+            f1, f2 = P[f"{b}.ff1"], P[f"{b}.ff2"]
+            g = geglu(gemm(n3, f1.w, f1.b))
+            gemm(g, f2.w, f2.b, _lib.EPI_RESID, resid=h, out=h)
         po = P[f"{p}.proj_out"]
         return gemm(h, po.w, po.b, _lib.EPI_RESID, resid=x)
 

@@ -27,11 +27,16 @@ class UNetSpec:
     cross_dim: int = 768
     groups: int = 32
     eps: float = 1e-5
-    linear_projection: bool = False                # SD2.1: proj_in / proj_out are Linear
+    linear_projection: bool = False                # SD2.1 / SDXL: proj_in / proj_out are Linear
+    tlayers: Tuple[int, ...] = ()                  # transformer_layers_per_block (SDXL: 1, 2, 10); () = one everywhere
 
     @property
     def temb_dim(self):
         return 4 * self.block_out[0]
+
+    def depth(self, block: int) -> int:
+        """BasicTransformerBlocks per Transformer2DModel of down block `block` (up block i uses depth(n-1-i), mid depth(n-1))."""
+        return self.tlayers[block] if self.tlayers else 1
 
 
 @dataclass(frozen=True)
@@ -77,7 +82,25 @@ SD_SPECS: Dict[str, SdSpec] = {
     "stabilityai/stable-diffusion-2-1": SdSpec(
         "stabilityai/stable-diffusion-2-1",
         unet=UNetSpec(heads=(5, 10, 20, 20), cross_dim=1024, linear_projection=True)),
+    # SDXL base: 3 blocks, no attention at full resolution, 1 / 2 / 10 transformer layers, two text encoders (768 + 1280).
+    # The reference's UNet forward never calls `add_embedding` (dift_sd.py:70-88 has no aug-emb step), so the "text_time"
+    # added-condition branch of the checkpoint is dead weight on this path.
+    "stabilityai/stable-diffusion-xl-base-1.0": SdSpec(
+        "stabilityai/stable-diffusion-xl-base-1.0",
+        unet=UNetSpec(block_out=(320, 640, 1280), down_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                      up_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), heads=(5, 10, 20), cross_dim=2048,
+                      linear_projection=True, tlayers=(1, 2, 10)),
+        vae=VaeSpec(scaling_factor=0.13025)),
 }
+
+
+def tiny_sdxl_spec() -> SdSpec:
+    """SDXL topology in miniature: first block without attention, deeper transformers lower down, Linear projections."""
+    return SdSpec("tiny-sdxl",
+                  unet=UNetSpec(block_out=(64, 128, 128), down_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                                up_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), heads=(1, 2, 2), cross_dim=64,
+                                linear_projection=True, tlayers=(1, 2, 3)),
+                  vae=VaeSpec(block_out=(64, 64, 128), layers_per_block=1, scaling_factor=0.13025), text_len=11)
 
 
 def tiny_sd_spec(name="tiny-sd", linear_projection=False) -> SdSpec:
@@ -102,11 +125,16 @@ def _resnet(p, cin, cout, temb):
     return t
 
 
-def _transformer(p, d, cross, linear):
+def _transformer(p, d, cross, linear, depth=1):
     proj = (d, d) if linear else (d, d, 1, 1)
-    b = f"{p}.transformer_blocks.0"
-    return [(f"{p}.norm.weight", (d,)), (f"{p}.norm.bias", (d,)), (f"{p}.proj_in.weight", proj), (f"{p}.proj_in.bias", (d,)),
-            (f"{b}.norm1.weight", (d,)), (f"{b}.norm1.bias", (d,)),
+    t = [(f"{p}.norm.weight", (d,)), (f"{p}.norm.bias", (d,)), (f"{p}.proj_in.weight", proj), (f"{p}.proj_in.bias", (d,))]
+    for k in range(depth):
+        t += _basic_block(f"{p}.transformer_blocks.{k}", d, cross)
+    return t + [(f"{p}.proj_out.weight", proj), (f"{p}.proj_out.bias", (d,))]
+
+
+def _basic_block(b, d, cross):
+    return [(f"{b}.norm1.weight", (d,)), (f"{b}.norm1.bias", (d,)),
             (f"{b}.attn1.to_q.weight", (d, d)), (f"{b}.attn1.to_k.weight", (d, d)), (f"{b}.attn1.to_v.weight", (d, d)),
             (f"{b}.attn1.to_out.0.weight", (d, d)), (f"{b}.attn1.to_out.0.bias", (d,)),
             (f"{b}.norm2.weight", (d,)), (f"{b}.norm2.bias", (d,)),
@@ -114,8 +142,7 @@ def _transformer(p, d, cross, linear):
             (f"{b}.attn2.to_out.0.weight", (d, d)), (f"{b}.attn2.to_out.0.bias", (d,)),
             (f"{b}.norm3.weight", (d,)), (f"{b}.norm3.bias", (d,)),
             (f"{b}.ff.net.0.proj.weight", (8 * d, d)), (f"{b}.ff.net.0.proj.bias", (8 * d,)),
-            (f"{b}.ff.net.2.weight", (d, 4 * d)), (f"{b}.ff.net.2.bias", (d,)),
-            (f"{p}.proj_out.weight", proj), (f"{p}.proj_out.bias", (d,))]
+            (f"{b}.ff.net.2.weight", (d, 4 * d)), (f"{b}.ff.net.2.bias", (d,))]
 
 
 def up_block_plan(u: UNetSpec, i: int):
@@ -138,19 +165,20 @@ def unet_param_table(u: UNetSpec, n_up_blocks: int = 1) -> List[Tuple[str, tuple
         for j in range(u.layers_per_block):
             t += _resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, T)
             if u.down_types[i].startswith("CrossAttn"):
-                t += _transformer(f"down_blocks.{i}.attentions.{j}", cout, u.cross_dim, u.linear_projection)
+                t += _transformer(f"down_blocks.{i}.attentions.{j}", cout, u.cross_dim, u.linear_projection, u.depth(i))
         if i != len(u.block_out) - 1:
             t += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (cout, cout, 3, 3)), (f"down_blocks.{i}.downsamplers.0.conv.bias", (cout,))]
         cin = cout
     cm = u.block_out[-1]
-    t += _resnet("mid_block.resnets.0", cm, cm, T) + _transformer("mid_block.attentions.0", cm, u.cross_dim, u.linear_projection)
+    nb = len(u.block_out)
+    t += _resnet("mid_block.resnets.0", cm, cm, T) + _transformer("mid_block.attentions.0", cm, u.cross_dim, u.linear_projection, u.depth(nb - 1))
     t += _resnet("mid_block.resnets.1", cm, cm, T)
     for i in range(n_up_blocks):
         cins, out, attn, ups = up_block_plan(u, i)
         for j, ci in enumerate(cins):
             t += _resnet(f"up_blocks.{i}.resnets.{j}", ci, out, T)
             if attn:
-                t += _transformer(f"up_blocks.{i}.attentions.{j}", out, u.cross_dim, u.linear_projection)
+                t += _transformer(f"up_blocks.{i}.attentions.{j}", out, u.cross_dim, u.linear_projection, u.depth(nb - 1 - i))
         if ups:
             t += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (out, out, 3, 3)), (f"up_blocks.{i}.upsamplers.0.conv.bias", (out,))]
     return t

@@ -43,8 +43,9 @@ class ClipTextEngine:
         self.final = (vec(w["final_layer_norm.weight"]), vec(w["final_layer_norm.bias"]))
 
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
-        """input_ids [B, L] int64 -> last_hidden_state [B, L, d] bf16."""
+    def forward(self, input_ids: torch.Tensor, hidden_state=None) -> torch.Tensor:
+        """input_ids [B, L] int64 -> last_hidden_state [B, L, d] bf16; hidden_state=-2 -> HF `hidden_states[-2]` (second-to-
+        last layer's output, no final LayerNorm), which SDXL's encode_prompt concatenates from its two encoders."""
         s = self.spec
         B, L = input_ids.shape
         if L > s.max_pos:
@@ -52,7 +53,8 @@ class ClipTextEngine:
         ids = input_ids.to(self.device)
         h = (self.tok[ids] + self.pos[:L][None]).to(torch.bfloat16).reshape(B * L, s.d).contiguous()   # embedding gather
         d = s.d
-        for P in self.layers:
+        layers = self.layers if hidden_state is None else self.layers[: len(self.layers) + 1 + hidden_state]
+        for P in layers:
             n1 = layernorm(h, *P["ln1"], s.eps)
             qk = gemm(n1, P["wqk"], P["bqk"])
             vt = linear_vt(n1, P["wv"], P["bv"])
@@ -61,4 +63,6 @@ class ClipTextEngine:
             n2 = layernorm(h, *P["ln2"], s.eps)
             f = gemm(n2, P["w1"], P["b1"], _lib.EPI_ACT, act=s.act)
             gemm(f, P["w2"], P["b2"], _lib.EPI_RESID, resid=h, out=h)
+        if hidden_state is not None:
+            return h.view(B, L, d)
         return layernorm(h, *self.final, s.eps).view(B, L, d)

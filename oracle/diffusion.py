@@ -68,16 +68,8 @@ def attention(q, k, v, heads):
     return (torch.softmax(s, dim=-1) @ sp(v)).transpose(1, 2).reshape(B, Tq, d)
 
 
-def transformer_2d(x, ctx, w, p, heads, groups, linear):
-    # transformer_2d.py continuous-input path + attention.py BasicTransformerBlock (layer_norm, GEGLU feed-forward)
-    B, C, H, W = x.shape
-    res = x
-    h = _gn(x, w, f"{p}.norm", groups, 1e-6)
-    if linear:
-        h = _lin(h.permute(0, 2, 3, 1).reshape(B, H * W, C), w, f"{p}.proj_in")
-    else:
-        h = _conv(h, w, f"{p}.proj_in", padding=0).permute(0, 2, 3, 1).reshape(B, H * W, C)
-    b = f"{p}.transformer_blocks.0"
+def _basic_block(h, ctx, w, b, heads, C):
+    # attention.py BasicTransformerBlock (layer_norm, self-attn, cross-attn, GEGLU feed-forward)
     ln = lambda t, n: F.layer_norm(t, (C,), w[f"{b}.{n}.weight"], w[f"{b}.{n}.bias"], 1e-5)
     n1 = ln(h, "norm1")
     a = attention(_lin(n1, w, f"{b}.attn1.to_q", False), _lin(n1, w, f"{b}.attn1.to_k", False), _lin(n1, w, f"{b}.attn1.to_v", False), heads)
@@ -87,7 +79,20 @@ def transformer_2d(x, ctx, w, p, heads, groups, linear):
     h = h + _lin(a, w, f"{b}.attn2.to_out.0")
     n3 = ln(h, "norm3")
     val, gate = _lin(n3, w, f"{b}.ff.net.0.proj").chunk(2, dim=-1)          # activations.py GEGLU
-    h = h + _lin(val * F.gelu(gate), w, f"{b}.ff.net.2")
+    return h + _lin(val * F.gelu(gate), w, f"{b}.ff.net.2")
+
+
+def transformer_2d(x, ctx, w, p, heads, groups, linear, depth=1):
+    # transformer_2d.py continuous-input path + attention.py BasicTransformerBlock (layer_norm, GEGLU feed-forward)
+    B, C, H, W = x.shape
+    res = x
+    h = _gn(x, w, f"{p}.norm", groups, 1e-6)
+    if linear:
+        h = _lin(h.permute(0, 2, 3, 1).reshape(B, H * W, C), w, f"{p}.proj_in")
+    else:
+        h = _conv(h, w, f"{p}.proj_in", padding=0).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    for k in range(depth):                                                 # transformer_layers_per_block (SDXL: 1 / 2 / 10)
+        h = _basic_block(h, ctx, w, f"{p}.transformer_blocks.{k}", heads, C)
     if linear:
         h = _lin(h, w, f"{p}.proj_out").reshape(B, H, W, C).permute(0, 3, 1, 2)
     else:
@@ -107,13 +112,13 @@ def unet_up_features(u, w, sample, t, ctx, up_ft_indices=(0,)):
         for j in range(u.layers_per_block):
             h = resnet_block(h, temb, w, f"down_blocks.{i}.resnets.{j}", g, eps)
             if u.down_types[i].startswith("CrossAttn"):
-                h = transformer_2d(h, ctx, w, f"down_blocks.{i}.attentions.{j}", u.heads[i], g, u.linear_projection)
+                h = transformer_2d(h, ctx, w, f"down_blocks.{i}.attentions.{j}", u.heads[i], g, u.linear_projection, u.depth(i))
             skips.append(h)
         if i != len(u.block_out) - 1:
             h = _conv(h, w, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
             skips.append(h)
     h = resnet_block(h, temb, w, "mid_block.resnets.0", g, eps)
-    h = transformer_2d(h, ctx, w, "mid_block.attentions.0", u.heads[-1], g, u.linear_projection)
+    h = transformer_2d(h, ctx, w, "mid_block.attentions.0", u.heads[-1], g, u.linear_projection, u.depth(len(u.block_out) - 1))
     h = resnet_block(h, temb, w, "mid_block.resnets.1", g, eps)
     out = {}
     rev_heads = tuple(reversed(u.heads))
@@ -123,7 +128,7 @@ def unet_up_features(u, w, sample, t, ctx, up_ft_indices=(0,)):
             h = torch.cat([h, skips.pop()], dim=1)
             h = resnet_block(h, temb, w, f"up_blocks.{i}.resnets.{j}", g, eps)
             if u.up_types[i].startswith("CrossAttn"):
-                h = transformer_2d(h, ctx, w, f"up_blocks.{i}.attentions.{j}", rev_heads[i], g, u.linear_projection)
+                h = transformer_2d(h, ctx, w, f"up_blocks.{i}.attentions.{j}", rev_heads[i], g, u.linear_projection, u.depth(len(u.block_out) - 1 - i))
         if i != len(u.block_out) - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")       # upsampling.py Upsample2D
             h = _conv(h, w, f"up_blocks.{i}.upsamplers.0.conv")

@@ -20,14 +20,18 @@ def _act(x, kind):
     raise ValueError(kind)
 
 
-def clip_text_hidden(w, input_ids, heads, act="quick_gelu", eps=1e-5):
-    """input_ids [B, L] -> last_hidden_state [B, L, d] (after final_layer_norm)."""
+def clip_text_hidden(w, input_ids, heads, act="quick_gelu", eps=1e-5, hidden_state=None):
+    """input_ids [B, L] -> last_hidden_state [B, L, d] (after final_layer_norm); hidden_state=-2 -> HF
+    `output_hidden_states=True).hidden_states[-2]` (output of the second-to-last layer, no final LN): what SDXL's
+    encode_prompt takes from both of its text encoders (pipeline_stable_diffusion_xl.py encode_prompt)."""
     B, L = input_ids.shape
     h = w["embeddings.token_embedding.weight"][input_ids] + w["embeddings.position_embedding.weight"][:L][None]
     d = h.shape[-1]
     dh = d // heads
     mask = torch.full((L, L), float("-inf")).triu(1).to(h.dtype)
     n_layers = 1 + max(int(k.split(".")[2]) for k in w if k.startswith("encoder.layers."))
+    if hidden_state is not None:
+        n_layers = n_layers + 1 + hidden_state               # hidden_states[k] = input of layer k; [-2] skips the last layer
     for i in range(n_layers):
         p = f"encoder.layers.{i}"
         lin = lambda x, n: F.linear(x, w[f"{p}.{n}.weight"], w[f"{p}.{n}.bias"])
@@ -38,4 +42,6 @@ def clip_text_hidden(w, input_ids, heads, act="quick_gelu", eps=1e-5):
         h = h + lin(a.transpose(1, 2).reshape(B, L, d), "self_attn.out_proj")
         n2 = F.layer_norm(h, (d,), w[f"{p}.layer_norm2.weight"], w[f"{p}.layer_norm2.bias"], eps)
         h = h + lin(_act(lin(n2, "mlp.fc1"), act), "mlp.fc2")
+    if hidden_state is not None:
+        return h
     return F.layer_norm(h, (d,), w["final_layer_norm.weight"], w["final_layer_norm.bias"], eps)

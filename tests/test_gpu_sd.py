@@ -245,6 +245,8 @@ def test_clip_text_engine_matches_hf_golden(tag):
     ref_bf16 = OT.clip_text_hidden({k: bf(v) if v.is_floating_point() else v for k, v in w.items()}, ids, ts.heads, ts.act).float()
     e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
     assert got.shape == want.shape and e_hip < max(2.0 * e_ref, 1e-2), (e_hip, e_ref)
+    pen = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", "text_tiny.npz"))[f"{tag}.penultimate"])
+    assert rel_err(ClipTextEngine(ts, w, DEV).forward(ids, hidden_state=-2), pen) < max(2.0 * e_ref, 1e-2)     # SDXL's hidden_states[-2]
 
 
 # ------------------------------------------------------------------------------------------------ full-width SD1.5

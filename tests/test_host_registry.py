@@ -31,8 +31,7 @@ def test_unknown_tower_raises_like_the_reference():
         LA.VisionEncoderStack(SimpleNamespace(mm_vision_tower="nope", mm_vision_select_layer=-2, mm_projector_type="linear", hidden_size=128))
     # diffusion towers: the SD-UNet featurizer is built; the other featurizers fail loudly, never silently
     dargs = dict(up_ft_index=0, t=100, prompt="", ensemble_size=1, img_size=768)
-    for name in ('stabilityai/stable-diffusion-3-medium-diffusers',
-                 'stabilityai/stable-diffusion-xl-base-1.0'):
+    for name in ('stabilityai/stable-diffusion-3-medium-diffusers',):
         with pytest.raises(NotImplementedError):
             B.build_diffusion_vision_tower(SimpleNamespace(vision_tower=name, **dargs))
     with pytest.raises(KeyError):

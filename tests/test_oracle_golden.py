@@ -127,8 +127,9 @@ def test_vit_oracle_matches_hf_hip_shapes(tag):
 
 
 # ------------------------------------------------------------------------------------------------ SD feature tower
-SD_TAGS = ("conv_up0", "conv_up1_ens2", "linear_up0")
-_SD_CASES = {"conv_up0": (False, 0, 1, 100, 11), "conv_up1_ens2": (False, 1, 2, 261, 12), "linear_up0": (True, 0, 1, 1, 13)}
+SD_TAGS = ("conv_up0", "conv_up1_ens2", "linear_up0", "xl_up0")
+_SD_CASES = {"conv_up0": (False, 0, 1, 100, 11), "conv_up1_ens2": (False, 1, 2, 261, 12), "linear_up0": (True, 0, 1, 1, 13),
+             "xl_up0": ("xl", 0, 1, 261, 14)}
 
 
 def load_sd_case(tag):
@@ -136,7 +137,7 @@ def load_sd_case(tag):
     from law_of_vision_representation_in_mllms_amd import sd_weights as SW
     linear, idx, ens, t, seed = _SD_CASES[tag]
     z = np.load(os.path.join(G, "sd_tiny.npz"))
-    sp = SW.tiny_sd_spec(linear_projection=linear)
+    sp = SW.tiny_sdxl_spec() if linear == "xl" else SW.tiny_sd_spec(linear_projection=linear)
     wu, wv = SW.synthetic_unet(sp.unet, seed, n_up_blocks=idx + 1), SW.synthetic_vae(sp.vae, seed + 100)
     inp = {k: torch.from_numpy(z[f"{tag}.{k}"]) for k in ("img", "prompt_embeds", "post_noise", "ddim_noise", "noisy_latents", "mean", "logvar")}
     inp.update(t=t, up_ft_index=idx, ensemble_size=ens)
@@ -177,6 +178,8 @@ def test_text_oracle_matches_hf(tag):
     ts, w, ids, want = load_text_case(tag)
     got = OT.clip_text_hidden(w, ids, heads=ts.heads, act=ts.act)
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+    pen = torch.from_numpy(np.load(os.path.join(G, "text_tiny.npz"))[f"{tag}.penultimate"])
+    torch.testing.assert_close(OT.clip_text_hidden(w, ids, heads=ts.heads, act=ts.act, hidden_state=-2), pen, rtol=1e-4, atol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------------ DiT feature tower
