@@ -31,6 +31,10 @@ MODEL = "openai/clip-vit-large-patch14-336"
 BATCH = 256
 N_LAYERS = 23                     # select_layer = -2: the 24th layer is never needed
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# HBM bytes per fc1 launch at batch 256 with the default (v2) GEMM, from rocprofv3 PMC passes of this kernel at this shape
+# (profiles/round1_traffic.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
+# MI355X_MICROARCH.md "HBM", both calibrated on layernorm_rows' known byte count).  Algorithmic bytes are 1.52e9.
+FC1_HBM_BYTES_PER_LAUNCH = {(2, 256): 4.058e9}
 
 
 def flops_per_image(spec, n_layers):
@@ -148,7 +152,9 @@ def main():
         kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1)}
         top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
         roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
+                "traffic": FC1_HBM_BYTES_PER_LAUNCH.get((args.gemm_variant, B)), "traffic_unit": "HBM bytes per launch (PMC, profiles/round1_traffic.md)",
+                "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),
                 "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"],
                 "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),
                                   "frac": round(fl_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
