@@ -170,12 +170,15 @@ int visrep_nchw_to_tokens(const void* x, int dtype, void* y, int B, int C, int H
 int visrep_resize_bilinear(const void* x, int dtype, void* y, int planes, int H, int W, int OH, int OW, void* stream);
 
 /* dift_sd.py:172-176: latents = (mean + exp(0.5 * clamp(logvar, -30, 20)) * post_noise) * scaling_factor
- * (autoencoder_kl.py encode + vae.py DiagonalGaussianDistribution.sample), then DDIMScheduler.add_noise
- * (scheduling_ddim.py:471-495): sqrt(ac) * latents + sqrt(1 - ac) * ddim_noise.  moments: fp32 [B*HW, ldm] with the mean
- * in columns [0, Z) and the log-variance in [Z, 2Z) (quant_conv output); the two noise tensors are the reference's
- * randn draws made explicit, fp32 [B, Z, H, W]; y: [B*HW, Cpad] bf16, channels [Z, Cpad) zero. */
+ * (autoencoder_kl.py encode + vae.py DiagonalGaussianDistribution.sample), then the scheduler's add_noise as
+ * y = coef_latent * latents + coef_noise * ddim_noise:  DDIMScheduler (scheduling_ddim.py:471-495) has
+ * coef_latent = sqrt(alphas_cumprod[t]), coef_noise = sqrt(1 - alphas_cumprod[t]); the vendored
+ * FlowMatchEulerDiscreteScheduler.add_noise used by the SD3 featurizer (scheduling_flow_match_euler_discrete.py:192-210,
+ * dift_sd3.py:108-111) has coef_latent = t, coef_noise = 1 - t with the raw integer timestep.  moments: fp32 [B*HW, ldm] with
+ * the mean in columns [0, Z) and the log-variance in [Z, 2Z); the two noise tensors are the reference's randn draws made
+ * explicit, fp32 [B, Z, H, W]; y: [B*HW, Cpad] bf16, channels [Z, Cpad) zero. */
 int visrep_sd_noisy_latents(const float* moments, int ldm, const float* post_noise, const float* ddim_noise, void* y, int B, int Z,
-                            int HW, int Cpad, float scaling, float alpha_cumprod, void* stream);
+                            int HW, int Cpad, float scaling, float coef_latent, float coef_noise, void* stream);
 
 /* dift_sd.py:275 ensemble mean: x [B, E, N] bf16 -> y [B, N] bf16 (fp32 accumulation). */
 int visrep_mean_groups(const void* x, void* y, int B, int E, long N, void* stream);

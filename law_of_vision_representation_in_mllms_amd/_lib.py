@@ -51,7 +51,7 @@ SIGNATURES = {
     "visrep_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "visrep_nchw_to_tokens": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_resize_bilinear": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
-    "visrep_sd_noisy_latents": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "visrep_sd_noisy_latents": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "visrep_mean_groups": (_i, [_vp, _vp, _i, _i, _l, _vp]),
     "visrep_im2col": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_cls_rows": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),

@@ -374,12 +374,11 @@ extern "C" int visrep_resize_bilinear(const void* x, int dtype, void* y, int pla
 }
 
 extern "C" int visrep_sd_noisy_latents(const float* moments, int ldm, const float* post_noise, const float* ddim_noise, void* y, int B,
-                                       int Z, int HW, int Cpad, float scaling, float alpha_cumprod, void* stream) {
+                                       int Z, int HW, int Cpad, float scaling, float coef_latent, float coef_noise, void* stream) {
     if (B <= 0 || Z <= 0 || HW <= 0 || Cpad < Z || (Cpad & 1) || ldm < 2 * Z) return visrep_set_error(VISREP_ERR_SHAPE, "sd_noisy_latents: bad shape");
-    if (!(alpha_cumprod > 0.f && alpha_cumprod <= 1.f)) return visrep_set_error(VISREP_ERR_ARG, "sd_noisy_latents: alpha_cumprod out of (0, 1]");
     const long total = (long)B * HW;
     hipLaunchKernelGGL(sd_noisy_latents, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, moments, ldm, post_noise, ddim_noise,
-                       (bf16_t*)y, total, Z, HW, Cpad, scaling, sqrtf(alpha_cumprod), sqrtf(1.0f - alpha_cumprod));
+                       (bf16_t*)y, total, Z, HW, Cpad, scaling, coef_latent, coef_noise);
     return launched("sd_noisy_latents: launch failed");
 }
 

@@ -158,6 +158,11 @@ class SdEngine:
     def _pack_core(self):
         self._pack_unet()
 
+    def noise_coefficients(self, t):
+        """(coef_latent, coef_noise) of scheduler.add_noise: DDIM (scheduling_ddim.py:471-495)."""
+        ac = float(self._ac[int(t)])
+        return math.sqrt(ac), math.sqrt(1.0 - ac)
+
     def core_features(self, lat, B, H, W):
         return self.unet_features(lat, B, H, W)
 
@@ -260,12 +265,12 @@ class SdEngine:
         self.P[f"{a}.to_v"] = self._lin(w[f"{a}.to_v.weight"], None)
         self.P[f"{a}.to_v.bias"] = self._dev(w[f"{a}.to_v.bias"], torch.float32)
         self.P["encoder.conv_norm_out"] = self._norm(w, "encoder.conv_norm_out")
-        # quant_conv (1x1) o conv_out (3x3) is one 3x3 convolution: W' = Wq Wc, b' = Wq bc + bq
-        wq = w["quant_conv.weight"].reshape(w["quant_conv.weight"].shape[0], -1)
-        wc = w["encoder.conv_out.weight"]
-        wfold = torch.einsum("oz,zikl->oikl", wq, wc)
-        bfold = wq @ w["encoder.conv_out.bias"] + w["quant_conv.bias"]
-        self.P["vae.moments"] = self._conv3(wfold, bfold)
+        # quant_conv (1x1) o conv_out (3x3) is one 3x3 convolution: W' = Wq Wc, b' = Wq bc + bq  (SD3's VAE has no quant_conv)
+        wc, bc = w["encoder.conv_out.weight"], w["encoder.conv_out.bias"]
+        if "quant_conv.weight" in w:
+            wq = w["quant_conv.weight"].reshape(w["quant_conv.weight"].shape[0], -1)
+            wc, bc = torch.einsum("oz,zikl->oikl", wq, wc), wq @ bc + w["quant_conv.bias"]
+        self.P["vae.moments"] = self._conv3(wc, bc)
 
     def _pack_unet(self):
         u, w = self.spec.unet, self.wu
@@ -473,9 +478,11 @@ class SdEngine:
         Be = B * ensemble_size
         moments, h, w = self.vae_moments(x)
         Z = sp.vae.latent_channels
-        lat = torch.empty(Be * h * w, 8, dtype=torch.bfloat16, device=self.device)
+        cpad = _ru(Z, 8)
+        lat = torch.empty(Be * h * w, cpad, dtype=torch.bfloat16, device=self.device)
+        c_lat, c_noise = self.noise_coefficients(t)
         rc = lib.visrep_sd_noisy_latents(_lib.ptr(moments), moments.stride(0), _lib.ptr(post), _lib.ptr(ddim), _lib.ptr(lat), Be, Z,
-                                         h * w, 8, float(sp.vae.scaling_factor), float(self._ac[int(t)]), _lib.stream_ptr())
+                                         h * w, cpad, float(sp.vae.scaling_factor), c_lat, c_noise, _lib.stream_ptr())
         _lib.check(rc, "visrep_sd_noisy_latents")
         ft = self.core_features(lat, Be, h, w)
         if ensemble_size > 1:

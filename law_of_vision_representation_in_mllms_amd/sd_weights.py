@@ -48,6 +48,7 @@ class VaeSpec:
     latent_channels: int = 4
     groups: int = 32
     scaling_factor: float = 0.18215
+    quant_conv: bool = True                        # SD3's 16-channel VAE: use_quant_conv = False
 
 
 @dataclass(frozen=True)
@@ -204,8 +205,9 @@ def vae_param_table(v: VaeSpec) -> List[Tuple[str, tuple]]:
     t += _resnet("encoder.mid_block.resnets.1", cm, cm, 0)
     z = 2 * v.latent_channels
     t += [("encoder.conv_norm_out.weight", (cm,)), ("encoder.conv_norm_out.bias", (cm,)),
-          ("encoder.conv_out.weight", (z, cm, 3, 3)), ("encoder.conv_out.bias", (z,)),
-          ("quant_conv.weight", (z, z, 1, 1)), ("quant_conv.bias", (z,))]
+          ("encoder.conv_out.weight", (z, cm, 3, 3)), ("encoder.conv_out.bias", (z,))]
+    if v.quant_conv:
+        t += [("quant_conv.weight", (z, z, 1, 1)), ("quant_conv.bias", (z,))]
     return t
 
 
@@ -232,7 +234,7 @@ def synthetic_vae(v: VaeSpec, seed: int):
     w = _synthetic(vae_param_table(v), seed)
     # keep the posterior log-variance moderate so exp(0.5 * logvar) * noise stays O(1) like a trained VAE's
     z = v.latent_channels
-    w["quant_conv.bias"][z:] -= 2.0
+    w["quant_conv.bias" if v.quant_conv else "encoder.conv_out.bias"][z:] -= 2.0
     return w
 
 
@@ -331,5 +333,71 @@ def synthetic_dit(c: DiTCoreSpec, seed: int, n_layers: int = None):
     w = _synthetic(dit_param_table(c, n_layers), seed)
     for k in w:                       # adaLN modulation: O(0.3) shifts / scales / gates instead of O(1) so depth stays tame
         if k.endswith("norm1.linear.weight"):
+            w[k] *= 0.3
+    return w
+
+
+# ----------------------------------------------------------------------------------------------- SD3 (MMDiT)
+@dataclass(frozen=True)
+class Sd3CoreSpec:
+    """SD3Transformer2DModel config subset (transformer_sd3.py:57-70; SD3-medium: 24 layers, 24 heads x 64 = 1536)."""
+    heads: int = 24
+    head_dim: int = 64
+    in_channels: int = 16
+    layers: int = 24
+    sample_size: int = 128
+    patch: int = 2
+    joint_dim: int = 4096          # width of the prompt embeddings (CLIP-L|CLIP-G padded to 4096, T5 rows)
+    pooled_dim: int = 2048         # pooled CLIP-L (768) | CLIP-G (1280) text embeds
+    pos_max: int = 192             # pos_embed_max_size: side of the stored sincos table, centre-cropped per input
+
+    @property
+    def d(self):
+        return self.heads * self.head_dim
+
+
+@dataclass(frozen=True)
+class Sd3Spec:
+    name: str
+    core: Sd3CoreSpec = field(default_factory=Sd3CoreSpec)
+    vae: VaeSpec = field(default_factory=lambda: VaeSpec(latent_channels=16, scaling_factor=1.5305, quant_conv=False))
+    sched: SchedulerSpec = field(default_factory=SchedulerSpec)        # unused: flow-matching add_noise needs no table
+
+
+SD3_SPECS: Dict[str, Sd3Spec] = {"stabilityai/stable-diffusion-3-medium-diffusers": Sd3Spec("stabilityai/stable-diffusion-3-medium-diffusers")}
+
+
+def tiny_sd3_spec() -> Sd3Spec:
+    return Sd3Spec("tiny-sd3", core=Sd3CoreSpec(heads=2, head_dim=64, layers=3, sample_size=8, joint_dim=64, pooled_dim=64, pos_max=12),
+                   vae=VaeSpec(block_out=(64, 64, 128), layers_per_block=1, latent_channels=16, scaling_factor=1.5305, quant_conv=False))
+
+
+def sd3_param_table(c: Sd3CoreSpec, n_layers: int = None) -> List[Tuple[str, tuple]]:
+    D = c.d
+    t = [("pos_embed.proj.weight", (D, c.in_channels, c.patch, c.patch)), ("pos_embed.proj.bias", (D,)),
+         ("time_text_embed.timestep_embedder.linear_1.weight", (D, 256)), ("time_text_embed.timestep_embedder.linear_1.bias", (D,)),
+         ("time_text_embed.timestep_embedder.linear_2.weight", (D, D)), ("time_text_embed.timestep_embedder.linear_2.bias", (D,)),
+         ("time_text_embed.text_embedder.linear_1.weight", (D, c.pooled_dim)), ("time_text_embed.text_embedder.linear_1.bias", (D,)),
+         ("time_text_embed.text_embedder.linear_2.weight", (D, D)), ("time_text_embed.text_embedder.linear_2.bias", (D,)),
+         ("context_embedder.weight", (D, c.joint_dim)), ("context_embedder.bias", (D,))]
+    n = c.layers if n_layers is None else n_layers
+    for i in range(n):
+        p = f"transformer_blocks.{i}"
+        last = i == c.layers - 1                                   # context_pre_only
+        t += [(f"{p}.norm1.linear.weight", (6 * D, D)), (f"{p}.norm1.linear.bias", (6 * D,)),
+              (f"{p}.norm1_context.linear.weight", ((2 if last else 6) * D, D)), (f"{p}.norm1_context.linear.bias", ((2 if last else 6) * D,))]
+        names = ["to_q", "to_k", "to_v", "add_k_proj", "add_v_proj", "add_q_proj", "to_out.0"] + ([] if last else ["to_add_out"])
+        for nme in names:
+            t += [(f"{p}.attn.{nme}.weight", (D, D)), (f"{p}.attn.{nme}.bias", (D,))]
+        for ff in ["ff"] + ([] if last else ["ff_context"]):
+            t += [(f"{p}.{ff}.net.0.proj.weight", (4 * D, D)), (f"{p}.{ff}.net.0.proj.bias", (4 * D,)),
+                  (f"{p}.{ff}.net.2.weight", (D, 4 * D)), (f"{p}.{ff}.net.2.bias", (D,))]
+    return t
+
+
+def synthetic_sd3(c: Sd3CoreSpec, seed: int, n_layers: int = None):
+    w = _synthetic(sd3_param_table(c, n_layers), seed)
+    for k in w:
+        if k.endswith(("norm1.linear.weight", "norm1_context.linear.weight")):
             w[k] *= 0.3
     return w

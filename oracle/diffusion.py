@@ -155,7 +155,9 @@ def vae_encode_moments(v, w, img):
     h = h + _lin(o, w, f"{a}.to_out.0").transpose(1, 2).reshape(B, C, H, W)
     h = resnet_block(h, None, w, "encoder.mid_block.resnets.1", g, 1e-6)
     h = _conv(_gn(h, w, "encoder.conv_norm_out", g, 1e-6, silu=True), w, "encoder.conv_out")
-    mean, logvar = _conv(h, w, "quant_conv", padding=0).chunk(2, dim=1)
+    if "quant_conv.weight" in w:                                          # SD3's VAE: use_quant_conv = False
+        h = _conv(h, w, "quant_conv", padding=0)
+    mean, logvar = h.chunk(2, dim=1)
     return mean, logvar.clamp(-30.0, 20.0)                                # vae.py DiagonalGaussianDistribution
 
 

@@ -693,6 +693,62 @@ def gen_dit():
     np.savez_compressed(f"{HERE}/dit_tiny.npz", **out)
 
 
+# ----------------------------------------------------------------------------- SD3 (MMDiT) feature tower
+def gen_sd3():
+    """Reference `MySD3Transformer2DModell` (dift_sd3.py:10-91) over the vendored MMDiT blocks + vendored AutoencoderKL
+    (16 latent channels, no quant_conv) + the vendored FlowMatchEulerDiscreteScheduler.add_noise with the raw timestep, as
+    `OneStepDiTPipeline.__call__` (:104-119); then the unfold of `SD3Featurizer.forward` (:170-174)."""
+    sys.path.insert(0, f"{REF}/diffusers/src")
+    import diffusers
+    from diffusers.models.autoencoders.autoencoder_kl import AutoencoderKL
+    from diffusers.schedulers.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    diffusers.StableDiffusion3Pipeline = object
+    spec = importlib.util.spec_from_file_location("ref_dift_sd3", f"{REF}/llava/model/multimodal_encoder/diffLVLM/src/models/dift_sd3.py")
+    dift = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dift)
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    out = {"diffusers_version": np.array(diffusers.__version__)}
+    for tag, (idx, t, B, side, L, seed) in {"last": (-1, 3, 2, 64, 9, 61), "mid": (1, 1, 1, 32, 5, 62)}.items():
+        sp = SW.tiny_sd3_spec()
+        c, v = sp.core, sp.vae
+        tr = dift.MySD3Transformer2DModell(sample_size=c.sample_size, patch_size=c.patch, in_channels=c.in_channels, num_layers=c.layers,
+                                           attention_head_dim=c.head_dim, num_attention_heads=c.heads, joint_attention_dim=c.joint_dim,
+                                           caption_projection_dim=c.d, pooled_projection_dim=c.pooled_dim, out_channels=c.in_channels,
+                                           pos_embed_max_size=c.pos_max).eval()
+        wc = SW.synthetic_sd3(c, seed)
+        r = tr.load_state_dict(wc, strict=False)
+        assert not r.unexpected_keys and all(k.startswith(("proj_out", "norm_out", "pos_embed.pos_embed")) for k in r.missing_keys), r
+        n = len(v.block_out)
+        vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * n, up_block_types=("UpDecoderBlock2D",) * n,
+                            block_out_channels=v.block_out, layers_per_block=v.layers_per_block, latent_channels=v.latent_channels,
+                            norm_num_groups=v.groups, scaling_factor=v.scaling_factor, use_quant_conv=False, use_post_quant_conv=False).eval()
+        r = vae.load_state_dict(SW.synthetic_vae(v, seed + 100), strict=False)
+        assert not r.unexpected_keys and all(k.startswith("decoder") for k in r.missing_keys), r
+        sched = FlowMatchEulerDiscreteScheduler()
+        rs = np.random.RandomState(seed + 200)
+        img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32))
+        ls = side // 2 ** (n - 1)
+        post = torch.from_numpy(rs.standard_normal((B, v.latent_channels, ls, ls)).astype(np.float32))
+        noise = torch.from_numpy((0.05 * rs.standard_normal((B, v.latent_channels, ls, ls))).astype(np.float32))
+        pe = torch.from_numpy(rs.standard_normal((1, L, c.joint_dim)).astype(np.float32))
+        pooled = torch.from_numpy(rs.standard_normal((1, c.pooled_dim)).astype(np.float32))
+        dist = vae.encode(img).latent_dist
+        latents = (dist.mean + dist.std * post) * vae.config.scaling_factor
+        tt = torch.full((B,), t, dtype=torch.long)                                           # dift_sd3.py:109
+        noisy = sched.add_noise(latents, noise, tt)
+        ft = tr(noisy, pooled_projections=pooled.expand(B, -1), encoder_hidden_states=pe.expand(B, -1, -1), up_ft_indices=[idx],
+                timestep=tt, joint_attention_kwargs=None)["up_ft"][idx]
+        h = w_ = int(ft.shape[-2] ** 0.5)
+        ft = ft.transpose(2, 1).reshape(B, -1, h, w_)
+        ft = ft.unfold(3, 2, 2).unfold(2, 2, 2)
+        ft = ft.reshape(B, -1, h // 2, w_ // 2, 4).permute(0, 4, 1, 2, 3).reshape(B, -1, h // 2, w_ // 2)
+        feats = ft.permute(0, 2, 3, 1).reshape(B, (h // 2) * (w_ // 2), -1)
+        out.update({f"{tag}.img": img.numpy(), f"{tag}.post_noise": post.numpy(), f"{tag}.noise": noise.numpy(), f"{tag}.prompt_embeds": pe.numpy(),
+                    f"{tag}.pooled": pooled.numpy(), f"{tag}.noisy_latents": noisy.numpy(), f"{tag}.features": feats.numpy()})
+        print(tag, "features", tuple(feats.shape), "rms", float(feats.pow(2).mean().sqrt()), "noisy rms", float(noisy.pow(2).mean().sqrt()))
+    np.savez_compressed(f"{HERE}/sd3_tiny.npz", **out)
+
+
 # ----------------------------------------------------------------------------- CLIP text encoder (prompt embeddings)
 def gen_text():
     """HF CLIPTextModel (what pipe.encode_prompt runs, dift_sd.py:258-263), tiny random-init configs."""
@@ -754,7 +810,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3}[w]()

@@ -134,7 +134,7 @@ def test_nchw_to_tokens_and_noisy_latents():
     ac = float(sp.sched.alphas_cumprod()[261])
     mom_d, post_d, ddim_d = mom.to(DEV), post.to(DEV), ddim.to(DEV)        # keep the device copies alive across the raw-pointer call
     rc = _lib.load().visrep_sd_noisy_latents(_lib.ptr(mom_d), 64, _lib.ptr(post_d), _lib.ptr(ddim_d), _lib.ptr(lat), B, Z,
-                                              h * w, 8, sp.vae.scaling_factor, ac, _lib.stream_ptr())
+                                              h * w, 8, sp.vae.scaling_factor, math.sqrt(ac), math.sqrt(1 - ac), _lib.stream_ptr())
     assert rc == 0
     want = OD.noisy_latents(sp, mean, logvar.clamp(-30, 20), post, ddim, 261)
     got = lat.cpu().float()

@@ -227,3 +227,31 @@ def test_imsd_oracle_matches_reference():
     torch.testing.assert_close(emb, inp["image_embeds"], rtol=1e-4, atol=1e-4)
     got = OD.imsd_features(sp, wu, wv, inp["img"], emb.unsqueeze(1), inp["post_noise"], inp["ddim_noise"], t=261, up_ft_index=0, ensemble_size=2)
     torch.testing.assert_close(got, want, rtol=1e-3, atol=3e-4)
+
+
+# ------------------------------------------------------------------------------------------------ SD3 (MMDiT) feature tower
+SD3_TAGS = {"last": (-1, 3, 61), "mid": (1, 1, 62)}
+
+
+def load_sd3_case(tag):
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    idx, t, seed = SD3_TAGS[tag]
+    z = np.load(os.path.join(G, "sd3_tiny.npz"))
+    sp = SW.tiny_sd3_spec()
+    inp = {k: torch.from_numpy(z[f"{tag}.{k}"]) for k in ("img", "post_noise", "noise", "prompt_embeds", "pooled", "noisy_latents")}
+    inp.update(t=t, up_ft_index=idx)
+    return sp, SW.synthetic_sd3(sp.core, seed), SW.synthetic_vae(sp.vae, seed + 100), inp, torch.from_numpy(z[f"{tag}.features"])
+
+
+@pytest.mark.parametrize("tag", list(SD3_TAGS))
+def test_sd3_oracle_matches_reference(tag):
+    from oracle import diffusion as OD
+    from oracle import sd3 as O3
+    sp, wc, wv, inp, want = load_sd3_case(tag)
+    mean, logvar = OD.vae_encode_moments(sp.vae, wv, inp["img"])
+    noisy = O3.flow_noisy_latents(sp, mean, logvar, inp["post_noise"], inp["noise"], inp["t"])
+    torch.testing.assert_close(noisy, inp["noisy_latents"], rtol=1e-4, atol=1e-4)
+    got = O3.sd3_features(sp, wc, wv, inp["img"], inp["prompt_embeds"], inp["pooled"], inp["post_noise"], inp["noise"], t=inp["t"],
+                          up_ft_index=inp["up_ft_index"])
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-3, atol=5e-4)
