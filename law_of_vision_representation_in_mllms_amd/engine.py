@@ -123,17 +123,25 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
-def linear_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """V projection in the attention kernel's V^T layout: returns [N, ldvt] bf16 (see csrc/attention.hip)."""
+def linear_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+              col_offset: int = 0) -> torch.Tensor:
+    """V projection in the attention kernel's V^T layout: returns [N, ldvt] bf16 (see csrc/attention.hip).
+
+    out / col_offset: write the tokens of `a` as columns [col_offset, col_offset + M) of an existing (zero-initialised) V^T
+    buffer - how a joint key sequence is assembled from several token groups (SD3: image tokens, then prompt tokens);
+    col_offset must be a multiple of 16 (the perm16 granule)."""
     lib = _lib.require_gpu()
     M, K = a.shape
     N = w.shape[0]
-    ldvt = _round_up(M, 64) + 64
-    vt = torch.zeros(N, ldvt, dtype=torch.bfloat16, device=a.device)
-    rc = lib.visrep_gemm_bf16(_lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(vt), ldvt, M, N, K,
-                              _lib.EPI_VT, 0, None, None, _lib.stream_ptr())
+    if out is None:
+        ldvt = _round_up(M, 64) + 64
+        out = torch.zeros(N, ldvt, dtype=torch.bfloat16, device=a.device)
+    if col_offset % 16 or col_offset + M > out.shape[1]:
+        raise ValueError("linear_vt: col_offset must be a multiple of 16 and fit the buffer")
+    rc = lib.visrep_gemm_bf16(_lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), C.c_void_p(out.data_ptr() + 2 * col_offset),
+                              out.stride(0), M, N, K, _lib.EPI_VT, 0, None, None, _lib.stream_ptr())
     _lib.check(rc, "visrep_gemm_bf16(VT)")
-    return vt
+    return out
 
 
 def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:

@@ -2,8 +2,8 @@
 
 Same registry tables, constructor arguments (`args.{up_ft_index, t, prompt, vision_tower, ensemble_size, img_size}`),
 `DiffImageProcessor.preprocess` and `forward(images)` contract ([B, h*w, C] features).  The SD-UNet featurizer
-(SD1.5 / SD2.1), the image-variation featurizer and the DiT featurizer run on the HIP path; the SDXL and SD3 featurizers
-are not built and fail loudly.
+(SD1.5 / SD2.1 / SDXL), the image-variation featurizer, the DiT featurizer and the SD3 (MMDiT) featurizer all run on the HIP
+path.
 """
 from typing import Optional
 
@@ -14,15 +14,8 @@ import torch.nn as nn
 from .src.models.dift_dit import DiTFeaturizer
 from .src.models.dift_imsd import IMSDFeaturizer
 from .src.models.dift_sd import SDFeaturizer
+from .src.models.dift_sd3 import SD3Featurizer
 
-
-def _not_built(name):
-    def make(*a, **k):
-        raise NotImplementedError(f"{name} is not built on the MI355X path yet (SURVEY.md §8 a5: SD-UNet, image-variation and DiT featurizers only)")
-    return make
-
-
-SD3Featurizer = _not_built("SD3Featurizer (dift_sd3.py)")
 
 build_featurelizer_mapping = {'lambdalabs/sd-image-variations-diffusers': IMSDFeaturizer,
                               'stabilityai/stable-diffusion-2-1': SDFeaturizer,

@@ -373,3 +373,67 @@ def test_imsd_tower_matches_reference_golden(monkeypatch):
     assert e_hip < max(2.0 * e_ref, 2e-2), (e_hip, e_ref)
     again = feat.forward(inp["img"], "ignored", t=261, up_ft_index=0, ensemble_size=2, post_noise=inp["post_noise"], ddim_noise=inp["ddim_noise"])
     assert torch.equal(again, got)                                            # graph replay with the per-image context buffer
+
+
+# ------------------------------------------------------------------------------------------------ SD3 (MMDiT) tower
+@pytest.mark.parametrize("tag", ["last", "mid"])
+def test_sd3_tower_matches_reference_golden(tag):
+    from test_oracle_golden import load_sd3_case
+    from law_of_vision_representation_in_mllms_amd.sd3_engine import Sd3Engine
+    from oracle import sd3 as O3
+    sp, wc, wv, inp, want = load_sd3_case(tag)
+    eng = Sd3Engine(sp, wc, wv, DEV, up_ft_index=inp["up_ft_index"])
+    kw = dict(t=inp["t"], post_noise=inp["post_noise"], ddim_noise=inp["noise"], pooled=inp["pooled"])
+    pe = inp["prompt_embeds"]
+    got = eng.forward(inp["img"], pe, **kw)
+    ref_bf16 = O3.sd3_features(sp, wc, wv, inp["img"], pe, inp["pooled"], inp["post_noise"], inp["noise"], t=inp["t"],
+                               up_ft_index=inp["up_ft_index"], dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert got.shape == want.shape and e_hip < max(2.0 * e_ref, 2e-2), (tag, e_hip, e_ref)
+    assert torch.equal(eng.forward(inp["img"], pe, **kw), got)                       # graph replay, bit-reproducible
+    with pytest.raises(ValueError, match="ensemble"):
+        eng.forward(inp["img"], pe, ensemble_size=2, **kw)
+
+
+def test_sd3_medium_width_blocks_and_featurizer_prompt(monkeypatch):
+    """SD3-medium widths (24 heads x 64 = 1536, joint 4096, pooled 2048, 16-channel VAE) for the first 2 blocks on a 128-px
+    image against the fp32 CPU oracle; the featurizer's prompt assembly (CLIP-L | CLIP-G | T5 zeros) with tiny text encoders."""
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.sd3_engine import Sd3Engine
+    from law_of_vision_representation_in_mllms_amd.text_engine import ClipTextEngine
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM.src.models import dift_sd3 as D3
+    from oracle import sd3 as O3
+    from oracle import text as OT
+    sp = SW.SD3_SPECS["stabilityai/stable-diffusion-3-medium-diffusers"]
+    wc, wv = SW.synthetic_sd3(sp.core, 61, n_layers=2), SW.synthetic_vae(sp.vae, 62)
+    rs = np.random.RandomState(9)
+    img = torch.from_numpy(rs.uniform(-1, 1, (1, 3, 128, 128)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((1, 16, 16, 16)).astype(np.float32))
+    noise = torch.from_numpy((0.05 * rs.standard_normal((1, 16, 16, 16))).astype(np.float32))
+    pe = torch.from_numpy(rs.standard_normal((1, 77 + 256, 4096)).astype(np.float32))
+    pe[:, 77:] = 0
+    pooled = torch.from_numpy(rs.standard_normal((1, 2048)).astype(np.float32))
+    got = Sd3Engine(sp, wc, wv, DEV, up_ft_index=1).forward(img, pe, t=2, post_noise=post, ddim_noise=noise, pooled=pooled)
+    assert got.shape == (1, 16, 6144)
+    want = O3.sd3_features(sp, wc, wv, img, pe, pooled, post, noise, t=2, up_ft_index=1)
+    ref_bf16 = O3.sd3_features(sp, wc, wv, img, pe, pooled, post, noise, t=2, up_ft_index=1, dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert e_hip < max(2.0 * e_ref, 2e-2), (e_hip, e_ref)
+    # prompt assembly with two tiny text encoders in place of CLIP-L / CLIP-G
+    tspecs = (SW.tiny_text_spec("quick_gelu", 2, 77), SW.tiny_text_spec("gelu", 3, 77))
+    feat = D3.SD3Featurizer.__new__(D3.SD3Featurizer)
+    feat.device, feat.spec, feat.tokenizers, feat._prompt_cache = torch.device(DEV), sp, [None, None], {}
+    tw = [SW.synthetic_text(ts, 70 + i) for i, ts in enumerate(tspecs)]
+    feat.text = [ClipTextEngine(ts, w, DEV) for ts, w in zip(tspecs, tw)]
+    proj = [SW._synthetic([("text_projection.weight", (ts.d, ts.d))], 80 + i)["text_projection.weight"] for i, ts in enumerate(tspecs)]
+    feat.text_proj = [p.to(DEV, torch.bfloat16) for p in proj]
+    pe2, pooled2 = feat.encode_prompt("a photo of a cat")
+    assert pe2.shape == (1, 77 + 256, 4096) and pooled2.shape == (1, 256)
+    assert (pe2[:, 77:] == 0).all() and (pe2[:, :77, 256:] == 0).all()
+    for i, (ts, w) in enumerate(zip(tspecs, tw)):
+        ids = feat.tokenize("a photo of a cat", i)
+        pen = OT.clip_text_hidden(w, ids, ts.heads, ts.act, hidden_state=-2)
+        assert rel_err(pe2[:, :77, i * 128:(i + 1) * 128], pen) < 2e-2
+        last = OT.clip_text_hidden(w, ids, ts.heads, ts.act)
+        want_pool = last[0, int(ids[0].argmax())] @ proj[i].t()
+        assert rel_err(pooled2[0, i * 128:(i + 1) * 128], want_pool) < 2e-2
