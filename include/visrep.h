@@ -154,6 +154,14 @@ int visrep_groupnorm(const void* x, const float* gamma, const float* beta, void*
  * (upsampling.py Upsample2D: F.interpolate(scale_factor=2, mode="nearest") + conv) without materialising it. */
 int visrep_im2col3x3(const void* x, void* y, int B, int H, int W, int C, int stride, int pad_mode, int upsample, int ldy, void* stream);
 
+/* nn.Conv2d(kernel 3) as an IMPLICIT GEMM: the gather of visrep_im2col3x3 happens inside the GEMM's A-operand LDS-DMA
+ * (per-lane source addresses, zero page for padded taps), so the 9x-expanded patch matrix never exists in HBM.
+ * x: [B*H*W, C] bf16 channels-last, C % 64 == 0; Wt: [Cout (% 64 == 0), ldw >= 9*C] bf16 with K order (ky, kx, c);
+ * out: [B*Ho*Wo, ldc] (fp32 for VISREP_EPI_F32); stride / pad_mode / upsample as visrep_im2col3x3; epilogue BIAS, RESID
+ * (out = resid + conv + bias, resid [B*Ho*Wo, ldc]) or F32.  Few-tile problems use the split-K path when a scratch is set. */
+int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
+                        int stride, int pad_mode, int upsample, int epilogue, const void* resid, void* stream);
+
 /* activations.py GEGLU: y[m, f] = x[m, f] * gelu_erf(x[m, F + f]); x [M, >= 2F] bf16, y [M, >= F] bf16. */
 int visrep_geglu(const void* x, int ldx, void* y, int ldy, long M, int F, void* stream);
 

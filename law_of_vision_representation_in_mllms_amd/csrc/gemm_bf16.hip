@@ -25,7 +25,9 @@ constexpr int TILE_BYTES = BM * BK * 2;      // 16 KB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // double buffer = 64 KB
 
-template <int EPI>
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};   // source of padded (out-of-image) conv taps
+
+template <int EPI, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,21 +44,49 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     const int lslot = (tid & 7) ^ ((srow >> 1) & 7);          // logical slot this lane must fetch (swizzle on the source)
     const bf16_t* ga[4];
     const bf16_t* gw[4];
+    int iy0[4], ix0[4], pb[4];                                 // CONV: top-left tap coordinates and image pixel base per staged row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int ra = m0 + j * 32 + srow;
         ra = ra < p.M ? ra : p.M - 1;                          // clamp: rows past M are computed but never stored
-        ga[j] = p.A + (size_t)ra * p.lda + kbase + lslot * 8;
+        if (CONV) {
+            const int hw = p.cHo * p.cWo;
+            const int b = ra / hw, pix = ra - b * hw;
+            const int oy = pix / p.cWo, ox = pix - oy * p.cWo;
+            iy0[j] = oy * p.cstride - p.cpad;
+            ix0[j] = ox * p.cstride - p.cpad;
+            pb[j] = b * p.cH * p.cW;
+            ga[j] = p.A + lslot * 8;
+        } else {
+            ga[j] = p.A + (size_t)ra * p.lda + kbase + lslot * 8;
+        }
         int rw = n0 + j * 32 + srow;
         rw = rw < p.N ? rw : p.N - 1;
         gw[j] = p.W + (size_t)rw * p.ldw + kbase + lslot * 8;
     }
+    // CONV: running (tap, channel offset) of the next K-tile to stage; stage() is called for kt = 0, 1, 2, ... in order
+    int tap = 0, c0 = 0;
+    if (CONV) { tap = kbase / p.cC; c0 = kbase - tap * p.cC; }
+    const int Hl = p.cH << p.cup, Wl = p.cW << p.cup;          // logical (nearest-2x upsampled) source size
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE_BYTES + wave * 1024;
         char* sw = sa + TILE_BYTES;
         const int ko = kt * BK;
+        if (CONV) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(ga[j] + ko, sa + j * 4096);
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+                const bool ok = (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+                const bf16_t* src = ga[j] + ((size_t)(pb[j] + (iy >> p.cup) * p.cW + (ix >> p.cup)) * p.cC + c0);
+                glds16(ok ? src : reinterpret_cast<const bf16_t*>(g_zero_page), sa + j * 4096);
+            }
+            c0 += BK;
+            if (c0 == p.cC) { c0 = 0; ++tap; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(ga[j] + ko, sa + j * 4096);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(gw[j] + ko, sw + j * 4096);
     };
@@ -113,15 +143,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     else gemm_epilogue_rowmajor<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
 
-template <int EPI>
+template <int EPI, bool CONV = false>
 int launch(const GemmArgs& a, hipStream_t s) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128<EPI, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_128<EPI>, dim3(ntm * ntn, a.kslice ? a.K / a.kslice : 1), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_bf16_128<EPI, CONV>), dim3(ntm * ntn, a.kslice ? a.K / a.kslice : 1), dim3(256), LDS_BYTES, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
 
@@ -168,6 +198,14 @@ unsigned long long* g_visrep_gemm_dbg_buf = nullptr;
 
 namespace {
 int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
+    if (a.conv) {                                              // implicit 3x3 convolution: 128x128 kernel only
+        switch (a.epi) {
+            case EPI_BIAS: return launch<EPI_BIAS, true>(a, s);
+            case EPI_RESID: return launch<EPI_RESID, true>(a, s);
+            case EPI_F32: return launch<EPI_F32, true>(a, s);
+        }
+        return visrep_set_error(VISREP_ERR_ARG, "conv3x3: epilogue must be BIAS, RESID or F32");
+    }
     if (variant == 3 && visrep_gemm_v3_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
@@ -224,7 +262,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 part.ldc = a.N;
                 part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr;
                 part.kslice = a.K / S;
-                const int rc = launch<EPI_F32>(part, s);
+                const int rc = a.conv ? launch<EPI_F32, true>(part, s) : launch<EPI_F32>(part, s);
                 if (rc) return rc;
                 const long nthreads = (long)a.M * (a.N / 4);
                 hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
@@ -236,7 +274,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     // The BASELINE shapes have M = 256 * 577 (577 is prime): 2308 / 4616 / 9232 tiles = 9 / 18 / 36 full rounds + a 4..16-tile
     // remainder that would cost a whole extra round on 252 idle CUs.  When the remainder is small, the rows of the last
     // round are split off and run as 128x128 tiles (v1), which spread over many CUs and finish in a fraction of a round.
-    if (variant >= 2 && a.N % 256 == 0 && a.epi != EPI_PATCH) {
+    if (variant >= 2 && a.N % 256 == 0 && a.epi != EPI_PATCH && !a.conv) {
         const int ncu = cu_count(), ntn = a.N / 256, ntm = (a.M + 255) / 256;
         const long tiles = (long)ntm * ntn, rounds = tiles / ncu, rem = tiles % ncu;
         if (rounds >= 1 && rem > 0 && rem * 4 <= ncu && (rounds * ncu) % ntn == 0) {

@@ -62,6 +62,26 @@ extern "C" int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     return visrep_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc,
+                                   int Cout, int stride, int pad_mode, int upsample, int epilogue, const void* resid, void* stream) {
+    if (!x || !Wt || !out) return visrep_set_error(VISREP_ERR_ARG, "conv3x3: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3: empty problem");
+    if (C % 64) return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3: C must be a multiple of 64 (use visrep_im2col3x3 + visrep_gemm_bf16 otherwise)");
+    if ((stride != 1 && stride != 2) || (pad_mode != 0 && pad_mode != 1) || (upsample != 0 && upsample != 1))
+        return visrep_set_error(VISREP_ERR_ARG, "conv3x3: stride 1|2, pad_mode 0 (symmetric 1) | 1 (0,1,0,1), upsample 0|1");
+    if (epilogue != VISREP_EPI_BIAS && epilogue != VISREP_EPI_RESID && epilogue != VISREP_EPI_F32)
+        return visrep_set_error(VISREP_ERR_ARG, "conv3x3: epilogue must be BIAS, RESID or F32");
+    if (epilogue == VISREP_EPI_RESID && !resid) return visrep_set_error(VISREP_ERR_ARG, "conv3x3: EPI_RESID needs resid");
+    const int Hl = H << upsample, Wl = W << upsample, pad_total = pad_mode == 0 ? 2 : 1;
+    GemmArgs a{};
+    a.A = (const bf16_t*)x; a.W = (const bf16_t*)Wt; a.C = (bf16_t*)out; a.bias = bias; a.resid = (const bf16_t*)resid;
+    a.conv = 1; a.cH = H; a.cW = W; a.cC = C; a.cstride = stride; a.cpad = pad_mode == 0 ? 1 : 0; a.cup = upsample;
+    a.cHo = (Hl + pad_total - 3) / stride + 1;
+    a.cWo = (Wl + pad_total - 3) / stride + 1;
+    a.M = B * a.cHo * a.cWo; a.N = Cout; a.K = 9 * C; a.lda = 8; a.ldw = ldw; a.ldc = ldc; a.epi = epilogue;
+    return visrep_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------------ ViT forward
 namespace {
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -21,6 +21,9 @@ struct GemmArgs {
     int epi, act;
     int patches, tokens, cls_off;   // EPI_PATCH row remap
     int kslice;                     // split-K (v1, EPI_F32 only): blockIdx.y = slice, K elements per slice; 0 = no split
+    // implicit 3x3 convolution (v1 kernel, conv = 1): A is the channels-last activation [B, cH, cW, cC] and the A tile of
+    // K-tile (tap, c0) is gathered on the fly: row m = (b, oy, ox) reads x[b, (oy*cstride+ky-cpad)>>cup, (ox*cstride+kx-cpad)>>cup, c0..]
+    int conv, cH, cW, cC, cHo, cWo, cstride, cpad, cup;
     unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };

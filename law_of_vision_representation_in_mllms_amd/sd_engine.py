@@ -70,6 +70,22 @@ def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, ld: int, stride: int = 1,
     return y, Ho, Wo
 
 
+def conv3x3(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, stride: int = 1, pad_mode: int = 0, upsample: bool = False,
+            epi: int = _lib.EPI_BIAS, resid=None):
+    """Implicit-GEMM 3x3 convolution (visrep_conv3x3_bf16): x [B*H*W, C] (C % 64 == 0), w [Cout, 9*C] -> ([B*Ho*Wo, Cout], Ho, Wo)."""
+    lib = _lib.require_gpu()
+    C = x.shape[1]
+    Hl, Wl = (H * 2, W * 2) if upsample else (H, W)
+    pad_total = 2 if pad_mode == 0 else 1
+    Ho, Wo = (Hl + pad_total - 3) // stride + 1, (Wl + pad_total - 3) // stride + 1
+    N = w.shape[0]
+    out = torch.empty(B * Ho * Wo, N, dtype=torch.float32 if epi == _lib.EPI_F32 else torch.bfloat16, device=x.device)
+    rc = lib.visrep_conv3x3_bf16(_lib.ptr(x), B, H, W, C, _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(out), out.stride(0), N, stride,
+                                 pad_mode, int(upsample), epi, _lib.ptr(resid), _lib.stream_ptr())
+    _lib.check(rc, "visrep_conv3x3_bf16")
+    return out, Ho, Wo
+
+
 def geglu(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.require_gpu()
     M, F2 = x.shape
@@ -144,6 +160,7 @@ class SdEngine:
         self._prompt_src = None
         self._dyn_ctx = None
         self.graph = graph
+        self.implicit_conv = True
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
 
@@ -335,7 +352,9 @@ class SdEngine:
     # ---------------------------------------------------------------- building blocks (token-major)
     def _conv(self, x, B, H, W, name, stride=1, pad_mode=0, upsample=False, epi=_lib.EPI_BIAS, resid=None):
         lin = self.P[name]
-        cols, Ho, Wo = im2col3x3(x, B, H, W, lin.w.shape[1], stride, pad_mode, upsample)
+        if self.implicit_conv and x.shape[1] % 64 == 0:                    # gather inside the GEMM's A-operand DMA
+            return conv3x3(x, B, H, W, lin.w, lin.b, stride, pad_mode, upsample, epi, resid)
+        cols, Ho, Wo = im2col3x3(x, B, H, W, lin.w.shape[1], stride, pad_mode, upsample)       # 3 / 4-channel inputs (padded to 8)
         return gemm(cols, lin.w, lin.b, epi, resid=resid), Ho, Wo
 
     def _resnet(self, x, B, H, W, p, groups, eps):
@@ -404,9 +423,8 @@ class SdEngine:
         h = self._resnet(h, B, H, W, "encoder.mid_block.resnets.1", g, 1e-6)
         gn, bn = self.P["encoder.conv_norm_out"]
         h = groupnorm(h, gn, bn, B, g, 1e-6, True)
-        lin = self.P["vae.moments"]
-        cols, _, _ = im2col3x3(h, B, H, W, lin.w.shape[1])
-        return gemm(cols, lin.w, lin.b, _lib.EPI_F32), H, W
+        mom, _, _ = self._conv(h, B, H, W, "vae.moments", epi=_lib.EPI_F32)
+        return mom, H, W
 
     def _vae_attention(self, x, B, T):
         """Single-head attention over all T latent pixels, head width = C (512 for SD): materialised scores per image

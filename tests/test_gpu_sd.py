@@ -77,6 +77,42 @@ def test_conv3x3_as_gather_plus_gemm(B, H, W, Ci, Co, stride, pad_mode, up):
     assert (got.cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("stride,pad_mode,up", [(1, 0, False), (2, 0, False), (2, 1, False), (1, 0, True)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 8, 64, 128), (1, 13, 10, 128, 64), (1, 24, 24, 320 + 64, 320), (3, 12, 12, 1280, 1280),
+                                         (1, 96, 96, 128, 128)])
+def test_conv3x3_implicit_gemm(B, H, W, Ci, Co, stride, pad_mode, up):
+    """The gather folded into the GEMM's A-operand DMA: vs F.conv2d, vs the explicit im2col path, all epilogues, split-K shapes."""
+    g = torch.Generator().manual_seed(H * 100 + Ci + stride)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = torch.randn(Co, generator=g) * 0.1
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    if pad_mode == 1:
+        want = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), b, stride=stride, padding=0)
+    else:
+        want = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    wp = bf(w.float().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)).to(DEV)
+    SE.ensure_scratch(torch.device(DEV))
+    xt = tokens(x).to(DEV)
+    got, Ho, Wo = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, up, _lib.EPI_F32)
+    assert (Ho, Wo) == tuple(want.shape[2:])
+    assert (untokens(got, B, Ho, Wo).cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+    cols, _, _ = SE.im2col3x3(xt, B, H, W, 9 * Ci, stride, pad_mode, up)
+    explicit = engine.gemm(cols, wp, b.to(DEV), _lib.EPI_F32)
+    assert (got - explicit).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+    res = bf(torch.randn(B * Ho * Wo, Co, generator=g)).to(DEV)
+    r, _, _ = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, up, _lib.EPI_RESID, resid=res)
+    assert rel_err(r, res.float().cpu() + tokens(want)) < 5e-3
+    o, _, _ = SE.conv3x3(xt, B, H, W, wp, None, stride, pad_mode, up, _lib.EPI_BIAS)
+    assert rel_err(o, tokens(want - b[None, :, None, None])) < 5e-3
+
+
+def test_conv3x3_rejects_narrow_channels():
+    x = torch.zeros(64, 8, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        SE.conv3x3(x, 1, 8, 8, torch.zeros(64, 72, dtype=torch.bfloat16, device=DEV), None)
+
+
 @pytest.mark.parametrize("M,N,K", [(144, 1280, 11520), (576, 320, 2880), (64, 128, 1024), (300, 1280, 23040)])
 def test_gemm_split_k_small_m_deep_k(M, N, K):
     """Few tiles, deep reduction: with the scratch attached the K loop is split over CUs and reduced in slice order."""
