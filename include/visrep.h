@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 100
+#define VISREP_VERSION 110
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
