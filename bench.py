@@ -122,8 +122,9 @@ def main():
         wo = L0["wo"].to(dev).to(torch.bfloat16)
         b1 = L0["b1"].to(dev)
 
-        def time_kernel(fn, reps=10):
-            fn()
+        def time_kernel(fn, reps=20, warm=5):
+            for _ in range(warm):            # steady state: the first launches after an idle gap run at a lower clock
+                fn()
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void geglu(const bf16_t* __restrict__ x, bf16_
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
-        const float h0 = 0.5f * g0 * (1.0f + erff(g0 * 0.70710678118654752f)), h1 = 0.5f * g1 * (1.0f + erff(g1 * 0.70710678118654752f));
+        const float h0 = gelu_erf(g0), h1 = gelu_erf(g1);
         o[e] = pack_bf16(bf_lo(a[e]) * h0, bf_hi(a[e]) * h1);
     }
     *reinterpret_cast<u32x4*>(y + row * ldy + f0) = o;
