@@ -2,7 +2,8 @@
 
 Same entry points: extract_features(image_path) -> Tensor[1, C, h, w] and process_images(input_dir, output_dir) writing
 <output_dir>/<class>/<image>_<suffix>.pt (extract_feature.py:54-106,110-130).  The reference is a module-level script with
-hard-coded `feature`/paths and an internally inconsistent DINOv2 branch (224-px input reshaped as 24x24); here
+hard-coded `feature`/paths (all ten `feature` values are supported: the four ViT towers and DIFT1.5 / DIFT2.1 / DIFTXL / IMDIFT /
+DiTDIFT / SD3DIFT) and an internally inconsistent DINOv2 branch (224-px input reshaped as 24x24); here
 `configure(feature, img_size, suffix)` sets them, grid = img_size // patch, and nothing runs at import time.
 Pre-processing is the reference's own (NOT the HF processors): PIL resize((s, s)) then (x/255 - 0.5) * 2 (l.65-67).
 """
@@ -21,7 +22,11 @@ feature = "DINOv2"
 _DEFAULT_SIZE = {"CLIP": 224, "OPENCLIP": 224, "DINOv2": 224, "SigLIP": 224}
 _TOWER_ID = {"CLIP": 'openai/clip-vit-large-patch14', "OPENCLIP": 'laion/CLIP-ViT-L-14-laion2B-s32B-b82K',
              "DINOv2": 'facebook/dinov2-large', "SigLIP": 'google/siglip-base-patch16-224'}
-_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64)
+# diffusion featurizers (extract_feature.py:23-34) and the input side each one is fed at (:56-63)
+_DIFT = {"DIFT2.1": ("sd", 'stabilityai/stable-diffusion-2-1', 768), "DIFT1.5": ("sd", 'runwayml/stable-diffusion-v1-5', 768),
+         "DIFTXL": ("sd", 'stabilityai/stable-diffusion-xl-base-1.0', 512), "IMDIFT": ("imsd", None, 768),
+         "DiTDIFT": ("dit", None, 512), "SD3DIFT": ("sd3", None, 512)}
+_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64, kind="vit")
 
 
 class args_c:
@@ -37,9 +42,12 @@ def configure(feature_name="DINOv2", img_size=None, suffix=None, synthetic_weigh
     from ..llava.model.multimodal_encoder.clip_encoder import CLIPVisionTower
     from ..llava.model.multimodal_encoder.dinov2_encoder import DinoV2VisionTower
     from ..llava.model.multimodal_encoder.siglip_encoder import SigLipVisionTower
+    if feature_name in _DIFT:
+        return _configure_dift(feature_name, img_size, suffix, synthetic_weights, batch)
     if feature_name not in _TOWER_ID:
-        raise NotImplementedError(f"feature {feature_name!r}: diffusion featurizers are a later row (SURVEY.md §8 a5)")
+        raise KeyError(f"unknown feature {feature_name!r}")
     feature = feature_name
+    _state.kind = "vit"
     size = img_size or _DEFAULT_SIZE[feature_name]
     a = args_c(img_size=size, synthetic_weights=synthetic_weights)
     cls = {"CLIP": CLIPVisionTower, "OPENCLIP": CLIPVisionTower, "DINOv2": DinoV2VisionTower, "SigLIP": SigLipVisionTower}[feature_name]
@@ -48,6 +56,34 @@ def configure(feature_name="DINOv2", img_size=None, suffix=None, synthetic_weigh
     _state.suffix = suffix or {"CLIP": "clip", "OPENCLIP": "openclip", "DINOv2": f"dino{size}" if size != 224 else "dino", "SigLIP": "siglip"}[feature_name]
     _state.batch = batch
     return _state.dift
+
+
+def _configure_dift(feature_name, img_size, suffix, synthetic_weights, batch):
+    global feature
+    from ..llava.model.multimodal_encoder.diffLVLM.src.models.dift_dit import DiTFeaturizer
+    from ..llava.model.multimodal_encoder.diffLVLM.src.models.dift_imsd import IMSDFeaturizer
+    from ..llava.model.multimodal_encoder.diffLVLM.src.models.dift_sd import SDFeaturizer
+    from ..llava.model.multimodal_encoder.diffLVLM.src.models.dift_sd3 import SD3Featurizer
+    kind, sd_id, size = _DIFT[feature_name]
+    syn = True if synthetic_weights else None
+    if kind == "sd":
+        _state.dift = SDFeaturizer(sd_id=sd_id, synthetic=syn)
+    else:
+        _state.dift = {"imsd": IMSDFeaturizer, "dit": DiTFeaturizer, "sd3": SD3Featurizer}[kind](synthetic=syn)
+    feature = feature_name
+    _state.kind, _state.img_size, _state.batch = kind, img_size or size, min(batch, 8)
+    _state.suffix = suffix or feature_name.lower()
+    return _state.dift
+
+
+def _dift_maps(px, post_noise=None, ddim_noise=None):
+    """[B, 3, s, s] -> [B, C, h, w] as extract_feature.py:68-103 returns per image (prompt '', ensemble 1, default t / block)."""
+    f = _state.dift.forward(px.to(torch.bfloat16), prompt='', ensemble_size=1, post_noise=post_noise, ddim_noise=ddim_noise)
+    if f.dim() == 3:
+        f = f.unsqueeze(0)
+    if _state.kind == "dit":
+        f = f.permute(0, 1, 3, 2)              # extract_feature.py:95: permute(0, 1, 3, 2).view(...) - the map is stored transposed
+    return f
 
 
 def _load_pixels(image_path, size):
@@ -67,6 +103,8 @@ def extract_features(image_path):
     if _state.dift is None:
         configure(feature)
     px = _load_pixels(image_path, _state.img_size).unsqueeze(0)
+    if _state.kind != "vit":
+        return _dift_maps(px)
     return _to_maps(_state.dift.forward(px))
 
 
@@ -87,7 +125,7 @@ def process_images(input_dir, output_dir):
     for s in range(0, len(todo), _state.batch):
         chunk = todo[s:s + _state.batch]
         px = torch.stack([_load_pixels(p, _state.img_size) for p, _ in chunk])
-        maps = _to_maps(_state.dift.forward(px)).cpu()
+        maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
         for (_, out), m in zip(chunk, maps):
             os.makedirs(os.path.dirname(out), exist_ok=True)
             torch.save(m.unsqueeze(0).clone(), out)

@@ -143,3 +143,20 @@ def test_extract_feature_and_pck_train_on_device(small_towers, tmp_path):
     q10, q05, q01, results2 = PT2.eval(eval_args_two(root, 16), PT2.DummyAggregationNetwork(), str(tmp_path), split="test")
     np.testing.assert_allclose([q10, q05, q01], z["eval2.pck"], atol=1e-7)
     np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results2]), z["eval2.pred"], atol=5e-3)
+
+
+def test_extract_feature_diffusion_feature_on_device(tmp_path):
+    """extract_feature with feature = "DIFT1.5" (full SD1.5 architecture, synthetic weights) at a small input side."""
+    src = tmp_path / "JPEGImages" / "dog"
+    os.makedirs(src)
+    rs = np.random.RandomState(3)
+    for i in range(3):
+        Image.fromarray(rs.randint(0, 255, (60, 80, 3), dtype=np.uint8)).save(src / f"im{i}.jpg")
+    EF.configure("DIFT1.5", img_size=128, synthetic_weights=True, batch=2)
+    try:
+        EF.process_images(str(tmp_path / "JPEGImages"), str(tmp_path / "features"))
+        f = torch.load(tmp_path / "features" / "dog" / "im1_dift1.5.pt")
+        assert f.shape == (1, 1280, 4, 4) and torch.isfinite(f.float()).all()
+        assert EF.extract_features(str(src / "im1.jpg")).shape == (1, 1280, 4, 4)
+    finally:
+        EF._state.dift, EF._state.kind = None, "vit"

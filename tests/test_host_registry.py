@@ -94,3 +94,35 @@ def test_specs_and_interpolation():
     flat = VW.flatten(w)
     back = VW.unflatten(flat)
     assert torch.equal(back["layers"][2]["w2"], w["layers"][2]["w2"]) and back["cls"] is None
+
+
+def test_extract_feature_diffusion_dispatch_shapes(tmp_path, monkeypatch):
+    """extract_feature.py:68-103 post-processing per `feature`, with a stand-in featurizer (no device work)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from law_of_vision_representation_in_mllms_amd.C_score import extract_feature as EF
+    assert {k: v[2] for k, v in EF._DIFT.items()} == {"DIFT2.1": 768, "DIFT1.5": 768, "DIFTXL": 512, "IMDIFT": 768, "DiTDIFT": 512, "SD3DIFT": 512}
+    calls = []
+
+    class Stub:
+        def forward(self, px, prompt, ensemble_size, post_noise=None, ddim_noise=None):
+            calls.append((tuple(px.shape), px.dtype, prompt, ensemble_size))
+            B = px.shape[0]
+            f = torch.arange(B * 6 * 2 * 3, dtype=torch.float32).view(B, 6, 2, 3)
+            return f.squeeze() if B == 1 else f
+    src = tmp_path / "JPEGImages" / "cat"
+    src.mkdir(parents=True)
+    for i in range(3):
+        Image.fromarray(np.full((20, 30, 3), 40 * i, np.uint8)).save(src / f"im{i}.jpg")
+    monkeypatch.setattr(EF, "_state", SimpleNamespace(dift=Stub(), img_size=32, suffix="dift1.5", batch=2, kind="sd"))
+    one = EF.extract_features(str(src / "im0.jpg"))
+    assert one.shape == (1, 6, 2, 3) and calls[-1] == ((1, 3, 32, 32), torch.bfloat16, '', 1)
+    EF.process_images(str(tmp_path / "JPEGImages"), str(tmp_path / "out"))
+    f = torch.load(tmp_path / "out" / "cat" / "im2_dift1.5.pt")
+    assert f.shape == (1, 6, 2, 3)
+    EF._state.kind = "dit"                                    # DiT maps are stored transposed (extract_feature.py:95)
+    t = EF.extract_features(str(src / "im0.jpg"))
+    assert t.shape == (1, 6, 3, 2) and torch.equal(t, one.permute(0, 1, 3, 2))
+    with pytest.raises(KeyError):
+        EF.configure("NOPE")
