@@ -191,6 +191,22 @@ int visrep_sd_noisy_latents(const float* moments, int ldm, const float* post_noi
 /* dift_sd.py:275 ensemble mean: x [B, E, N] bf16 -> y [B, N] bf16 (fp32 accumulation). */
 int visrep_mean_groups(const void* x, void* y, int B, int E, long N, void* stream);
 
+/* ==== Device input pipeline: everything after JPEG decode ================================================
+ * One axis of Pillow's 8-bit separable resampling (src/libImaging/Resample.c ImagingResampleHorizontal_8bpc /
+ * Vertical_8bpc) - what `PIL.Image.resize` does inside the reference's pre-processing (C_score/extract_feature.py:65-66,
+ * HF CLIPImageProcessor.resize, llava/mm_utils.py:64-95) - BIT-EXACT: out[line, xx, c] = clip8((2^21 + sum_x in[line,
+ * xmin[xx] + x, c] * kk[xx][x]) >> 22) with bounds = (xmin, count) pairs and the 22-bit fixed-point coefficient table the
+ * host builds like precompute_coeffs + normalize_coeffs_8bpc (device_preprocess.pil_coeffs).  Strides in bytes select the
+ * axis: horizontal pass line = row, vertical pass line = column. */
+int visrep_resample_u8(const void* in, void* out, long n_lines, int out_len, int channels, long in_line_stride, long in_elem_stride,
+                       long out_line_stride, long out_elem_stride, const int* bounds, const int* kk, int ksize, void* stream);
+
+/* crop + ToTensor + Normalize: out[c, y, x] = (in[y0+y, x0+x, c] / 255 - mean3[c]) / std3[c], IEEE fp32 (bit-identical to the
+ * numpy expression of the CPU processors); in: uint8 [H, W, 3] on the device; mean3 / std3: HOST float[3];
+ * out: [3, crop_h, crop_w] VISREP_F32 or VISREP_BF16. */
+int visrep_u8hwc_to_chw_norm(const void* in, int H, int W, int x0, int y0, int crop_h, int crop_w, const float* mean3, const float* std3,
+                             void* out, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

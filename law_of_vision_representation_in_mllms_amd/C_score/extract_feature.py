@@ -26,7 +26,7 @@ _TOWER_ID = {"CLIP": 'openai/clip-vit-large-patch14', "OPENCLIP": 'laion/CLIP-Vi
 _DIFT = {"DIFT2.1": ("sd", 'stabilityai/stable-diffusion-2-1', 768), "DIFT1.5": ("sd", 'runwayml/stable-diffusion-v1-5', 768),
          "DIFTXL": ("sd", 'stabilityai/stable-diffusion-xl-base-1.0', 512), "IMDIFT": ("imsd", None, 768),
          "DiTDIFT": ("dit", None, 512), "SD3DIFT": ("sd3", None, 512)}
-_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64, kind="vit")
+_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64, kind="vit", device_preprocess=False)
 
 
 class args_c:
@@ -92,6 +92,15 @@ def _load_pixels(image_path, size):
     return (a / 255.0 - 0.5) * 2
 
 
+def _load_pixels_device(image_path, size, device="cuda"):
+    """Same values as _load_pixels, but only the JPEG decode runs on the host: Pillow-exact bicubic resize and the
+    (x / 255 - 0.5) * 2 arithmetic run on the GPU (device_preprocess)."""
+    from .. import device_preprocess as DP
+    a = np.array(Image.open(image_path).convert('RGB'))
+    dev = torch.from_numpy(a).to(device)
+    return DP.to_tensor(DP.resize_u8(dev, (size, size)), (0, 0, size, size), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+
+
 def _to_maps(f):
     # tokens [B, N, C] -> [B, C, g, g]   (extract_feature.py:82,86,90 with g = sqrt(N))
     B, N, C = f.shape
@@ -124,7 +133,8 @@ def process_images(input_dir, output_dir):
         todo = todo[d.get_rank()::d.get_world_size()]                        # image-sharded across ranks, no collective
     for s in range(0, len(todo), _state.batch):
         chunk = todo[s:s + _state.batch]
-        px = torch.stack([_load_pixels(p, _state.img_size) for p, _ in chunk])
+        load = _load_pixels_device if getattr(_state, "device_preprocess", False) else _load_pixels
+        px = torch.stack([load(p, _state.img_size) for p, _ in chunk])
         maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
         for (_, out), m in zip(chunk, maps):
             os.makedirs(os.path.dirname(out), exist_ok=True)

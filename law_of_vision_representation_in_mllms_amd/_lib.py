@@ -51,6 +51,8 @@ SIGNATURES = {
     "visrep_geglu": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
     "visrep_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "visrep_nchw_to_tokens": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "visrep_resample_u8": (_i, [_vp, _vp, _l, _i, _i, _l, _l, _l, _l, _vp, _vp, _i, _vp]),
+    "visrep_u8hwc_to_chw_norm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _vp]),
     "visrep_resize_bilinear": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_sd_noisy_latents": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "visrep_mean_groups": (_i, [_vp, _vp, _i, _i, _l, _vp]),

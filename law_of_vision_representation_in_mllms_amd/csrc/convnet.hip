@@ -388,3 +388,72 @@ extern "C" int visrep_mean_groups(const void* x, void* y, int B, int E, long N, 
     hipLaunchKernelGGL(mean_groups, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, total, N / 2, E);
     return launched("mean_groups: launch failed");
 }
+
+// ================================================================================================ input pipeline
+// PIL-exact separable resampling of 8-bit images (Pillow src/libImaging/Resample.c, 8bpc path): fixed-point coefficients
+// (22 fractional bits) prepared on the host exactly like precompute_coeffs + normalize_coeffs_8bpc, int32 accumulation from
+// 1 << 21, arithmetic shift, clamp to [0, 255].  One pass = one axis; `line` / `elem` strides select rows or columns.
+namespace {
+__global__ __launch_bounds__(256) void resample_u8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long total, int out_len,
+                                                   int channels, long ils, long ies, long ols, long oes, const int* __restrict__ bounds,
+                                                   const int* __restrict__ kk, int ksize) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // (line, xx, c)
+    if (idx >= total) return;
+    const int c = (int)(idx % channels);
+    const long r = idx / channels;
+    const int xx = (int)(r % out_len);
+    const long line = r / out_len;
+    const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    const int* k = kk + (long)xx * ksize;
+    const uint8_t* src = in + line * ils + (long)xmin * ies + c;
+    int ss = 1 << 21;
+    for (int x = 0; x < cnt; ++x) ss += (int)src[x * ies] * k[x];
+    ss >>= 22;
+    out[line * ols + (long)xx * oes + c] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+// crop + ToTensor + normalise: out[c, y, x] = (in[y0 + y, x0 + x, c] / 255 - mean[c]) / std[c]  (IEEE fp32 division: bit-identical
+// to numpy's `(a / 255.0 - mean) / std` of the CPU processors), fp32 or bf16 output, NCHW
+template <bool F32>
+__global__ __launch_bounds__(256) void u8hwc_to_chw_norm(const uint8_t* __restrict__ in, void* __restrict__ out, long total, int W, int x0, int y0,
+                                                         int S_h, int S_w, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // (c, y, x)
+    if (idx >= total) return;
+    const int x = (int)(idx % S_w);
+    const long r = idx / S_w;
+    const int y = (int)(r % S_h), c = (int)(r / S_h);
+    const float v = (float)in[((long)(y0 + y) * W + (x0 + x)) * 3 + c] / 255.0f;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    const float o = (v - mean) / sd;
+    if (F32) reinterpret_cast<float*>(out)[idx] = o;
+    else reinterpret_cast<bf16_t*>(out)[idx] = (bf16_t)(pack_bf16(o, 0.f) & 0xffffu);
+}
+}  // namespace
+
+extern "C" int visrep_resample_u8(const void* in, void* out, long n_lines, int out_len, int channels, long in_line_stride,
+                                  long in_elem_stride, long out_line_stride, long out_elem_stride, const int* bounds, const int* kk, int ksize,
+                                  void* stream) {
+    if (!in || !out || !bounds || !kk) return visrep_set_error(VISREP_ERR_ARG, "resample_u8: null pointer");
+    if (n_lines <= 0 || out_len <= 0 || channels <= 0 || ksize <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "resample_u8: empty problem");
+    const long total = n_lines * out_len * channels;
+    hipLaunchKernelGGL(resample_u8, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)in, (uint8_t*)out, total, out_len,
+                       channels, in_line_stride, in_elem_stride, out_line_stride, out_elem_stride, bounds, kk, ksize);
+    return launched("resample_u8: launch failed");
+}
+
+extern "C" int visrep_u8hwc_to_chw_norm(const void* in, int H, int W, int x0, int y0, int crop_h, int crop_w, const float* mean3,
+                                        const float* std3, void* out, int dtype, void* stream) {
+    if (!in || !out || !mean3 || !std3) return visrep_set_error(VISREP_ERR_ARG, "u8hwc_to_chw_norm: null pointer (mean3 / std3 are HOST arrays)");
+    if (x0 < 0 || y0 < 0 || crop_h <= 0 || crop_w <= 0 || x0 + crop_w > W || y0 + crop_h > H)
+        return visrep_set_error(VISREP_ERR_SHAPE, "u8hwc_to_chw_norm: crop outside the image");
+    const long total = 3L * crop_h * crop_w;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VISREP_F32)
+        hipLaunchKernelGGL(u8hwc_to_chw_norm<true>, dim3(blocks_for(total)), dim3(256), 0, st, (const uint8_t*)in, out, total, W, x0, y0, crop_h,
+                           crop_w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else if (dtype == VISREP_BF16)
+        hipLaunchKernelGGL(u8hwc_to_chw_norm<false>, dim3(blocks_for(total)), dim3(256), 0, st, (const uint8_t*)in, out, total, W, x0, y0, crop_h,
+                           crop_w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else return visrep_set_error(VISREP_ERR_ARG, "u8hwc_to_chw_norm: dtype must be bf16 (0) or f32 (1)");
+    return launched("u8hwc_to_chw_norm: launch failed");
+}

@@ -1,0 +1,170 @@
+"""Device-side image pre-processing: everything after JPEG decode runs on the MI355X.
+
+The reference resizes with `PIL.Image.resize` (default BICUBIC: C_score/extract_feature.py:65-66; HF CLIPImageProcessor /
+llava `process_images`, llava/mm_utils.py:64-95) and then does ToTensor / normalise on the host, one image at a time.  Here
+the decoded uint8 image is copied to the GPU once and
+
+    resize_u8   Pillow's 8-bit separable bicubic resampling, BIT-EXACT (visrep_resample_u8, two passes)
+    to_tensor   crop + /255 + (x - mean) / std in IEEE fp32, bit-identical to the CPU processors (visrep_u8hwc_to_chw_norm)
+
+`pil_coeffs` restates Pillow's `precompute_coeffs` + `normalize_coeffs_8bpc` (src/libImaging/Resample.c, third-party, version
+of the installed Pillow; checked bit-for-bit against `Image.resize` itself in tests/test_host_preprocess.py) in Python
+floats, i.e. C doubles, with the same operation order: the tables are tiny and cached per (in, out) size pair.
+"""
+from __future__ import annotations
+
+import math
+from functools import lru_cache
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@lru_cache(maxsize=256)
+def pil_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """(bounds int32 [out, 2] = (xmin, count), kk int32 [out, ksize], ksize) of Pillow's bicubic filter for one axis."""
+    scale = float(in_size) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + k * (1 << PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def resample_reference(img: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
+    """The same two fixed-point passes in numpy (host check of the tables; not used by the product path)."""
+    ow, oh = size
+    out = img
+    for axis, (n_in, n_out) in ((1, (img.shape[1], ow)), (0, (img.shape[0], oh))):
+        if n_in == n_out:
+            continue
+        bounds, kk, _ = pil_coeffs(n_in, n_out)
+        src = np.moveaxis(out.astype(np.int64), axis, 0)
+        dst = np.empty((n_out,) + src.shape[1:], np.uint8)
+        for xx in range(n_out):
+            x0, n = bounds[xx]
+            acc = (1 << (PRECISION_BITS - 1)) + np.tensordot(kk[xx, :n].astype(np.int64), src[x0:x0 + n], axes=(0, 0))
+            dst[xx] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+        out = np.moveaxis(dst, 0, axis)
+    return np.ascontiguousarray(out)
+
+
+_TABLES = {}
+
+
+def _device_tables(n_in, n_out, device):
+    key = (n_in, n_out, str(device))
+    if key not in _TABLES:
+        bounds, kk, ksize = pil_coeffs(n_in, n_out)
+        _TABLES[key] = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
+    return _TABLES[key]
+
+
+def resize_u8(img: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """img uint8 [H, W, 3] on the GPU -> uint8 [OH, OW, 3], bit-identical to PIL `Image.resize((OW, OH), BICUBIC)`."""
+    lib = _lib.require_gpu()
+    if img.dtype != torch.uint8 or img.dim() != 3:
+        raise ValueError("resize_u8 wants a uint8 [H, W, C] tensor")
+    ow, oh = size
+    H, W, C = img.shape
+    cur = img.contiguous()
+    if W != ow:                                                   # horizontal pass: line = row
+        b, k, ks = _device_tables(W, ow, cur.device)
+        nxt = torch.empty(H, ow, C, dtype=torch.uint8, device=cur.device)
+        rc = lib.visrep_resample_u8(_lib.ptr(cur), _lib.ptr(nxt), H, ow, C, W * C, C, ow * C, C, _lib.ptr(b), _lib.ptr(k), ks, _lib.stream_ptr())
+        _lib.check(rc, "visrep_resample_u8")
+        cur = nxt
+    if H != oh:                                                   # vertical pass: line = column
+        b, k, ks = _device_tables(H, oh, cur.device)
+        nxt = torch.empty(oh, ow, C, dtype=torch.uint8, device=cur.device)
+        rc = lib.visrep_resample_u8(_lib.ptr(cur), _lib.ptr(nxt), ow, oh, C, C, ow * C, C, ow * C, _lib.ptr(b), _lib.ptr(k), ks, _lib.stream_ptr())
+        _lib.check(rc, "visrep_resample_u8")
+        cur = nxt
+    return cur
+
+
+def to_tensor(img: torch.Tensor, box: Tuple[int, int, int, int], mean: Sequence[float], std: Sequence[float], dtype=torch.float32,
+              out: torch.Tensor = None) -> torch.Tensor:
+    """img uint8 [H, W, 3] on the GPU, box = (left, top, width, height) -> [3, height, width]: (x / 255 - mean) / std."""
+    import ctypes as C
+    lib = _lib.require_gpu()
+    H, W, _ = img.shape
+    l, t, w, h = box
+    if out is None:
+        out = torch.empty(3, h, w, dtype=dtype, device=img.device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    rc = lib.visrep_u8hwc_to_chw_norm(_lib.ptr(img), H, W, l, t, h, w, m, s, _lib.ptr(out), _lib.F32 if out.dtype == torch.float32 else _lib.BF16,
+                                      _lib.stream_ptr())
+    _lib.check(rc, "visrep_u8hwc_to_chw_norm")
+    return out
+
+
+class DevicePreprocessor:
+    """Device twin of image_processing.SimpleImageProcessor (same geometry, same arithmetic): PIL images in, pixel batch out."""
+
+    def __init__(self, resize_to, crop, mean, std, square_resize=False, device=None, dtype=torch.float32):
+        self.resize_to, self.crop, self.mean, self.std, self.square_resize = resize_to, crop, list(mean), list(std), square_resize
+        self.image_mean, self.image_std = self.mean, self.std                # the attributes llava/mm_utils.py process_images reads
+        self.crop_size, self.size = {"height": crop, "width": crop}, {"shortest_edge": resize_to}
+        self.device = torch.device(device if device is not None else "cuda")
+        self.dtype = dtype
+
+    @classmethod
+    def like(cls, proc, device=None, dtype=torch.float32):
+        return cls(proc.resize_to, proc.crop, proc.image_mean, proc.image_std, proc.square_resize, device, dtype)
+
+    def geometry(self, w, h):
+        if self.square_resize:
+            return (self.crop, self.crop), (0, 0, self.crop, self.crop)
+        s = self.resize_to / min(w, h)
+        nw, nh = max(self.resize_to, int(round(w * s))), max(self.resize_to, int(round(h * s)))
+        return (nw, nh), ((nw - self.crop) // 2, (nh - self.crop) // 2, self.crop, self.crop)
+
+    @torch.no_grad()
+    def preprocess(self, images, return_tensors="pt"):
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        out = torch.empty(len(images), 3, self.crop, self.crop, dtype=self.dtype, device=self.device)
+        for i, im in enumerate(images):
+            a = np.array(im.convert("RGB"))                                      # decode stays on the host (writable copy for torch)
+            dev = torch.from_numpy(a).to(self.device, non_blocking=True)
+            size, box = self.geometry(a.shape[1], a.shape[0])
+            to_tensor(resize_u8(dev, size), box, self.mean, self.std, out=out[i])
+        return {"pixel_values": out}
+
+    __call__ = preprocess

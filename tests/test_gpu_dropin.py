@@ -23,6 +23,8 @@ from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder im
 from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_projector.builder import build_vision_projector  # noqa: E402
 from oracle import ascore as OA, projector as OP, vit as OV  # noqa: E402
 
+DEV = "cuda:0"
+
 pytestmark = pytest.mark.gpu
 
 
@@ -160,3 +162,37 @@ def test_extract_feature_diffusion_feature_on_device(tmp_path):
         assert EF.extract_features(str(src / "im1.jpg")).shape == (1, 1280, 4, 4)
     finally:
         EF._state.dift, EF._state.kind = None, "vit"
+
+
+@pytest.mark.parametrize("w,h,ow,oh", [(640, 480, 224, 224), (500, 375, 448, 336), (100, 80, 224, 224), (768, 768, 224, 224), (17, 9, 5, 31),
+                                       (224, 300, 224, 224)])
+def test_device_resize_is_bit_exact_with_pil(w, h, ow, oh):
+    from law_of_vision_representation_in_mllms_amd import device_preprocess as DP
+    rs = np.random.RandomState(w * 7 + h)
+    a = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    a[: h // 3] = rs.randint(0, 2, (h // 3, w, 3)) * 255
+    want = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BICUBIC))
+    got = DP.resize_u8(torch.from_numpy(a).to(DEV), (ow, oh)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_device_preprocessor_equals_cpu_processors(tmp_path):
+    """CLIP / DINOv2 / SigLIP processor geometry and arithmetic on the device: bit-identical fp32 pixel tensors; and the C-path
+    loader of extract_feature."""
+    from law_of_vision_representation_in_mllms_amd import device_preprocess as DP
+    from law_of_vision_representation_in_mllms_amd import vit_weights as VW
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.image_processing import default_image_processor
+    rs = np.random.RandomState(11)
+    imgs = [Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8)) for w, h in ((640, 427), (333, 500), (224, 224))]
+    for name in ("openai/clip-vit-large-patch14-336", "facebook/dinov2-large", "google/siglip-base-patch16-224"):
+        cpu = default_image_processor(VW.SPECS[name])
+        want = cpu.preprocess(imgs)["pixel_values"]
+        got = DP.DevicePreprocessor.like(cpu, DEV).preprocess(imgs)["pixel_values"]
+        assert got.shape == want.shape and torch.equal(got.cpu(), want), name
+    # llava/mm_utils.py process_images with image_aspect_ratio = 'pad' accepts the device processor as is
+    from law_of_vision_representation_in_mllms_amd.llava import mm_utils as MU
+    cpu = default_image_processor(VW.SPECS["openai/clip-vit-large-patch14-336"])
+    cfg = SimpleNamespace(image_aspect_ratio="pad")
+    assert torch.equal(MU.process_images(imgs, DP.DevicePreprocessor.like(cpu, DEV), cfg).cpu(), MU.process_images(imgs, cpu, cfg))
+    imgs[0].save(tmp_path / "a.jpg")
+    assert torch.equal(EF._load_pixels_device(str(tmp_path / "a.jpg"), 224, DEV).cpu(), EF._load_pixels(str(tmp_path / "a.jpg"), 224))

@@ -1,0 +1,25 @@
+"""The restated Pillow resampling tables (device_preprocess.pil_coeffs) against `PIL.Image.resize` itself, bit for bit, on the CPU;
+the device kernels consume exactly these tables (GPU parity: tests/test_gpu_dropin.py)."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from law_of_vision_representation_in_mllms_amd import device_preprocess as DP
+
+
+@pytest.mark.parametrize("w,h,ow,oh", [(640, 480, 224, 224), (500, 375, 448, 336), (333, 500, 336, 504), (100, 80, 224, 224), (768, 768, 224, 224),
+                                       (17, 9, 5, 31), (224, 300, 224, 224), (1024, 683, 336, 336)])
+def test_fixed_point_bicubic_equals_pil(w, h, ow, oh):
+    rs = np.random.RandomState(w + h)
+    a = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    a[: h // 3] = rs.randint(0, 2, (h // 3, w, 3)) * 255            # hard edges: exercise the clamp of over/undershoot
+    want = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BICUBIC))
+    got = DP.resample_reference(a, (ow, oh))
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_coeff_tables_shape_and_sum():
+    b, k, ks = DP.pil_coeffs(640, 224)
+    assert b.shape == (224, 2) and k.shape == (224, ks) and ks == 13
+    assert np.all(np.abs(k.sum(1) - (1 << 22)) <= ks)             # rows sum to 1.0 in 22-bit fixed point, up to rounding
+    assert b[0, 0] == 0 and b[-1].sum() == 640
