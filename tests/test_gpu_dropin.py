@@ -196,3 +196,46 @@ def test_device_preprocessor_equals_cpu_processors(tmp_path):
     assert torch.equal(MU.process_images(imgs, DP.DevicePreprocessor.like(cpu, DEV), cfg).cpu(), MU.process_images(imgs, cpu, cfg))
     imgs[0].save(tmp_path / "a.jpg")
     assert torch.equal(EF._load_pixels_device(str(tmp_path / "a.jpg"), 224, DEV).cpu(), EF._load_pixels(str(tmp_path / "a.jpg"), 224))
+
+
+def test_fused_pipelines_equal_the_file_route(small_towers, tmp_path):
+    """pipeline.py: features stay in HBM; the scores equal the dump-to-disk route exactly."""
+    from law_of_vision_representation_in_mllms_amd import pipeline as PL
+    rs = np.random.RandomState(21)
+    images = [Image.fromarray(rs.randint(0, 256, (60 + 3 * i, 80, 3), dtype=np.uint8)) for i in range(6)]
+    # ---- A score: three encoder stacks (tower + mlp2x_gelu projector), file route = save_tensor_to_folder + A_score.compute
+    stacks = {}
+    for name, tower_id in dict(clip336='openai/clip-vit-large-patch14-336', clip224='openai/clip-vit-large-patch14', dino='facebook/dinov2-large').items():
+        cfg = SimpleNamespace(mm_vision_tower=tower_id, mm_vision_select_layer=-2, mm_vision_select_feature='patch', mm_projector_type='mlp2x_gelu',
+                              hidden_size=256)
+        torch.manual_seed(len(name))
+        stacks[name] = LA.VisionEncoderStack(cfg)
+    fused = PL.a_scores_from_stacks(stacks, images, batch=4, verbose=False)
+    for name, stack in stacks.items():
+        proc = stack.get_vision_tower().image_processor
+        for k, im in enumerate(images, 1):
+            f = stack.encode_images(proc.preprocess([im])["pixel_values"])[0]
+            os.makedirs(tmp_path / "bench" / name, exist_ok=True)
+            torch.save(f.cpu(), tmp_path / "bench" / name / f"tensor_{k}.pt")
+    filed = AC.compute(str(tmp_path / "bench"), list(stacks), n_images=len(images), verbose=False)
+    for name in stacks:
+        assert abs(fused[name] - filed[name]) < 2e-3 * abs(filed[name]), name          # batch-1 vs batched tower rounding only
+    assert abs(fused["clip336"] - 0.5) > 1e-3 and fused.keys() == filed.keys()
+    # ---- C score: dense maps straight from a tower vs extract_feature files + pck_train.eval
+    root, z = make_tree(str(tmp_path / "spair"))
+    jpeg = os.path.join(root, "JPEGImages")
+    for cat in ("aeroplane", "cat"):
+        os.makedirs(os.path.join(jpeg, cat), exist_ok=True)
+        for i in range(5):
+            Image.fromarray(rs.randint(0, 256, (70, 90, 3), dtype=np.uint8)).save(os.path.join(jpeg, cat, f"img{i}.jpg"))
+    EF.configure("DINOv2", img_size=42, suffix="dinofile", batch=4)
+    EF.process_images(jpeg, os.path.join(root, "features"))
+    a = eval_args(root, 3)
+    a.MODEL = "dinofile"
+    want = PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+
+    def extract(paths):
+        return EF._state.dift.forward(torch.stack([EF._load_pixels(p, 42) for p in paths]))
+    got = PL.c_score_from_tower(a, extract, str(tmp_path), batch=3)
+    np.testing.assert_allclose(got[:3], want[:3], atol=1e-7)
+    np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in got[3]]), np.stack([r["src_kpts_pred"] for r in want[3]]), atol=0.5)
