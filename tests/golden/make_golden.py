@@ -779,6 +779,44 @@ def gen_text():
     np.savez_compressed(f"{HERE}/text_tiny.npz", **out)
 
 
+# ----------------------------------------------------------------------------- AC policy
+def gen_policy():
+    """policy/fit.py (exec'd with its two hard-coded paths replaced), policy/validate_run.py (imported likewise) and one subset size
+    of the policy/prediction.py search, on the reference's own data table policy/ablations_t.csv.  The fixture keeps the numeric
+    columns the policy reads (13 models x (8 benchmarks + 8 A scores + C score)) and what the reference computed from them."""
+    import contextlib
+    import io
+    import pandas as pd
+    csv = f"{REF}/policy/ablations_t.csv"
+    df = pd.read_csv(csv)
+    from law_of_vision_representation_in_mllms_amd.policy import fit as PF
+    cols = ["model"] + PF.BENCHMARKS + [f"{b}_average" for b in PF.BENCHMARKS] + ["corres"]
+    out = {f"col.{c}": (df[c].to_numpy().astype(str) if c == "model" else df[c].to_numpy(np.float64)) for c in cols}
+    for data, model in (("AC", "polynomial"), ("A", "polynomial"), ("C", "linear"), ("AC", "linear")):
+        src = open(f"{REF}/policy/fit.py").read().replace("/Users/shijiayang/Desktop/Vision_Feature_AC_private/visualizations/ablations_t.csv", csv)
+        src = src.replace("/Users/shijiayang/Desktop/Vision_Feature_AC_private/visualizations/{args.file_name}.csv", "/tmp/{args.file_name}.csv")
+        buf = io.StringIO()
+        argv, sys.argv = sys.argv, ["fit.py", "--data", data, "--model", model, "--file_name", "visrep_policy_tmp"]
+        try:
+            with contextlib.redirect_stdout(buf):
+                exec(compile(src, "fit.py", "exec"), {"__name__": "__main__"})
+        finally:
+            sys.argv = argv
+        r2 = {ln.split()[0]: float(ln.split()[1]) for ln in buf.getvalue().splitlines() if ln.split() and ln.split()[0] in PF.BENCHMARKS}
+        out[f"fit.{data}.{model}"] = np.array([r2[b] for b in PF.BENCHMARKS])
+    vsrc = open(f"{REF}/policy/validate_run.py").read().replace("/Users/shijiayang/Desktop/Vision_Feature_AC_private/visualizations/ablations_t.csv", csv)
+    ns = {}
+    exec(compile(vsrc, "validate_run.py", "exec"), ns)
+    cases = [("mme", ("CLIP224", "DINOv2", "SD1.5", "SigLIP", "SDXL", "DiT", "OpenCLIP"), 3), ("ok_vqa", tuple(PF.ALL_MODELS[:9]), 1),
+             ("seed_image", tuple(PF.ALL_MODELS[2:]), 2)]
+    for i, (b, tm, top) in enumerate(cases):
+        ok, picked = ns["validate_run"](b, list(tm), top)
+        out[f"val.{i}.benchmark"], out[f"val.{i}.train"], out[f"val.{i}.top"] = np.array(b), np.array(tm), np.array(top)
+        out[f"val.{i}.ok"], out[f"val.{i}.picked"] = np.array(bool(ok)), np.array(picked.to_list())
+    np.savez_compressed(f"{HERE}/policy.npz", **out)
+    print("policy.npz  R2(AC, poly):", np.round(out["fit.AC.polynomial"], 4))
+
+
 # ----------------------------------------------------------------------------- projector
 def gen_projector():
     ph = types.ModuleType("ref_proj.perceiver_helpers")
@@ -810,7 +848,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy}[w]()
