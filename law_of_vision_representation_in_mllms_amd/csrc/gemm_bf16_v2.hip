@@ -96,12 +96,25 @@ VR_DEV void barrier() {
 }
 
 struct TileWalk {           // the block's list of output tiles: chunk of its XCD, strided by the blocks of that XCD
-    int start, stride, count, ntn;
+    int start, stride, count, ntn, ntm;
+    // Tile order.  The ~32 blocks of an XCD work on ~32 CONSECUTIVE tile indices at any moment and share that XCD's L2, so the
+    // set of operand panels behind a window of 32 indices should be small.  Row-major order gives 2 A panels + 16 W panels for
+    // N = 4096 (fc1: W is re-fetched for every pair of row panels - 2.3 GB of its 2.85 GB HBM reads, profiles/round1_traffic.md);
+    // walking R x 8 blocks (R = 4 row panels x 8 column panels) needs 4 + 8.  For ntn <= 8 both orders coincide.
     VR_DEV void decode(int i, int& m0, int& n0) const {
         const int ii = i < count ? i : count - 1;        // past-the-end loads re-read the last tile (never consumed)
         const int t = start + ii * stride;
-        m0 = (t / ntn) * TM;
-        n0 = (t % ntn) * TN;
+        if (ntn > 8 && (ntn & 7) == 0) {
+            const int R = 4, c = 8;
+            const int sr = t / (R * ntn), u = t - sr * R * ntn;
+            const int rl = min(R, ntm - sr * R);          // the last super-row may be shorter
+            const int cg = u / (rl * c), v = u - cg * rl * c;
+            m0 = (sr * R + v / c) * TM;
+            n0 = (cg * c + v % c) * TN;
+        } else {
+            m0 = (t / ntn) * TM;
+            n0 = (t % ntn) * TN;
+        }
     }
 };
 
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
         tw.stride = per;
         tw.count = j < csize ? (csize - j + per - 1) / per : 0;
         tw.ntn = ntn;
+        tw.ntm = ntm;
     }
     if (tw.count == 0) return;                                 // uniform per block: no barrier has been executed yet
     const int nk = p.K / TK;
