@@ -34,7 +34,7 @@ PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # HBM bytes per fc1 launch at batch 256 with the default (v2) GEMM, from rocprofv3 PMC passes of this kernel at this shape
 # (profiles/round1_traffic.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md "HBM", both calibrated on layernorm_rows' known byte count).  Algorithmic bytes are 1.52e9.
-FC1_HBM_BYTES_PER_LAUNCH = {(2, 256): 4.058e9}
+FC1_HBM_BYTES_PER_LAUNCH = {(2, 256): 3.126e9}
 
 
 def flops_per_image(spec, n_layers):
