@@ -17,6 +17,19 @@ def _round_up(v: int, a: int) -> int:
     return (v + a - 1) // a * a
 
 
+_SCRATCH = {}
+
+
+def ensure_scratch(device, nbytes: int = 32 << 20) -> None:
+    """One process-wide split-K scratch for visrep_gemm_bf16 (visrep_set_scratch): few-tile problems - the 128x128 tail
+    launches of the ViT GEMMs, the low-resolution convolutions of the diffusion towers - split their K loop over idle CUs.
+    S * M * N * 4 bytes <= 16.8 MB by construction of the split rule (S * tiles <= 256 CUs, 128x128 tiles)."""
+    if "buf" not in _SCRATCH:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(_lib.require_gpu().visrep_set_scratch(_lib.ptr(buf), nbytes), "visrep_set_scratch")
+        _SCRATCH["buf"] = buf
+
+
 class VitEngine:
     """One ViT tower on one GPU.
 
@@ -33,6 +46,7 @@ class VitEngine:
             raise ValueError("HIP attention kernel supports head_dim 64 only")
         if spec.d % 128 or spec.mlp % 128:
             raise ValueError("d and mlp must be multiples of 128")
+        ensure_scratch(self.device)
         self.kpad = _round_up(3 * spec.patch * spec.patch, 64)
         self._keep = []          # device tensors referenced by raw pointers
         dev = self.device

@@ -24,24 +24,12 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
-from .engine import gemm, layernorm, linear_vt
+from .engine import _SCRATCH, ensure_scratch, gemm, layernorm, linear_vt  # noqa: F401 (re-exported)
 from .sd_weights import SdSpec, up_block_plan
 
 
 def _ru(v: int, a: int) -> int:
     return (v + a - 1) // a * a
-
-
-_SCRATCH = {}
-
-
-def ensure_scratch(device, nbytes: int = 32 << 20) -> None:
-    """One process-wide split-K scratch for visrep_gemm_bf16 (visrep_set_scratch): S * M * N * 4 bytes <= 16.8 MB by
-    construction of the split rule (S * tiles <= 256 CUs, 128x128 tiles)."""
-    if "buf" not in _SCRATCH:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _lib.check(_lib.require_gpu().visrep_set_scratch(_lib.ptr(buf), nbytes), "visrep_set_scratch")
-        _SCRATCH["buf"] = buf
 
 
 # ------------------------------------------------------------------------------------------------ thin op wrappers
