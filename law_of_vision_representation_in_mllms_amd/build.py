@@ -31,6 +31,15 @@ def build_ablation_lib() -> str:
     return out
 
 
+def build_attn_ablation_lib(mask: int) -> str:
+    """Library with -DVISREP_ATTN_ABLATE=mask (tools/attn_ablate.py only; results are wrong for mask != 0)."""
+    out = os.path.join(PKG, f"libvisrep_hip_attn{mask}.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + [f"-DVISREP_ATTN_ABLATE={mask}"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB

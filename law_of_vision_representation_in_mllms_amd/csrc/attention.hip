@@ -27,6 +27,13 @@
 #include "common.h"
 #include "visrep_internal.h"
 
+// Timing-only ablation builds (-DVISREP_ATTN_ABLATE=mask, tools/attn_ablate.py): results are WRONG for mask != 0.
+//   1: no v_exp (p = the FMA result)   2: no P.V MFMAs   4: no Q.K^T MFMAs   8: no LDS fragment reads (registers reused)
+//   16: no per-tile barrier / next-tile DMA (tile 0 is re-used)
+#ifndef VISREP_ATTN_ABLATE
+#define VISREP_ATTN_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int KT = 64;                    // keys per tile
@@ -96,8 +103,8 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
         const int cur = it & 1;
-        if (it + 1 < ntile) stage(cur ^ 1, it + 1);
-        const char* sk = smem + cur * STAGE_B;
+        if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage(cur ^ 1, it + 1);
+        const char* sk = smem + ((VISREP_ATTN_ABLATE & 16) ? 0 : cur) * STAGE_B;
         const char* sv = sk + KV_B;
 
         // ---- S^T tiles: s[kt2] = K[kt2*32.., :] . Q^T
@@ -107,8 +114,10 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
         for (int kk = 0; kk < 4 * ND; ++kk) {
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + (kk >> 2) * TILE_B + kt2 * 4096 + rbase + (((2 * (kk & 3) + hi) ^ rsw) << 4));
-                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt2], 0, 0, 0);
+                const bf16x8 kf = (VISREP_ATTN_ABLATE & 8) ? qf[(kk + kt2) % (4 * ND)]
+                    : *reinterpret_cast<const bf16x8*>(sk + (kk >> 2) * TILE_B + kt2 * 4096 + rbase + (((2 * (kk & 3) + hi) ^ rsw) << 4));
+                if (!(VISREP_ATTN_ABLATE & 4)) s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt2], 0, 0, 0);
+                else s[kt2][kk & 15] += (float)kf[0];
             }
         }
         // ---- mask (first / last tile of the image only), running max on the RAW scores; the softmax scale is folded
@@ -135,8 +144,9 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r], p.sc, -msc));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r + 1], p.sc, -msc));
+                const float a0 = __builtin_fmaf(s[kt2][r], p.sc, -msc), a1 = __builtin_fmaf(s[kt2][r + 1], p.sc, -msc);
+                const float p0 = (VISREP_ATTN_ABLATE & 1) ? a0 : __builtin_amdgcn_exp2f(a0);
+                const float p1 = (VISREP_ATTN_ABLATE & 1) ? a1 : __builtin_amdgcn_exp2f(a1);
                 psum += p0 + p1;
                 pb[kt2][r >> 1] = pack_bf16(p0, p1);
             }
@@ -161,11 +171,13 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
             }
 #pragma unroll
             for (int dt = 0; dt < 2 * ND; ++dt) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + (dt >> 1) * TILE_B + (dt & 1) * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                const bf16x8 vf = (VISREP_ATTN_ABLATE & 8) ? qf[(c + dt) % (4 * ND)]
+                    : *reinterpret_cast<const bf16x8*>(sv + (dt >> 1) * TILE_B + (dt & 1) * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
+                if (!(VISREP_ATTN_ABLATE & 2)) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                else o[dt][c] += (float)vf[0] + (float)pf[1];
             }
         }
-        __syncthreads();
+        if (!(VISREP_ATTN_ABLATE & 16)) __syncthreads();
     }
 
     // ---- normalise and store: lane holds O[q][d = dt*32 + 8*rg + 4*hi + (0..3)]
