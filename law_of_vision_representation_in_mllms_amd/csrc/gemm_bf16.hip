@@ -251,9 +251,10 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (g_visrep_scratch && a.epi != EPI_VT && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0) {
         const int ncu = cu_count();
         const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-        if (tiles * 2 <= ncu) {
+        // the 128x128 kernel keeps two blocks per CU resident: 2 * ncu block slots; fill them when the tiles alone do not
+        if (tiles < 2L * ncu) {
             const int kt = a.K / BK;
-            int S = (int)(ncu / tiles);
+            int S = (int)(2L * ncu / tiles);
             if (S > kt / 4) S = kt / 4;                                   // at least 4 K-tiles per slice
             while (S > 1 && kt % S) --S;
             if (S > 1 && (size_t)S * a.M * a.N * sizeof(float) <= g_visrep_scratch_bytes) {

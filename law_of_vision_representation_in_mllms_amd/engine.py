@@ -20,10 +20,10 @@ def _round_up(v: int, a: int) -> int:
 _SCRATCH = {}
 
 
-def ensure_scratch(device, nbytes: int = 32 << 20) -> None:
+def ensure_scratch(device, nbytes: int = 64 << 20) -> None:
     """One process-wide split-K scratch for visrep_gemm_bf16 (visrep_set_scratch): few-tile problems - the 128x128 tail
     launches of the ViT GEMMs, the low-resolution convolutions of the diffusion towers - split their K loop over idle CUs.
-    S * M * N * 4 bytes <= 16.8 MB by construction of the split rule (S * tiles <= 256 CUs, 128x128 tiles)."""
+    S * M * N * 4 bytes <= 33.6 MB by construction of the split rule (S * tiles <= 2 * 256 block slots, 128x128 tiles)."""
     if "buf" not in _SCRATCH:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _lib.check(_lib.require_gpu().visrep_set_scratch(_lib.ptr(buf), nbytes), "visrep_set_scratch")
