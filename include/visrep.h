@@ -71,6 +71,16 @@ int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float
 int visrep_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int rows, int d, float eps,
                      void* stream);
 
+/* ---- LayerNorm folded into a GEMM.  visrep_layernorm_stats only READS x and writes rt[row] = (rstd, -mean * rstd) (float2 per row;
+ * allocate round_up(rows, 128) + 8 entries, zero past `rows`); visrep_gemm_bf16_ln then computes, for A = the RAW rows x and
+ * W = gamma o W_orig,   C[m, n] = epilogue( rt[m].x * (A W^T)[m, n] + rt[m].y * ln_s[n] + bias[n] )
+ * which equals Linear(LayerNorm(x)) when ln_s[n] = sum_k W[n, k] and bias = W_orig beta + b.  epilogue: VISREP_EPI_BIAS, _ACT or _VT.
+ * The normalised activations are never written to HBM (the reference materialises them: HF nn.LayerNorm before every
+ * attention / MLP block, e.g. modeling_clip.py CLIPEncoderLayer.forward). */
+int visrep_layernorm_stats(const void* x, int ldx, void* rt, int rows, int d, float eps, void* stream);
+int visrep_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* ln_rt, const float* ln_s, void* C,
+                        int ldc, int M, int N, int K, int epilogue, int act, void* stream);
+
 /* ---- multi-head self-attention forward (HF CLIPAttention / Dinov2SelfAttention / SiglipAttention: softmax(QK^T
  * scale) V, fp32 softmax).  qk: [B*T, 2*H*64] bf16 (Q | K, head-major columns); vt: V^T as written by
  * visrep_gemm_bf16(..., VISREP_EPI_VT): [H*64, ldvt] with ldvt >= round_up(B*T, 64), % 64 == 0, columns beyond B*T
@@ -104,6 +114,9 @@ typedef struct {
 typedef struct {           /* device pointers; matrices bf16 [out,in], vectors fp32; ls1/ls2 NULL when no LayerScale */
     const float *ln1_g, *ln1_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo; const float* ls1;
     const float *ln2_g, *ln2_b; const void* w1; const float* b1; const void* w2; const float* b2; const float* ls2;
+    /* LayerNorm folded into the consuming GEMMs (both non-NULL to enable; ln*_g / ln*_b are then unused): wqkv = gamma1 o Wqkv and
+     * bqkv = Wqkv beta1 + b (likewise w1 / b1 with LN2), sqkv[n] = sum_k wqkv[n, k] over the bf16-rounded rows [3d], s1 [mlp]. */
+    const float *sqkv, *s1;
 } visrep_vit_layer;
 typedef struct {
     const void* patch_w;   /* bf16 [d, kpad], zero padded past 3*p*p */

@@ -23,7 +23,7 @@ class VitConfig(C.Structure):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ls1", "ln2_g", "ln2_b", "w1", "b1",
-                                          "w2", "b2", "ls2")]
+                                          "w2", "b2", "ls2", "sqkv", "s1")]
 
 
 class VitWeights(C.Structure):
@@ -43,6 +43,8 @@ SIGNATURES = {
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "visrep_set_scratch": (_i, [_vp, _sz]),
+    "visrep_layernorm_stats": (_i, [_vp, _i, _vp, _i, _i, _f, _vp]),
+    "visrep_gemm_bf16_ln": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_attention_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "visrep_groupnorm_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),

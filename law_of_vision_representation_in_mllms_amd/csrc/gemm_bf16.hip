@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
         const float4 v = *reinterpret_cast<const float4*>(part + s * plane + (size_t)m * p.N + n);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    if (p.ln_rt) {                                             // LayerNorm folded into the GEMM: rstd * (acc - mean * s)
+        const float2 rt = p.ln_rt[m];
+        const float4 sv = *reinterpret_cast<const float4*>(p.ln_s + n);
+        acc.x = __builtin_fmaf(acc.x, rt.x, rt.y * sv.x); acc.y = __builtin_fmaf(acc.y, rt.x, rt.y * sv.y);
+        acc.z = __builtin_fmaf(acc.z, rt.x, rt.y * sv.z); acc.w = __builtin_fmaf(acc.w, rt.x, rt.y * sv.w);
+    }
     if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
@@ -261,7 +267,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 GemmArgs part = a;
                 part.C = reinterpret_cast<bf16_t*>(g_visrep_scratch);
                 part.ldc = a.N;
-                part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr;
+                part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr; part.ln_rt = nullptr; part.ln_s = nullptr;
                 part.kslice = a.K / S;
                 const int rc = a.conv ? launch<EPI_F32, true>(part, s) : launch<EPI_F32>(part, s);
                 if (rc) return rc;
@@ -289,6 +295,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 else if (a.epi == EPI_F32) tail.C = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(a.C) + (size_t)m1 * a.ldc);
                 else tail.C = a.C + (size_t)m1 * a.ldc;
                 if (a.resid) tail.resid = a.resid + (size_t)m1 * a.ldc;
+                if (a.ln_rt) tail.ln_rt = a.ln_rt + m1;
                 const int rc = dispatch_one(head, s, variant);
                 return rc ? rc : dispatch_one(tail, s, 1);
             }

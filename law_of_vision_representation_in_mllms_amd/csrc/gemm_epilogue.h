@@ -26,10 +26,10 @@ VR_DEV void drain_visible_loads() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // v
 
 template <typename ACC> struct AccGeom { static constexpr int QN = sizeof(ACC) / 16, RBLK = QN == 1 ? 16 : 32; };
 
-template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, typename ACC>
+template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK, NC = NJ * QN;   // NC column groups of 4 per lane
-    float4 bv[NC], lv[HAS_LS ? NC : 1];
+    float4 bv[NC], lv[(HAS_LS || HAS_LN) ? NC : 1];           // lv: LayerScale gamma, or the LN column sums s[n]
 #pragma unroll
     for (int c = 0; c < NC; ++c) bv[c] = float4{0.f, 0.f, 0.f, 0.f};
     auto col = [&](int c) { return nb + (c / QN) * RBLK + (c % QN) * 8 + hg * 4; };
@@ -40,6 +40,16 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
     if (HAS_LS) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) lv[c] = *reinterpret_cast<const float4*>(p.ls + col(c));
+    }
+    float2 rt_all[HAS_LN ? NI : 1];                          // LN: (rstd, -mean * rstd) of every row of this lane, loaded up front
+    if (HAS_LN) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) lv[c] = *reinterpret_cast<const float4*>(p.ln_s + col(c));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = mb + i * RBLK + fr;
+            rt_all[i] = p.ln_rt[(EDGE && m >= p.M) ? p.M - 1 : m];
+        }
     }
     drain_visible_loads();
     // rows are processed in groups of RB: all residual / position loads of a group are issued before its first store
@@ -80,8 +90,16 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int j = c / QN, q = c % QN, n = col(c);
-                float v0 = acc[i][j][4 * q + 0] + bv[c].x, v1 = acc[i][j][4 * q + 1] + bv[c].y;
-                float v2 = acc[i][j][4 * q + 2] + bv[c].z, v3 = acc[i][j][4 * q + 3] + bv[c].w;
+                float v0, v1, v2, v3;
+                if (HAS_LN) {       // rstd * (acc - mean * s) + bias'
+                    v0 = __builtin_fmaf(acc[i][j][4 * q + 0], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].x, bv[c].x));
+                    v1 = __builtin_fmaf(acc[i][j][4 * q + 1], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].y, bv[c].y));
+                    v2 = __builtin_fmaf(acc[i][j][4 * q + 2], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].z, bv[c].z));
+                    v3 = __builtin_fmaf(acc[i][j][4 * q + 3], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].w, bv[c].w));
+                } else {
+                    v0 = acc[i][j][4 * q + 0] + bv[c].x; v1 = acc[i][j][4 * q + 1] + bv[c].y;
+                    v2 = acc[i][j][4 * q + 2] + bv[c].z; v3 = acc[i][j][4 * q + 3] + bv[c].w;
+                }
                 if (EPI == EPI_ACT) {
                     v0 = apply_act(v0, ACT); v1 = apply_act(v1, ACT); v2 = apply_act(v2, ACT); v3 = apply_act(v3, ACT);
                 }
@@ -107,11 +125,14 @@ template <int EPI, int NI, int NJ, int ACT, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     const bool interior = mb + NI * AccGeom<ACC>::RBLK <= p.M;
     if (EPI == EPI_RESID && p.ls) {                          // LayerScale towers (DINOv2): its own path keeps the others lean
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false>(p, acc, mb, nb, fr, hg);
+    } else if ((EPI == EPI_BIAS || EPI == EPI_ACT) && p.ln_rt) {   // LayerNorm folded into this GEMM
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true>(p, acc, mb, nb, fr, hg);
     } else {
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false>(p, acc, mb, nb, fr, hg);
     }
 }
 
@@ -130,31 +151,71 @@ VR_DEV void gemm_epilogue_rowmajor(const GemmArgs& p, const ACC (&acc)[NI][NJ], 
 }
 
 // V^T scatter: vt[n * ldc + perm16(m)], four consecutive tokens per 8-byte store (layout: see attention.hip)
-template <int NI, int NJ, typename ACC>
-VR_DEV void gemm_epilogue_vt(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+template <int NI, int NJ, bool HAS_LN, typename ACC>
+VR_DEV void gemm_epilogue_vt_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK;
-    float bj[NJ];
+    float bj[NJ], sj[HAS_LN ? NJ : 1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bj[j] = 0.f;
     if (p.bias) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bj[j] = p.bias[nb + j * RBLK + fr];
     }
-    drain_visible_loads();
+    if (HAS_LN) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        bf16_t* colp = p.C + (size_t)(nb + j * RBLK + fr) * p.ldc;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int q = 0; q < QN; ++q) {
-                const int m = mb + i * RBLK + q * 8 + hg * 4;                       // multiple of 4
-                if (m < p.M) {                                                       // columns >= M are never read unmasked
-                    const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-token groups 1 <-> 2
-                    u32x2 v = {pack_bf16(acc[i][j][4 * q + 0] + bj[j], acc[i][j][4 * q + 1] + bj[j]),
-                               pack_bf16(acc[i][j][4 * q + 2] + bj[j], acc[i][j][4 * q + 3] + bj[j])};
-                    store_b64(colp + mp, v);
-                }
-            }
+        for (int j = 0; j < NJ; ++j) sj[j] = p.ln_s[nb + j * RBLK + fr];
     }
+    drain_visible_loads();
+    // LN statistics of the tokens this lane stores (four consecutive m per (i, q); the buffer is padded and zero past M) are
+    // loaded for half of the row blocks at a time: all at once costs 64 VGPRs on top of the live accumulators (spills)
+    constexpr int IH = (HAS_LN && NI >= 4) ? NI / 2 : NI;
+#pragma unroll
+    for (int i0 = 0; i0 < NI; i0 += IH) {
+        float4 ra[HAS_LN ? IH * QN : 1], rb[HAS_LN ? IH * QN : 1];
+        if (HAS_LN) {
+#pragma unroll
+            for (int i = 0; i < IH; ++i)
+#pragma unroll
+                for (int q = 0; q < QN; ++q) {
+                    const int m = mb + (i0 + i) * RBLK + q * 8 + hg * 4;
+                    const float4* src = reinterpret_cast<const float4*>(p.ln_rt + m);
+                    ra[i * QN + q] = src[0];                // (rstd0, t0, rstd1, t1)
+                    rb[i * QN + q] = src[1];                // (rstd2, t2, rstd3, t3)
+                }
+            drain_visible_loads();
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bf16_t* colp = p.C + (size_t)(nb + j * RBLK + fr) * p.ldc;
+#pragma unroll
+            for (int ii = 0; ii < IH; ++ii)
+#pragma unroll
+                for (int q = 0; q < QN; ++q) {
+                    const int i = i0 + ii;
+                    const int m = mb + i * RBLK + q * 8 + hg * 4;                       // multiple of 4
+                    if (m < p.M) {                                                       // columns >= M are never read unmasked
+                        const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-token groups 1 <-> 2
+                        float v0, v1, v2, v3;
+                        if (HAS_LN) {
+                            const float4 a4 = ra[ii * QN + q], b4 = rb[ii * QN + q];
+                            v0 = __builtin_fmaf(acc[i][j][4 * q + 0], a4.x, __builtin_fmaf(a4.y, sj[j], bj[j]));
+                            v1 = __builtin_fmaf(acc[i][j][4 * q + 1], a4.z, __builtin_fmaf(a4.w, sj[j], bj[j]));
+                            v2 = __builtin_fmaf(acc[i][j][4 * q + 2], b4.x, __builtin_fmaf(b4.y, sj[j], bj[j]));
+                            v3 = __builtin_fmaf(acc[i][j][4 * q + 3], b4.z, __builtin_fmaf(b4.w, sj[j], bj[j]));
+                        } else {
+                            v0 = acc[i][j][4 * q + 0] + bj[j]; v1 = acc[i][j][4 * q + 1] + bj[j];
+                            v2 = acc[i][j][4 * q + 2] + bj[j]; v3 = acc[i][j][4 * q + 3] + bj[j];
+                        }
+                        u32x2 v = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                        store_b64(colp + mp, v);
+                    }
+                }
+        }
+    }
+}
+
+template <int NI, int NJ, typename ACC>
+VR_DEV void gemm_epilogue_vt(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    if (p.ln_rt) gemm_epilogue_vt_impl<NI, NJ, true>(p, acc, mb, nb, fr, hg);
+    else gemm_epilogue_vt_impl<NI, NJ, false>(p, acc, mb, nb, fr, hg);
 }

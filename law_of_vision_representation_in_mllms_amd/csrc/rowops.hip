@@ -59,6 +59,43 @@ __global__ __launch_bounds__(256) void layernorm_rows(const bf16_t* __restrict__
     }
 }
 
+// LayerNorm statistics only: rt[row] = (rstd, -mean * rstd).  The normalisation itself is folded into the consuming GEMM
+// (gamma into its weights, the mean / rstd terms into its epilogue: visrep_gemm_bf16_ln), so the normalised tensor is never
+// written: this pass only READS the residual stream.  One wave per row, same two-pass fp32 statistics as layernorm_rows.
+__global__ __launch_bounds__(256) void layernorm_stats_rows(const bf16_t* __restrict__ x, int ldx, float2* __restrict__ rt, int M, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = d >> 3;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float f[4][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f[c][2 * k] = bf_lo(v[k]); f[c][2 * k + 1] = bf_hi(v[k]); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += f[c][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[c][k] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < nch) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float t = f[c][k] - mean; sq += t * t; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
+    if (lane == 0) rt[row] = float2{rstd, -mean * rstd};
+}
+
 // ------------------------------------------------------------------------------------------------ im2col
 // pixels [B, 3, H, W] (fp32 or bf16) -> cols [B*gh*gw, Kpad] bf16 with k = c*p*p + i*p + j (Conv2d weight order),
 // zero-filled for k >= 3*p*p.  One thread per 8 output elements (16-B store).
@@ -117,6 +154,13 @@ extern "C" int visrep_layernorm(const void* x, int ldx, const float* gamma, cons
     hipLaunchKernelGGL(layernorm_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, gamma, beta,
                        (bf16_t*)y, ldy, rows, d, eps);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "layernorm: launch failed");
+}
+
+extern "C" int visrep_layernorm_stats(const void* x, int ldx, void* rt, int rows, int d, float eps, void* stream) {
+    if (rows <= 0) return 0;
+    if (d % 8 || d > 2048 || (ldx % 8)) return visrep_set_error(VISREP_ERR_SHAPE, "layernorm_stats: need d % 8 == 0, d <= 2048");
+    hipLaunchKernelGGL(layernorm_stats_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (float2*)rt, rows, d, eps);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "layernorm_stats: launch failed");
 }
 
 extern "C" int visrep_im2col(const void* pixels, int pixel_dtype, void* cols, int B, int Himg, int Wimg, int patch, int Kpad,

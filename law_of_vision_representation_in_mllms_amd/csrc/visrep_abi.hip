@@ -62,6 +62,17 @@ extern "C" int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     return visrep_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+extern "C" int visrep_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* ln_rt, const float* ln_s,
+                                   void* C, int ldc, int M, int N, int K, int epilogue, int act, void* stream) {
+    if (!A || !W || !C || !ln_rt || !ln_s) return visrep_set_error(VISREP_ERR_ARG, "gemm_ln: null pointer");
+    if (epilogue != VISREP_EPI_BIAS && epilogue != VISREP_EPI_ACT && epilogue != VISREP_EPI_VT)
+        return visrep_set_error(VISREP_ERR_ARG, "gemm_ln: epilogue must be BIAS, ACT or VT");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.ln_rt = (const float2*)ln_rt; a.ln_s = ln_s;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.epi = epilogue; a.act = act;
+    return visrep_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc,
                                    int Cout, int stride, int pad_mode, int upsample, int epilogue, const void* resid, void* stream) {
     if (!x || !Wt || !out) return visrep_set_error(VISREP_ERR_ARG, "conv3x3: null pointer");
@@ -86,7 +97,7 @@ extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, co
 namespace {
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Ws {
-    size_t h, qk, vt, mlp, total;
+    size_t h, qk, vt, mlp, rt, total;
     int ldvt;
 };
 Ws layout(const visrep_vit_config* c, int B) {
@@ -101,6 +112,7 @@ Ws layout(const visrep_vit_config* c, int B) {
     const size_t mlp_b = Mp * c->mlp * 2;
     const size_t cols_b = up((size_t)B * (c->tokens - c->has_cls), 128) * c->kpad * 2;
     w.mlp = off; off += up(mlp_b > cols_b ? mlp_b : cols_b, 256);   // im2col columns alias the MLP buffer
+    w.rt = off;  off += up((Mp + 8) * sizeof(float2), 256);         // folded-LayerNorm row statistics (zero past M)
     w.total = off;
     return w;
 }
@@ -145,27 +157,46 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
     // V^T columns past B*T are read (with zero softmax weight) by the last key tile: keep them finite
     if (hipMemsetAsync(vt, 0, (size_t)d * L.ldvt * 2, s) != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward: memset failed");
 
+    float2* rt = (float2*)(base + L.rt);
+    if (hipMemsetAsync(rt, 0, (up(M, 128) + 8) * sizeof(float2), s) != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward: memset failed");
+
     const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
     for (int l = 0; l < n_layers; ++l) {
         const visrep_vit_layer& W = w->layers[l];
-        VR_TRY(visrep_layernorm(x, d, W.ln1_g, W.ln1_b, h, d, M, d, c->eps, stream));
+        const bool fold = W.sqkv && W.s1;     // LayerNorm folded into the QK / V / fc1 GEMMs: only its statistics are computed
         GemmArgs a{};
-        a.A = h; a.lda = d; a.K = d; a.M = M;
+        if (fold) {
+            VR_TRY(visrep_layernorm_stats(x, d, rt, M, d, c->eps, stream));
+            a.A = x; a.ln_rt = rt; a.ln_s = W.sqkv;
+        } else {
+            VR_TRY(visrep_layernorm(x, d, W.ln1_g, W.ln1_b, h, d, M, d, c->eps, stream));
+            a.A = h;
+        }
+        a.lda = d; a.K = d; a.M = M;
         // Q | K projection
         a.W = (const bf16_t*)W.wqkv; a.ldw = d; a.N = 2 * d; a.C = qk; a.ldc = 2 * d; a.bias = W.bqkv; a.epi = EPI_BIAS;
         VR_TRY(visrep_gemm_dispatch(a, s));
         // V projection written transposed + perm16 for the attention kernel
         a.W = (const bf16_t*)W.wqkv + (size_t)2 * d * d; a.N = d; a.C = vt; a.ldc = L.ldvt; a.bias = W.bqkv + 2 * d; a.epi = EPI_VT;
+        if (fold) a.ln_s = W.sqkv + 2 * d;
         VR_TRY(visrep_gemm_dispatch(a, s));
         VR_TRY(visrep_mhsa_fwd(qk, 2 * d, vt, L.ldvt, h, d, B, T, c->heads, 64, scale, stream));
         // out projection + LayerScale + residual (in place on x)
+        a.A = h; a.ln_rt = nullptr; a.ln_s = nullptr;
         a.W = (const bf16_t*)W.wo; a.N = d; a.C = x; a.ldc = d; a.bias = W.bo; a.epi = EPI_RESID; a.resid = x; a.ls = W.ls1;
         VR_TRY(visrep_gemm_dispatch(a, s));
-        VR_TRY(visrep_layernorm(x, d, W.ln2_g, W.ln2_b, h, d, M, d, c->eps, stream));
         GemmArgs f{};
-        f.A = h; f.lda = d; f.K = d; f.M = M; f.W = (const bf16_t*)W.w1; f.ldw = d; f.N = c->mlp; f.C = mlp; f.ldc = c->mlp;
+        if (fold) {
+            VR_TRY(visrep_layernorm_stats(x, d, rt, M, d, c->eps, stream));
+            f.A = x; f.ln_rt = rt; f.ln_s = W.s1;
+        } else {
+            VR_TRY(visrep_layernorm(x, d, W.ln2_g, W.ln2_b, h, d, M, d, c->eps, stream));
+            f.A = h;
+        }
+        f.lda = d; f.K = d; f.M = M; f.W = (const bf16_t*)W.w1; f.ldw = d; f.N = c->mlp; f.C = mlp; f.ldc = c->mlp;
         f.bias = W.b1; f.epi = EPI_ACT; f.act = c->act;
         VR_TRY(visrep_gemm_dispatch(f, s));
+        f.ln_rt = nullptr; f.ln_s = nullptr;
         f.A = mlp; f.lda = c->mlp; f.K = c->mlp; f.W = (const bf16_t*)W.w2; f.ldw = c->mlp; f.N = d; f.C = x; f.ldc = d;
         f.bias = W.b2; f.epi = EPI_RESID; f.act = 0; f.resid = x; f.ls = W.ls2;
         VR_TRY(visrep_gemm_dispatch(f, s));

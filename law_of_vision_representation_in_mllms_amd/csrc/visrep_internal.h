@@ -17,6 +17,10 @@ struct GemmArgs {
     const bf16_t* resid;  // EPI_RESID: residual rows (may alias C)
     const float* ls;      // EPI_RESID: optional LayerScale gamma [N]
     const float* pos;     // EPI_PATCH: position embedding [tokens, N] fp32
+    // LayerNorm folded into the GEMM (EPI_BIAS / EPI_ACT / EPI_VT): A is the RAW residual stream, W = gamma o W_orig,
+    // C = rstd[m] * (A W^T - mean[m] * s[n]) + bias'[n] with ln_rt[m] = (rstd, -mean * rstd), ln_s[n] = sum_k W[n, k]
+    const float2* ln_rt;  // [M] per-row statistics (visrep_layernorm_stats) or null
+    const float* ln_s;    // [N]
     int M, N, K, lda, ldw, ldc;
     int epi, act;
     int patches, tokens, cls_off;   // EPI_PATCH row remap

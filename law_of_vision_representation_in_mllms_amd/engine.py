@@ -38,8 +38,15 @@ class VitEngine:
     `output_hidden_states=True` convention the reference towers index with `select_layer`).
     """
 
-    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None):
+    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, fuse_ln: Optional[bool] = None):
+        """fuse_ln (default off; VISREP_FUSE_LN=1 turns it on): fold every block's LayerNorm into the GEMMs that consume it -
+        gamma into the weight rows, beta into the bias, the per-row mean / rstd into the GEMM epilogue
+        (visrep_layernorm_stats + the ln_rt / ln_s epilogue) - so the normalised activations are never written to HBM.
+        Measured +0.3 % on the ViT-L/14-336 forward (the read-only statistics pass and the heavier epilogues eat most of the
+        saved write), so it stays opt-in until the statistics come out of the preceding residual GEMM's epilogue."""
         self.lib = _lib.require_gpu()
+        import os
+        self.fuse_ln = (os.environ.get("VISREP_FUSE_LN", "0") == "1") if fuse_ln is None else bool(fuse_ln)
         self.spec = spec
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         if spec.d != spec.heads * 64:
@@ -72,12 +79,26 @@ class VitEngine:
         n = len(weights["layers"])
         self.n_layers = n
         self._layers = (_lib.VitLayer * max(n, 1))()
+        def fold(Wm, bias, g, b):
+            """Linear(LayerNorm(x)) = rstd * (x (g o W)^T - mean * s) + (W b + bias): (g o W in bf16, s over the ROUNDED rows, b')."""
+            Wb = Wm.detach().float().to(torch.bfloat16).float()               # the weights the unfused path multiplies with
+            Wf = (Wb * g.detach().float()[None]).to(torch.bfloat16)
+            return Wf, Wf.float().sum(1), Wb @ b.detach().float() + bias.detach().float()
+
         for i, L in enumerate(weights["layers"]):
             ent = self._layers[i]
+            L = dict(L)
+            extra = {"sqkv": None, "s1": None}
+            if self.fuse_ln:
+                L["wqkv"], extra["sqkv"], L["bqkv"] = fold(L["wqkv"], L["bqkv"], L["ln1_g"], L["ln1_b"])
+                L["w1"], extra["s1"], L["b1"] = fold(L["w1"], L["b1"], L["ln2_g"], L["ln2_b"])
             for k in ("wqkv", "wo", "w1", "w2"):
                 setattr(ent, k, mat(L[k]).data_ptr())
             for k in ("ln1_g", "ln1_b", "bqkv", "bo", "ls1", "ln2_g", "ln2_b", "b1", "b2", "ls2"):
                 v = vec(L.get(k))
+                setattr(ent, k, 0 if v is None else v.data_ptr())
+            for k, t in extra.items():
+                v = vec(t)
                 setattr(ent, k, 0 if v is None else v.data_ptr())
         self._w = _lib.VitWeights()
         self._w.patch_w = self._patch_w.data_ptr()

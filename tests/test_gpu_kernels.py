@@ -110,6 +110,42 @@ def test_gemm_v2_many_tiles_per_block_and_reuse(gemm_variant):
         assert max_err(out, want) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(577 * 3, 512, 256, "bias"), (300, 256, 1024, "act"), (1000, 1024, 256, "vt"), (70000, 256, 1024, "bias"),
+                                        (256, 2048, 1024, "act")])
+def test_gemm_with_folded_layernorm(M, N, K, epi, gemm_variant):
+    """Linear(LayerNorm(x)) from the RAW rows: gamma folded into W, mean / rstd applied in the epilogue (incl. split-K tails)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = bf(torch.randn(M, K, generator=g) * 2 + torch.randn(M, 1, generator=g))          # rows with their own mean
+    gam, bet = torch.randn(K, generator=g) * 0.3 + 1, torch.randn(K, generator=g) * 0.2
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).float()
+    bias = torch.randn(N, generator=g) * 0.1
+    want = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet, 1e-5) @ W.t() + bias
+    Wf = bf(W * gam[None])
+    s, bp = Wf.float().sum(1), W @ bet + bias
+    lib = _lib.load()
+    engine.ensure_scratch(torch.device(DEV))
+    xd, Wd, sd, bd = x.to(DEV), Wf.to(DEV), s.to(DEV), bp.to(DEV)
+    rt = torch.zeros((M + 127) // 128 * 128 + 8, 2, dtype=torch.float32, device=DEV)
+    _lib.check(lib.visrep_layernorm_stats(_lib.ptr(xd), K, _lib.ptr(rt), M, K, 1e-5, _lib.stream_ptr()), "stats")
+    mu, var = x.float().mean(1), x.float().var(1, unbiased=False)
+    assert torch.allclose(rt[:M, 0].cpu(), (var + 1e-5).rsqrt(), rtol=1e-5) and torch.allclose(rt[:M, 1].cpu(), -mu * (var + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+    if epi == "vt":
+        ld = (M + 63) // 64 * 64 + 64
+        out = torch.zeros(N, ld, dtype=torch.bfloat16, device=DEV)
+        rc = lib.visrep_gemm_bf16_ln(_lib.ptr(xd), K, _lib.ptr(Wd), K, _lib.ptr(bd), _lib.ptr(rt), _lib.ptr(sd), _lib.ptr(out), ld, M, N, K, _lib.EPI_VT, 0,
+                                     _lib.stream_ptr())
+        _lib.check(rc, "gemm_ln")
+        ref = engine.linear_vt(bf(torch.nn.functional.layer_norm(x.float(), (K,), gam, bet, 1e-5)).to(DEV), bf(W).to(DEV), bias.to(DEV))
+        assert rel_err(out[:, :M], ref[:, :M]) < 6e-3                   # same perm16 layout as the unfused V^T projection
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act = "gelu" if epi == "act" else "none"
+        rc = lib.visrep_gemm_bf16_ln(_lib.ptr(xd), K, _lib.ptr(Wd), K, _lib.ptr(bd), _lib.ptr(rt), _lib.ptr(sd), _lib.ptr(out), N, M, N, K,
+                                     _lib.EPI_ACT if epi == "act" else _lib.EPI_BIAS, _lib.ACT[act], _lib.stream_ptr())
+        _lib.check(rc, "gemm_ln")
+        assert rel_err(out, ref_act(want, act)) < 6e-3
+
+
 def test_gemm_rejects_bad_shapes():
     a = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(100, 64, dtype=torch.bfloat16, device=DEV)
@@ -182,6 +218,19 @@ def test_tower_matches_reference_golden(tag, gemm_variant):
     ref_bf16 = OV.tower_features(spec, w, px, -2, "cls_patch" if spec.family == "siglip" else "patch", dtype=torch.bfloat16)
     e_hip, e_ref = rel_err(feat, want), rel_err(ref_bf16, want)
     assert e_hip < max(2.0 * e_ref, 1e-2), (tag, e_hip, e_ref)
+
+
+def test_tower_folded_layernorm_equals_unfolded_and_reference():
+    for tag in VIT_HIP_TAGS:
+        spec, w, px, want = load_vit_hip_case(tag)
+        a = engine.VitEngine(spec, w, DEV, fuse_ln=True).forward(px.to(DEV))
+        b = engine.VitEngine(spec, w, DEV, fuse_ln=False).forward(px.to(DEV))
+        assert rel_err(a, b) < 1e-2, tag
+        n = spec.layers - 1                                                  # and against the reference golden, like the default path
+        feat = engine.VitEngine(spec, w, DEV, fuse_ln=True).forward(px.to(DEV), n_layers=n)
+        feat = feat[:, 1:] if spec.family != "siglip" else feat
+        ref_bf16 = OV.tower_features(spec, w, px, -2, "cls_patch" if spec.family == "siglip" else "patch", dtype=torch.bfloat16)
+        assert rel_err(feat, want) < max(2.0 * rel_err(ref_bf16, want), 1e-2), tag
 
 
 def test_tower_all_hidden_states_and_batch_invariance(gemm_variant):
