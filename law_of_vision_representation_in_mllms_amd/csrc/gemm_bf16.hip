@@ -246,36 +246,43 @@ int cu_count() {
 }
 }  // namespace
 
+namespace {
+// Few output tiles but a deep reduction (3x3 convolutions of the diffusion towers at 12x12 / 24x24 resolution: M = 144 .. 576,
+// K = 9 * 1280 .. 9 * 2560; the 128x128 tail launches of the ViT GEMMs): a handful of CUs would walk K serially.  Split K over
+// blockIdx.y into fp32 planes in the caller's scratch (visrep_set_scratch) and reduce them in slice order with the epilogue
+// fused.  Returns 1 when the problem was handled this way, 0 when it was not eligible, < 0 on error.
+int try_split_k(const GemmArgs& a, hipStream_t s) {
+    if (!(g_visrep_scratch && a.epi != EPI_VT && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
+    const int ncu = cu_count();
+    const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    // the 128x128 kernel keeps two blocks per CU resident: 2 * ncu block slots; fill them when the tiles alone do not
+    if (tiles >= 2L * ncu) return 0;
+    const int kt = a.K / BK;
+    int S = (int)(2L * ncu / tiles);
+    if (S > kt / 4) S = kt / 4;                                   // at least 4 K-tiles per slice
+    while (S > 1 && kt % S) --S;
+    if (S <= 1 || (size_t)S * a.M * a.N * sizeof(float) > g_visrep_scratch_bytes) return 0;
+    GemmArgs part = a;
+    part.C = reinterpret_cast<bf16_t*>(g_visrep_scratch);
+    part.ldc = a.N;
+    part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr; part.ln_rt = nullptr; part.ln_s = nullptr;
+    part.kslice = a.K / S;
+    const int rc = a.conv ? launch<EPI_F32, true>(part, s) : launch<EPI_F32>(part, s);
+    if (rc) return rc;
+    const long nthreads = (long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+    return hipGetLastError() == hipSuccess ? 1 : visrep_set_error(VISREP_ERR_LAUNCH, "gemm: split-K reduce launch failed");
+}
+}  // namespace
+
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
     if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
     const int variant = g_visrep_gemm_variant;
-    // Few output tiles but a deep reduction (3x3 convolutions of the diffusion towers at 12x12 / 24x24 resolution:
-    // M = 144 .. 576, K = 9 * 1280 .. 9 * 2560): a handful of CUs would walk K serially.  Split K over blockIdx.y into fp32
-    // planes in the caller's scratch (visrep_set_scratch) and reduce them in slice order with the epilogue fused.
-    if (g_visrep_scratch && a.epi != EPI_VT && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0) {
-        const int ncu = cu_count();
-        const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-        // the 128x128 kernel keeps two blocks per CU resident: 2 * ncu block slots; fill them when the tiles alone do not
-        if (tiles < 2L * ncu) {
-            const int kt = a.K / BK;
-            int S = (int)(2L * ncu / tiles);
-            if (S > kt / 4) S = kt / 4;                                   // at least 4 K-tiles per slice
-            while (S > 1 && kt % S) --S;
-            if (S > 1 && (size_t)S * a.M * a.N * sizeof(float) <= g_visrep_scratch_bytes) {
-                GemmArgs part = a;
-                part.C = reinterpret_cast<bf16_t*>(g_visrep_scratch);
-                part.ldc = a.N;
-                part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr; part.ln_rt = nullptr; part.ln_s = nullptr;
-                part.kslice = a.K / S;
-                const int rc = a.conv ? launch<EPI_F32, true>(part, s) : launch<EPI_F32>(part, s);
-                if (rc) return rc;
-                const long nthreads = (long)a.M * (a.N / 4);
-                hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
-                return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "gemm: split-K reduce launch failed");
-            }
-        }
+    {
+        const int sk = try_split_k(a, s);
+        if (sk) return sk < 0 ? sk : 0;
     }
     // Tile quantisation: the persistent 256x256 kernels run one block per CU, so T tiles cost ceil(T / CUs) tile-times.
     // The BASELINE shapes have M = 256 * 577 (577 is prime): 2308 / 4616 / 9232 tiles = 9 / 18 / 36 full rounds + a 4..16-tile
@@ -297,7 +304,9 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 if (a.resid) tail.resid = a.resid + (size_t)m1 * a.ldc;
                 if (a.ln_rt) tail.ln_rt = a.ln_rt + m1;
                 const int rc = dispatch_one(head, s, variant);
-                return rc ? rc : dispatch_one(tail, s, 1);
+                if (rc) return rc;
+                const int sk = try_split_k(tail, s);                     // the tail has few tiles: split its K loop when it pays
+                return sk ? (sk < 0 ? sk : 0) : dispatch_one(tail, s, 1);
             }
         }
     }
