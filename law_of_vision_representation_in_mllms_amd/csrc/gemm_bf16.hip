@@ -143,6 +143,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     else gemm_epilogue_rowmajor<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
 
+// split-K reduction for the V^T epilogue: thread = (4 consecutive tokens m, one feature n); vt[n * ldc + perm16(m)]
+__global__ __launch_bounds__(256) void splitk_reduce_vt(const float* __restrict__ part, int S, const GemmArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int mq = (p.M + 3) >> 2;
+    if (idx >= (long)mq * p.N) return;
+    const int n = (int)(idx % p.N), m = (int)(idx / p.N) * 4;   // n fastest: coalesced reads of the fp32 planes
+    const size_t plane = (size_t)p.M * p.N;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (m + e < p.M) {
+            float a = part[(size_t)(m + e) * p.N + n];
+            for (int s = 1; s < S; ++s) a += part[s * plane + (size_t)(m + e) * p.N + n];
+            if (p.ln_rt) { const float2 rt = p.ln_rt[m + e]; a = __builtin_fmaf(a, rt.x, rt.y * p.ln_s[n]); }
+            v[e] = a + (p.bias ? p.bias[n] : 0.f);
+        }
+    }
+    const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // perm16: swap 4-token groups 1 <-> 2
+    u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p.C + (size_t)n * p.ldc + mp) = o;
+}
+
 template <int EPI, bool CONV = false>
 int launch(const GemmArgs& a, hipStream_t s) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
@@ -252,7 +274,7 @@ namespace {
 // blockIdx.y into fp32 planes in the caller's scratch (visrep_set_scratch) and reduce them in slice order with the epilogue
 // fused.  Returns 1 when the problem was handled this way, 0 when it was not eligible, < 0 on error.
 int try_split_k(const GemmArgs& a, hipStream_t s) {
-    if (!(g_visrep_scratch && a.epi != EPI_VT && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
+    if (!(g_visrep_scratch && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
     const int ncu = cu_count();
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     // the 128x128 kernel keeps two blocks per CU resident: 2 * ncu block slots; fill them when the tiles alone do not
@@ -269,8 +291,13 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
     part.kslice = a.K / S;
     const int rc = a.conv ? launch<EPI_F32, true>(part, s) : launch<EPI_F32>(part, s);
     if (rc) return rc;
-    const long nthreads = (long)a.M * (a.N / 4);
-    hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+    if (a.epi == EPI_VT) {
+        const long nthreads = (long)((a.M + 3) / 4) * a.N;
+        hipLaunchKernelGGL(splitk_reduce_vt, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+    } else {
+        const long nthreads = (long)a.M * (a.N / 4);
+        hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+    }
     return hipGetLastError() == hipSuccess ? 1 : visrep_set_error(VISREP_ERR_LAUNCH, "gemm: split-K reduce launch failed");
 }
 }  // namespace
