@@ -50,8 +50,8 @@ class HipMLPProjector(nn.Sequential):
         ws, bs = self._pack(x.device)
         shp = x.shape
         for w in ws:
-            if w.shape[0] % 128 or w.shape[1] % 64:
-                raise ValueError("projector widths must be multiples of 128 (outputs) / 64 (inputs) for the MFMA GEMM")
+            if w.shape[0] % 64 or w.shape[1] % 64:
+                raise ValueError("projector widths must be multiples of 64 for the MFMA GEMM")
         h = x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
         n = len(ws)
         for i, (w, b) in enumerate(zip(ws, bs)):
