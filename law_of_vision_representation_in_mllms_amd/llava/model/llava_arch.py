@@ -103,11 +103,14 @@ class VisionEncoderStack(nn.Module):
 
 
 class _CfgView:
-    """Per-tower view of the model config: same attributes, `mm_vision_tower` narrowed to one id."""
+    """Per-tower view of the model config: same attributes, `mm_vision_tower` / `vision_tower` narrowed to one id
+    (the reference rewrites config.mm_vision_tower - and config.vision_tower for the diffusion towers - per tower,
+    llava_arch.py:61-84; DiffVisionTower reads args.vision_tower, diffusion_encoder.py:52)."""
 
     def __init__(self, base, name):
         object.__setattr__(self, "_b", base)
         object.__setattr__(self, "mm_vision_tower", name)
+        object.__setattr__(self, "vision_tower", name)
 
     def __getattr__(self, k):
         return getattr(object.__getattribute__(self, "_b"), k)

@@ -65,6 +65,13 @@ def test_delay_load_gives_config_only_tower():
     assert t2.select_feature == 'cls_patch' and t2.hidden_size == 768 and t2.num_patches == 196
 
 
+def test_cfg_view_narrows_both_tower_names():
+    base = SimpleNamespace(mm_vision_tower="openai/clip-vit-large-patch14.runwayml/stable-diffusion-v1-5", vision_tower="whatever", t=261, img_size=768)
+    v = LA._CfgView(base, "runwayml/stable-diffusion-v1-5")
+    assert v.mm_vision_tower == v.vision_tower == "runwayml/stable-diffusion-v1-5" and v.t == 261 and v.img_size == 768
+    assert LA.VisionEncoderStack._split(base.mm_vision_tower) == ["openai/clip-vit-large-patch14", "runwayml/stable-diffusion-v1-5"]
+
+
 def test_fusion_id_splitting():
     s = LA.VisionEncoderStack._split
     assert s('openai/clip-vit-large-patch14-336.facebook/dinov2-large') == ['openai/clip-vit-large-patch14-336', 'facebook/dinov2-large']
