@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 
     stage(0, 0);
     __syncthreads();
+    if (qt * 128 + wave * 32 >= p.Tq) {
+        // this wave's 32 query rows are all past the sequence (the last query tile of T = 577 has 65 rows: wave 3 is empty):
+        // it only keeps staging its quarter of the K / V^T tiles and meeting the barriers, and leaves its SIMD to other blocks
+        for (int it = 0; it < ntile; ++it) {
+            if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage((it & 1) ^ 1, it + 1);
+            if (!(VISREP_ATTN_ABLATE & 16)) __syncthreads();
+        }
+        return;
+    }
     for (int it = 0; it < ntile; ++it) {
         const int cur = it & 1;
         if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage(cur ^ 1, it + 1);
