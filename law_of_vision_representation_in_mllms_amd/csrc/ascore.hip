@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntt = (p.Nt + A_BM - 1) / A_BM;
-    const int img = blockIdx.x / ntt, tt = blockIdx.x - img * ntt;
+    // XCD-aware: the row tiles of one image (they all stream the same reference rows) must share an L2, i.e. run on ONE XCD;
+    // hardware round-robins consecutive workgroups over the 8 XCDs, so consecutive LOGICAL blocks are remapped onto one XCD
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int img = bid / ntt, tt = bid - img * ntt;
     const bf16_t* other = reinterpret_cast<const bf16_t*>(p.other) + (size_t)img * p.Nt * p.D;
     const bf16_t* ref = reinterpret_cast<const bf16_t*>(p.ref) + (size_t)img * p.Nr * p.D;
     const float* cr = p.c_ref + (size_t)img * p.Nr;
@@ -212,6 +215,9 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
             const int cur = kt & 1;
             if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
             const char* sb = smem + cur * A_STAGE;
+            // edge tiles: a wave whose 64 target rows or 64 reference columns lie entirely past the end (Nt = 576 = 4.5 tiles: half
+            // of the last row / column tile) skips its fragment reads and MFMAs; it still stages and meets the barriers
+            if (m0 + wm * 64 < p.Nt && n0 + wn * 64 < p.Nr)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 xa[4], xr[4];
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
     __syncthreads();
     if (lane == 0) red[512 + wave] = v;
     __syncthreads();
-    if (tid == 0) p.partial[blockIdx.x] = red[512] + red[513] + red[514] + red[515];
+    if (tid == 0) p.partial[bid] = red[512] + red[513] + red[514] + red[515];
 }
 
 template <typename T>
