@@ -46,3 +46,9 @@ def test_compute_paths_fail_loudly_without_gpu():
     from law_of_vision_representation_in_mllms_amd import ascore_ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ascore_ops.max_cos_mean(torch.zeros(1, 4, 16), torch.zeros(1, 4, 16))
+
+
+def test_graft_entry_build_runs_without_gpu():
+    """The driver's "does it build" hook: compiles (or finds up to date) the gfx950 library, loads it, checks the ABI version."""
+    import __graft_entry__ as g
+    g.build()
