@@ -139,10 +139,12 @@ int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, 
  * C_score/pck_train.py:24-29 normalize_feats): feats = bank of [C, P*P] fp32 maps; per pair image indices, source
  * patch indices [n_pairs,kmax] (kmax <= 32), keypoint counts; lin = float32(np.linspace(-1,1,P)); xy [n_pairs,kmax,2].
  * split = 0: one encoder (pck_train.py); split = C1 > 0: channels [0,C1) and [C1,C) are two encoders normalised separately,
- * concatenated and normalised again (C_score/pck_train_two.py:24-36 normalize_feats). */
+ * concatenated and normalised again (C_score/pck_train_two.py:24-36 normalize_feats).
+ * layout = 0: maps are [C, P*P] (the reference's on-disk [1, C, P, P]); layout = 1: [P*P, C], the towers' own token layout - a
+ * keypoint's descriptor is then one contiguous row (C and split multiples of 4). */
 int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
                            const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window, int soft_eval,
-                           float beta, float anno_stride, float anno_half, void* stream);
+                           float beta, float anno_stride, float anno_half, int layout, void* stream);
 /* per-pair PCK hit counts (C_score/pck_train.py:101,149-163): kps1/kps2 [n_pairs,kmax,3] (x,y,vis) fp32, thresholds
  * fp64 [n_pairs], alphas3 = HOST pointer to 3 floats; counts int32 [n_pairs,4] = hits@a0,a1,a2, n_visible. */
 int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp, int n_pairs,

@@ -107,6 +107,11 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     else:
         bank_t, slot = bank[0], bank[1]
         split = int(bank[2]) if len(bank) > 2 else 0
+    layout = bank[3] if bank is not None and len(bank) > 3 else "cp"
+    if layout == "cp" and bank_t.shape[1] % 4 == 0 and split % 4 == 0:
+        # position-major [n, P^2, C]: a keypoint's descriptor becomes one contiguous row (see csrc/cscore.hip); one transpose of
+        # the category's bank replaces a strided line gather per (pair, keypoint, channel)
+        bank_t, layout = bank_t.transpose(1, 2).contiguous(), "pc"
     kps = kps.float()
     K = kps.shape[1]
     if K > 32:
@@ -120,7 +125,7 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     sl = slice(lo, hi)
     xy = cscore_ops.transfer(bank_t, torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy()),
                              torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW, soft_eval=bool(args.SOFT_EVAL),
-                             anno_size=args.ANNO_SIZE, split=split)
+                             anno_size=args.ANNO_SIZE, split=split, layout=layout)
     alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)
     if thresholds is not None:
         thr = torch.tensor(thresholds, dtype=torch.float64)

@@ -16,17 +16,23 @@ def lin_table(P: int, device) -> torch.Tensor:
 
 @torch.no_grad()
 def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_idx: torch.Tensor, nkp: torch.Tensor, P: int,
-             window: int = 5, soft_eval: bool = True, beta: float = 0.02, anno_size: int = 840, split: int = 0) -> torch.Tensor:
+             window: int = 5, soft_eval: bool = True, beta: float = 0.02, anno_size: int = 840, split: int = 0,
+             layout: str = "cp") -> torch.Tensor:
     """Keypoint transfer for a batch of pairs.
 
     bank [n_images, C, P*P] fp32 (the reference's on-disk [1, C, P, P] maps, flattened); img1/img2/nkp int32 [n];
     patch_idx int32 [n, kmax] (kmax <= 32).  Returns xy fp32 [n, kmax, 2] in the annotation frame.
     split > 0: the bank holds two encoders concatenated on the channel axis ([0, split) and [split, C)), normalised
     separately, concatenated and re-normalised (pck_train_two.py:24-36).
+    layout "pc": bank is position-major [n_images, P*P, C] - the towers' own [N, C] token layout; a keypoint's descriptor is one
+    contiguous row, which is what the kernel wants (C and split multiples of 4).
     """
     lib = _lib.require_gpu()
-    if bank.dtype != torch.float32 or bank.dim() != 3 or bank.shape[2] != P * P:
-        raise ValueError("bank must be fp32 [n_images, C, P*P]")
+    if layout not in ("cp", "pc"):
+        raise ValueError("layout must be 'cp' ([n, C, P*P]) or 'pc' ([n, P*P, C])")
+    if bank.dtype != torch.float32 or bank.dim() != 3 or bank.shape[2 if layout == "cp" else 1] != P * P:
+        raise ValueError("bank must be fp32 [n_images, C, P*P] (layout 'cp') or [n_images, P*P, C] (layout 'pc')")
+    C_ = bank.shape[1 if layout == "cp" else 2]
     bank = bank.contiguous()
     n, kmax = patch_idx.shape
     dev = bank.device
@@ -35,8 +41,8 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     xy = torch.zeros(n, kmax, 2, dtype=torch.float32, device=dev)
     stride = anno_size / P
     rc = lib.visrep_cscore_transfer(_lib.ptr(bank), _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(patch_idx), _lib.ptr(nkp),
-                                    _lib.ptr(lin_table(P, dev)), _lib.ptr(xy), n, kmax, P, bank.shape[1], int(split), int(window), int(soft_eval),
-                                    float(beta), float(stride), float(stride // 2), _lib.stream_ptr())
+                                    _lib.ptr(lin_table(P, dev)), _lib.ptr(xy), n, kmax, P, C_, int(split), int(window), int(soft_eval),
+                                    float(beta), float(stride), float(stride // 2), 0 if layout == "cp" else 1, _lib.stream_ptr())
     _lib.check(rc, "visrep_cscore_transfer")
     return xy
 

@@ -11,6 +11,10 @@
 //            the [C, P^2] fp32 feature maps (128-B coalesced per half wave); squared norms of both operands are
 //            accumulated from the same registers, so normalisation costs no extra HBM pass.
 //            Each wave owns 32-target tiles; HBM traffic per pair = both maps once = 2 * P^2 * C * 4 B.
+//            Layout 1 (position-major [P^2, C], the towers' own token layout): a keypoint's descriptor is one contiguous row, so
+//            the source gather reads K * C * 4 B instead of K * C cache LINES (with [C, P^2] every (channel, keypoint) element
+//            sits in its own 128-B line: 2.6 MB of line traffic per pair against 1 MB for the whole target map, and each wave
+//            repeats it per tile); each lane streams 64 contiguous bytes of its row per step, a lane pair a full line.
 //   phase B  per keypoint row (one wave each): first-index argmax, clamped (2w+1)^2 window, entries outside the
 //            window are ZERO (not -inf) and stay in the softmax (reference semantics), beta = 0.02,
 //            expectation over linspace(-1,1,P), un-normalise, clamp, scale to the annotation frame.
@@ -22,7 +26,7 @@
 namespace {
 
 struct CArgs {
-    const float* feats;            // feature bank [n_images][C][P*P] fp32
+    const float* feats;            // feature bank [n_images][C][P*P] fp32 (layout 0) or [n_images][P*P][C] (layout 1)
     const int* img1; const int* img2;   // per pair image index into the bank
     const int* patch_idx;          // [n_pairs][kmax] source patch index per keypoint
     const int* nkp;                // [n_pairs] keypoints in this pair (<= 32)
@@ -32,6 +36,7 @@ struct CArgs {
     float beta, stride, half;      // anno_size / P, floor(stride / 2)
 };
 
+template <bool PM>                 // PM: position-major bank [P^2, C]
 __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int PP = p.P * p.P;
@@ -51,11 +56,43 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     const int ntile = (PP + 31) >> 5;
     const bool two = p.split > 0;
     const int c_mid = two ? p.split : p.C;
-    const float* a_ptr = F1 + (size_t)hi * PP + sk;
+    const float* a_ptr = PM ? F1 + (size_t)sk * p.C : F1 + (size_t)hi * PP + sk;
     float fa = 0.f, fb = 0.f;             // per keypoint (lane lq): source-side factors of the two channel blocks
     bool first = true;
     auto gram = [&](int c0, int c1, const float* bp, f32x16& acc, float& n1, float& n2) {
         int c = c0;
+        if (PM) {
+            // 32 channels per step: lane (lq, hi) streams channels [c + 16 hi, c + 16 hi + 16) of ITS row as four float4; the MFMA
+            // k-pair of step (u, e) is (c + 4u + e, c + 16 + 4u + e) - any pairing is fine as long as both operands use it
+            const float* ar = a_ptr + 16 * hi;
+            const float* br = bp + 16 * hi;
+            for (; c + 32 <= c1; c += 32) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = *reinterpret_cast<const float4*>(ar + c + 4 * u);
+                    b[u] = *reinterpret_cast<const float4*>(br + c + 4 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bw[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        n1 += av[e] * av[e];
+                        n2 += bw[e] * bw[e];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bw[e], acc, 0, 0, 0);
+                    }
+                }
+            }
+            for (; c < c1; c += 2) {                         // fewer than 32 channels left: one k-pair (c, c + 1) per MFMA
+                const float a = a_ptr[c + hi];
+                const float b = bp[c + hi];
+                n1 += a * a;
+                n2 += b * b;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            return;
+        }
         for (; c + 16 <= c1; c += 16) {                  // 16 independent loads in flight per lane before the MFMA chain
             float a[8], b[8];
 #pragma unroll
@@ -81,7 +118,7 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     for (int tile = wave; tile < ntile; tile += 4) {
         const int t = tile * 32 + lq;
         const int tc = t < PP ? t : PP - 1;
-        const float* b_ptr = F2 + (size_t)hi * PP + tc;
+        const float* b_ptr = PM ? F2 + (size_t)tc * p.C : F2 + (size_t)hi * PP + tc;
         f32x16 acc_a = f32x16{}, acc_b = f32x16{};
         float n1a = 0.f, n1b = 0.f, n2a = 0.f, n2b = 0.f;
         gram(0, c_mid, b_ptr, acc_a, n1a, n2a);
@@ -197,19 +234,23 @@ __global__ void cscore_pck(const float* __restrict__ xy, const float* __restrict
 
 extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
                                       const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window,
-                                      int soft_eval, float beta, float anno_stride, float anno_half, void* stream) {
+                                      int soft_eval, float beta, float anno_stride, float anno_half, int layout, void* stream) {
     if (n_pairs <= 0) return 0;
+    if (layout != 0 && layout != 1) return visrep_set_error(VISREP_ERR_ARG, "cscore: layout must be 0 ([C, P*P]) or 1 ([P*P, C])");
+    if (layout == 1 && ((C & 3) || (split & 3))) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: the position-major layout needs C and split to be multiples of 4");
     if (kmax <= 0 || kmax > 32) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: kmax must be in 1..32");
     if (P <= 0 || P > 32 || C <= 0 || (C & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: need 1 <= P <= 32 and even C");
     if (split < 0 || split >= C || (split & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: split must be even and in [0, C)");
     CArgs a{feats, img1, img2, patch_idx, nkp, lin, xy, n_pairs, kmax, P, C, split, window, soft_eval, beta, anno_stride, anno_half};
     const size_t lds = sizeof(float) * ((size_t)32 * P * P);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
+    static size_t lds_set[2] = {0, 0};
+    if (lds > lds_set[layout]) {
+        if (layout) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set[layout] = lds;
     }
-    hipLaunchKernelGGL(cscore_transfer, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
+    if (layout) hipLaunchKernelGGL(cscore_transfer<true>, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cscore_transfer<false>, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "cscore_transfer: launch failed");
 }
 

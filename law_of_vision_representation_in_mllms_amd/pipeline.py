@@ -60,15 +60,15 @@ def a_scores_from_stacks(stacks: Dict[str, object], images: Sequence, batch: int
 
 
 def _to_map(f: torch.Tensor) -> torch.Tensor:
-    """tower tokens [B, N, C] or featurizer maps [B, C, h, w] -> [B, C, P^2] fp32."""
+    """tower tokens [B, N, C] (kept as they are) or featurizer maps [B, C, h, w] -> position-major [B, P^2, C] fp32."""
     if f.dim() == 3:
-        return f.permute(0, 2, 1).float()
-    return f.reshape(f.shape[0], f.shape[1], -1).float()
+        return f.float()
+    return f.reshape(f.shape[0], f.shape[1], -1).permute(0, 2, 1).float()
 
 
 @torch.no_grad()
 def feature_bank(extract: Callable[[Sequence[str]], torch.Tensor], files: Sequence[str], batch: int = 32):
-    """Distinct images of `files` -> ([n_img, C, P^2] fp32 device bank, per-file-slot bank index)."""
+    """Distinct images of `files` -> ([n_img, P^2, C] fp32 device bank in the towers' own token layout, per-file-slot bank index)."""
     uniq, slot = {}, []
     for f in files:
         if f not in uniq:
@@ -94,12 +94,15 @@ def c_score_from_tower(args, extract: Callable[[Sequence[str]], torch.Tensor], s
         split_c = 0
         if extract2 is not None:
             bank2, _ = feature_bank(extract2, files, batch)
-            split_c = bank.shape[1]
-            bank = torch.cat([bank, bank2], 1).contiguous()
-        if bank.shape[2] != args.NUM_PATCHES ** 2:
-            raise ValueError(f"feature maps have {bank.shape[2]} positions, NUM_PATCHES = {args.NUM_PATCHES}")
+            split_c = bank.shape[2]
+            bank = torch.cat([bank, bank2], 2).contiguous()
+        if bank.shape[1] != args.NUM_PATCHES ** 2:
+            raise ValueError(f"feature maps have {bank.shape[1]} positions, NUM_PATCHES = {args.NUM_PATCHES}")
+        layout = "pc"
+        if bank.shape[2] % 4 or split_c % 4:                      # channel counts the position-major kernel cannot take
+            bank, layout = bank.transpose(1, 2).contiguous(), "cp"
         pck, _, out_results, img_correct = PT._compute_pck(args, save_path, aggre_net, files, kps, cat, used_points,
-                                                           thresholds if args.BBOX_THRE else None, (bank, slot, split_c), models=("fused",))
+                                                           thresholds if args.BBOX_THRE else None, (bank, slot, split_c, layout), models=("fused",))
         total_out_results.extend(out_results)
         update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, pck, img_correct)
     pck_010, pck_005, pck_001 = log_weighted_pcks(args, PT.logger, pcks, pcks_05, pcks_01, weights)

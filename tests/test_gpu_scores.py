@@ -102,13 +102,15 @@ def test_cscore_vs_oracle_full_width(P, C):
     kps[:, :, :2] = rs.uniform(0, 839.9, (n_pairs, K, 2))
     nkp = rs.randint(3, K + 1, n_pairs).astype(np.int32)
     idx = np.stack([OC.kpts_to_patch_idx(torch.from_numpy(kps[i]), P) for i in range(n_pairs)]).astype(np.int32)
-    xy = cscore_ops.transfer(bank_t.to(DEV), torch.from_numpy(i1), torch.from_numpy(i2), torch.from_numpy(idx), torch.from_numpy(nkp), P)
-    xy = xy.cpu()
+    a = (torch.from_numpy(i1), torch.from_numpy(i2), torch.from_numpy(idx), torch.from_numpy(nkp), P)
+    xy = cscore_ops.transfer(bank_t.to(DEV), *a).cpu()
+    xy_pc = cscore_ops.transfer(bank_t.transpose(1, 2).contiguous().to(DEV), *a, layout="pc").cpu()       # towers' own [P^2, C] layout
     for i in range(n_pairs):
         d1 = OC.descriptors_from_map(bank_t[i1[i]].view(1, C, P, P), P)
         d2 = OC.descriptors_from_map(bank_t[i2[i]].view(1, C, P, P), P)
         want = OC.keypoint_transfer(d1, d2, idx[i][: nkp[i]], P)
         assert (xy[i, : nkp[i]] - want).abs().max().item() < 2e-2, i
+        assert (xy_pc[i, : nkp[i]] - want).abs().max().item() < 2e-2, i
 
 
 @pytest.mark.parametrize("P,C1,C2", [(16, 1024, 1024), (24, 1024, 1280), (16, 32, 24), (24, 1024, 2)])
@@ -132,6 +134,12 @@ def test_cscore_two_encoder_split_vs_oracle(P, C1, C2):
     args = (torch.from_numpy(i1), torch.from_numpy(i2), torch.from_numpy(idx), torch.from_numpy(nkp), P)
     xy = cscore_ops.transfer(bank_t.to(DEV), *args, split=C1).cpu()
     xy_one = cscore_ops.transfer(bank_t.to(DEV), *args).cpu()
+    if C1 % 4 == 0 and C % 4 == 0:
+        xy_pc = cscore_ops.transfer(bank_t.transpose(1, 2).contiguous().to(DEV), *args, split=C1, layout="pc").cpu()
+        assert (xy_pc - xy).abs().max().item() < 2e-2
+    else:
+        with pytest.raises(RuntimeError, match="multiples of 4"):
+            cscore_ops.transfer(bank_t.transpose(1, 2).contiguous().to(DEV), *args, split=C1, layout="pc")
     differs = False
     for i in range(n_pairs):
         d1 = OC.normalize_feats_two(bank_t[i1[i]].t()[None], C1)

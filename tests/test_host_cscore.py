@@ -21,20 +21,22 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 CATS = ("aeroplane", "cat")
 
 
-def cpu_descriptors(m, P, split=0):
-    """[C, P^2] raw map -> [1, P^2, C] descriptors, one encoder (pck_train.py) or two (pck_train_two.py)."""
+def cpu_descriptors(m, P, split=0, layout="cp"):
+    """[C, P^2] (or position-major [P^2, C]) raw map -> [1, P^2, C] descriptors, one encoder (pck_train.py) or two (pck_train_two.py)."""
+    if layout == "pc":
+        m = m.t()
     C = m.shape[0]
     if split == 0:
         return OC.descriptors_from_map(m.view(1, C, P, P), P)
     return OC.normalize_feats_two(m.view(1, C, P * P).permute(0, 2, 1), split)
 
 
-def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840, split=0):
+def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840, split=0, layout="cp"):
     n, kmax = patch_idx.shape
     out = torch.zeros(n, kmax, 2)
     for i in range(n):
-        d1 = cpu_descriptors(bank[int(img1[i])], P, split)
-        d2 = cpu_descriptors(bank[int(img2[i])], P, split)
+        d1 = cpu_descriptors(bank[int(img1[i])], P, split, layout)
+        d2 = cpu_descriptors(bank[int(img2[i])], P, split, layout)
         k = int(nkp[i])
         out[i, :k] = OC.keypoint_transfer(d1, d2, patch_idx[i, :k].numpy(), P, anno_size, soft_eval, window, beta)
     return out

@@ -39,12 +39,13 @@ for P in (16, 24):
     idx = torch.from_numpy(rs.randint(0, P * P, (n_pairs, 20)).astype(np.int32))
     kps = torch.rand(n_pairs, 20, 3) * 839; kps[:, :, 2] = 1
     thr = torch.from_numpy(rs.uniform(150, 700, n_pairs))
-    def run():
-        xy = cscore_ops.transfer(bank, i1, i2, idx, nkp, P)
-        return cscore_ops.pck_counts(xy, kps, kps, thr, nkp)
-    sec = timed(run)
     by = 2.0 * P * P * C * 4 * n_pairs
-    out[f"C.P{P}"] = {"pairs_per_s": round(n_pairs / sec, 1), "ms_all_pairs": round(sec * 1e3, 3), "alg_GB/s": round(by / sec / 1e9, 1),
-                      "frac_of_8TB/s": round(by / sec / 8e12, 4)}
-    del bank
+    for layout, bk in (("cp", bank), ("pc", bank.transpose(1, 2).contiguous())):
+        def run():
+            xy = cscore_ops.transfer(bk, i1, i2, idx, nkp, P, layout=layout)
+            return cscore_ops.pck_counts(xy, kps, kps, thr, nkp)
+        sec = timed(run)
+        out[f"C.P{P}.{layout}"] = {"pairs_per_s": round(n_pairs / sec, 1), "ms_all_pairs": round(sec * 1e3, 3), "alg_GB/s": round(by / sec / 1e9, 1),
+                                   "frac_of_8TB/s": round(by / sec / 8e12, 4)}
+    del bank, bk
 print(json.dumps(out, indent=1))
