@@ -117,7 +117,24 @@ def extract_features(image_path):
     return _to_maps(_state.dift.forward(px))
 
 
-def process_images(input_dir, output_dir):
+def _prefetched(chunks, load, workers):
+    """Yield (chunk, pixel batch) with JPEG decode (+ resize) of chunk i+1 running on a thread pool while the GPU works on chunk i
+    (PIL releases the GIL while decoding; the reference decodes, runs and saves one image at a time)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if workers <= 1 or not chunks:
+        for chunk in chunks:
+            yield chunk, torch.stack([load(p, _state.img_size) for p, _ in chunk])
+        return
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        submit = lambda chunk: [pool.submit(load, p, _state.img_size) for p, _ in chunk]
+        pending = submit(chunks[0])
+        for i, chunk in enumerate(chunks):
+            nxt = submit(chunks[i + 1]) if i + 1 < len(chunks) else None
+            yield chunk, torch.stack([f.result() for f in pending])
+            pending = nxt
+
+
+def process_images(input_dir, output_dir, workers=8):
     """Walks input_dir like the reference; towers run in batches (the reference runs batch 1), files are identical."""
     if _state.dift is None:
         configure(feature)
@@ -131,10 +148,9 @@ def process_images(input_dir, output_dir):
     d = torch.distributed
     if d.is_available() and d.is_initialized():
         todo = todo[d.get_rank()::d.get_world_size()]                        # image-sharded across ranks, no collective
-    for s in range(0, len(todo), _state.batch):
-        chunk = todo[s:s + _state.batch]
-        load = _load_pixels_device if getattr(_state, "device_preprocess", False) else _load_pixels
-        px = torch.stack([load(p, _state.img_size) for p, _ in chunk])
+    load = _load_pixels_device if getattr(_state, "device_preprocess", False) else _load_pixels
+    chunks = [todo[s:s + _state.batch] for s in range(0, len(todo), _state.batch)]
+    for chunk, px in _prefetched(chunks, load, 1 if getattr(_state, "device_preprocess", False) else workers):
         maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
         for (_, out), m in zip(chunk, maps):
             os.makedirs(os.path.dirname(out), exist_ok=True)

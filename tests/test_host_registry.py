@@ -133,3 +133,21 @@ def test_extract_feature_diffusion_dispatch_shapes(tmp_path, monkeypatch):
     assert t.shape == (1, 6, 3, 2) and torch.equal(t, one.permute(0, 1, 3, 2))
     with pytest.raises(KeyError):
         EF.configure("NOPE")
+
+
+def test_extract_feature_prefetch_keeps_order_and_pairs(monkeypatch):
+    """The decode pool hands batches back in walk order whatever the worker count (files must match the serial run)."""
+    import time
+    import torch
+    from law_of_vision_representation_in_mllms_amd.C_score import extract_feature as EF
+    monkeypatch.setattr(EF, "_state", SimpleNamespace(img_size=4, batch=3))
+
+    def load(path, size):
+        time.sleep(0.002 * (7 - path % 7))                   # later items finish first
+        return torch.full((2,), float(path))
+    chunks = [[(i, f"o{i}") for i in range(s, min(s + 3, 10))] for s in range(0, 10, 3)]
+    for workers in (1, 4):
+        got = list(EF._prefetched(chunks, load, workers))
+        assert [c for c, _ in got] == chunks
+        assert [px[:, 0].tolist() for _, px in got] == [[float(i) for i, _ in c] for c in chunks]
+    assert list(EF._prefetched([], load, 4)) == []
