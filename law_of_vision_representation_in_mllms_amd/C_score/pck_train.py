@@ -14,7 +14,8 @@ runs ONE keypoint-transfer launch and ONE PCK-count launch for all pairs of the 
 torch.distributed initialised the pairs of a category are sharded over ranks in contiguous blocks and the hit counters
 are all-reduced (RCCL) — per-image means stay exact because counts, not means, are reduced.
 
-Not built (fail loudly): training (`DO_EVAL` false), ADAPT_FLIP, COMPUTE_GEOAWARE_METRICS, pascal / ap10k.
+COMPUTE_GEOAWARE_METRICS (pck_train.py:68-80,169-192,231-243) reuses the count launch on the geometry-aware key points.
+Not built (fail loudly): training (`DO_EVAL` false), ADAPT_FLIP.
 """
 import argparse
 import os
@@ -25,9 +26,10 @@ import torch
 
 from .. import cscore_ops
 from .model_utils.projection_network import DummyAggregationNetwork
-from .utils.logger import get_logger, load_config, log_weighted_pcks, update_stats
+from .utils.logger import get_logger, load_config, log_geo_stats, log_weighted_pcks, update_geo_stats, update_stats
 from .utils.utils_correspondence import calculate_keypoint_transformation, kpts_to_patch_idx  # noqa: F401 (API parity)
 from .utils.utils_dataset import get_dataset_info, load_eval_data
+from .utils.utils_geoware import AP10K_GEO_AWARE, SPAIR_GEO_AWARE, filtered_groups, geo_aware_points, renumber_used_points
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 logger = get_logger()
@@ -59,10 +61,7 @@ def get_patch_descriptors(args, aggre_net, num_patches, files, pair_idx, flip=Fa
     return normalize_feats(args, img1_desc[0]), normalize_feats(args, img2_desc[0]), mask1, mask2
 
 
-def _renumber_used_points(kpts, idx):
-    out = torch.zeros(30, kpts.shape[1])
-    out[idx] = kpts
-    return out
+_renumber_used_points = renumber_used_points
 
 
 def _dist():
@@ -94,8 +93,9 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
 
 
 def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models):
-    if getattr(args, "ADAPT_FLIP", False) or getattr(args, "COMPUTE_GEOAWARE_METRICS", False):
-        raise NotImplementedError("ADAPT_FLIP / COMPUTE_GEOAWARE_METRICS are not built on the MI355X path yet (SURVEY §8f N4)")
+    if getattr(args, "ADAPT_FLIP", False):
+        raise NotImplementedError("ADAPT_FLIP is not built (the reference's get_distance only accepts 60x60 maps; SURVEY §8f N4)")
+    geo = bool(getattr(args, "COMPUTE_GEOAWARE_METRICS", False))
     P = args.NUM_PATCHES
     N = len(files) // 2
     dev = torch.device(device)
@@ -126,14 +126,29 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     xy = cscore_ops.transfer(bank_t, torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy()),
                              torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW, soft_eval=bool(args.SOFT_EVAL),
                              anno_size=args.ANNO_SIZE, split=split, layout=layout)
-    alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)
+    alphas = shown_alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)
     if thresholds is not None:
         thr = torch.tensor(thresholds, dtype=torch.float64)
-    else:   # alpha * ANNO_SIZE is a float32 product in the reference (pck_train.py:160): pre-round it per alpha is not
-        thr = torch.full((N,), float(args.ANNO_SIZE), dtype=torch.float64)    # expressible with one threshold; exact for 840
+    else:   # alpha * ANNO_SIZE is a float32 product in the reference (pck_train.py:160,222): hand the kernel that rounded
+        thr = torch.ones(N, dtype=torch.float64)                              # product as its alpha, with a unit threshold
+        alphas = tuple(float(np.float32(a) * np.float32(args.ANNO_SIZE)) for a in alphas)
     counts = cscore_ops.pck_counts(xy, k1[sl], k2[sl], thr[sl], nkp[sl], alphas)
-    cnt = torch.zeros(N, 4, dtype=torch.int32, device=counts.device)
-    cnt[sl] = counts
+    cnt = torch.zeros(N, 8 if geo else 4, dtype=torch.int32, device=counts.device)
+    cnt[sl, :4] = counts
+    if geo:
+        # geometry-aware subset (pck_train.py:68-80,169-192,231-243): the same count launch with every other key point's
+        # visibility cleared in the source annotation, so hits and totals are over the geo-aware points only
+        table = AP10K_GEO_AWARE if args.EVAL_DATASET == 'ap10k' else SPAIR_GEO_AWARE.get(category)
+        if table is None:
+            raise ValueError(f"no geometry-aware key point groups for category {category!r}")
+        groups = filtered_groups(table, (torch.arange(K) if used_points is None else used_points).tolist())
+        vis_all, vis2_all = (k1[:, :, 2] * k2[:, :, 2] > 0).numpy(), (k2[:, :, 2] > 0).numpy()
+        geo_mask = torch.zeros(N, K)
+        for i in range(N):
+            geo_mask[i, geo_aware_points(groups, vis_all[i], vis2_all[i])] = 1
+        k1g = k1.clone()
+        k1g[:, :, 2] *= geo_mask
+        cnt[sl, 4:] = cscore_ops.pck_counts(xy, k1g[sl], k2[sl], thr[sl], nkp[sl], alphas)
     pred = torch.zeros(N, K, 2, dtype=torch.float32, device=xy.device)
     pred[sl] = xy
     if d:
@@ -158,8 +173,21 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     correct.append(n_kpts)
     shown = correct[:3] if args.KPT_RESULT else img_correct[:3]
     if rank == 0:
-        logger.info(f'{category}...' + ' | '.join(f'PCK-Transfer@{a:.2f}: {v * 100:.2f}%' for a, v in zip(alphas, shown)))
-    return correct, [], out_results, img_correct
+        logger.info(f'{category}...' + ' | '.join(f'PCK-Transfer@{a:.2f}: {v * 100:.2f}%' for a, v in zip(_f32(shown_alphas), shown)))
+    geo_score = []
+    if geo:
+        n_geo = int(cnt[:, 7].sum())
+        geo_pairs = int((cnt[:, 7] > 0).sum())
+        correct_geo = (torch.from_numpy(cnt[:, 4:7].sum(0).astype(np.int64)) / n_geo).tolist()
+        geo_score = [geo_pairs / N, n_geo / n_kpts, *correct_geo, n_geo]
+        if rank == 0:
+            logger.info(' | '.join(f'PCK-Transfer_geo-aware@{a:.2f}: {v * 100:.2f}%' for a, v in zip(_f32(shown_alphas), correct_geo[:3])))
+            logger.info(f'Geo-aware occurance count: {geo_pairs}, with ratio {geo_pairs / N * 100:.2f}%; total count ratio {n_geo / n_kpts * 100:.2f}%')
+    return correct, geo_score, out_results, img_correct
+
+
+def _f32(alphas):
+    return torch.tensor(alphas).tolist()          # the reference prints alpha.tolist() of a float32 tensor
 
 
 def eval(args, aggre_net, save_path, split='val', _compute=None):
@@ -167,6 +195,8 @@ def eval(args, aggre_net, save_path, split='val', _compute=None):
     aggre_net.eval()
     data_dir, categories, split = get_dataset_info(args, split)
     total_out_results, pcks, pcks_05, pcks_01, weights, kpt_weights = ([] for _ in range(6))
+    geo = bool(getattr(args, "COMPUTE_GEOAWARE_METRICS", False))
+    geo_lists = [[] for _ in range(6)]
     for cat in categories:
         files, kps, thresholds, used_points = load_eval_data(args, data_dir, cat, split)
         compute_args = (save_path, aggre_net, files, kps, cat, used_points)
@@ -174,7 +204,11 @@ def eval(args, aggre_net, save_path, split='val', _compute=None):
                                                       else compute_pck_fn(args, *compute_args))
         total_out_results.extend(out_results)
         update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, pck, img_correct)
+        if geo:
+            update_geo_stats(*geo_lists, correct_geo)
     pck_010, pck_005, pck_001 = log_weighted_pcks(args, logger, pcks, pcks_05, pcks_01, weights)
+    if geo:
+        log_geo_stats(args, *geo_lists, kpt_weights, total_out_results)
     aggre_net.train()
     return pck_010, pck_005, pck_001, total_out_results
 

@@ -1,4 +1,4 @@
-"""Config / stats / log lines of the C score — C_score/utils/logger.py:8-72 without the loguru dependency."""
+"""Config / stats / log lines of the C score — C_score/utils/logger.py:8-98 without the loguru dependency."""
 import logging
 import sys
 
@@ -44,3 +44,23 @@ def log_weighted_pcks(args, logger, pcks, pcks_05, pcks_01, weights):
     else:
         logger.info(f"Weighted Per kpt PCK0.10: {pck_010 * 100:.2f}%, kpt PCK0.05: {pck_005 * 100:.2f}%, kpt PCK0.01: {pck_001 * 100:.2f}")
     return pck_010, pck_005, pck_001
+
+
+def update_geo_stats(geo_aware, geo_aware_count, pcks_geo, pcks_geo_05, pcks_geo_01, weights_geo, correct_geo):
+    """correct_geo = compute_pck's geo_score: [pairs with geo points / N, geo points / key points, PCK@3 alphas, n geo points]."""
+    for lst, v in zip((geo_aware, geo_aware_count, pcks_geo, pcks_geo_05, pcks_geo_01, weights_geo), correct_geo):
+        lst.append(v)
+
+
+def log_geo_stats(args, geo_aware, geo_aware_count, pcks_geo, pcks_geo_05, pcks_geo_01, weights_geo, weights_kpt, total_out_results):
+    from .eval_spair import convert_all_results, get_img_result
+    avg_geo_aware = np.average(geo_aware) * 100
+    avg_geo_aware_count = np.average(geo_aware_count, weights=weights_kpt) * 100
+    logger.info(f"Average images geo-aware occurrence: {avg_geo_aware:.2f}%, Average points geo-aware occurrence: {avg_geo_aware_count:.2f}%")
+    if not args.KPT_RESULT and args.TRAIN_DATASET == "spair":     # per-image numbers come from re-reading the annotations
+        g10, g05, g01 = get_img_result(convert_all_results(total_out_results), geo=True)[0].tolist()
+        logger.info(f"Weighted Per image geo-aware PCK0.10: {g10*100:.2f}%, image PCK0.05: {g05*100:.2f}%, image PCK0.01: {g01*100:.2f}%")
+        return g10, g05, g01
+    g10, g05, g01 = (np.average(p, weights=weights_geo) * 100 for p in (pcks_geo, pcks_geo_05, pcks_geo_01))
+    logger.info(f"Weighted Per kpts geo-aware PCK0.10: {g10:.2f}%, kpts PCK0.05: {g05:.2f}%, kpts PCK0.01: {g01:.2f}%")
+    return g10, g05, g01

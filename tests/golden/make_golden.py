@@ -414,7 +414,7 @@ def gen_spair():
     rs = np.random.RandomState(41)
     root = f"{HERE}/mini_spair"
     shutil.rmtree(root, ignore_errors=True)
-    cats = {"aeroplane": (4, 5, 12), "cat": (3, 4, 9)}          # images, pairs, annotated kps (of the 30 slots)
+    cats = {"aeroplane": (4, 6, 14), "cat": (3, 4, 9)}          # images, pairs, annotated kps (of the 30 slots)
     sizes = {}
     for cat, (n_img, n_pairs, n_kp) in cats.items():
         os.makedirs(f"{root}/ImageAnnotation/{cat}")
@@ -423,13 +423,25 @@ def gen_spair():
             w, h = int(rs.randint(200, 640)), int(rs.randint(200, 640))
             if i == 0:
                 h = w                                              # a square image: no padding branch
+            if cat == "aeroplane":
+                # same frame and jittered copies of one keypoint set: with the near-identical feature maps below the transfer
+                # lands close to the target annotation, so the PCK / geo-aware PCK values are not all zero
+                w, h = 520, 390
+                if i == 0:
+                    base_kps = [[int(rs.randint(40, w - 40)), int(rs.randint(40, h - 40))] for _ in range(30)]
             sizes[(cat, i)] = (w, h)
             kps = {}
             for k in range(30):
-                kps[str(k)] = [int(rs.randint(5, w - 5)), int(rs.randint(5, h - 5))] if (k < n_kp and rs.rand() > 0.25) else None
-            kps["0"] = [int(w // 3), int(h // 2)]
+                if cat == "aeroplane":
+                    jit = rs.randint(-14, 15, 2)
+                    kps[str(k)] = [int(base_kps[k][0] + jit[0]), int(base_kps[k][1] + jit[1])] if (k < n_kp and rs.rand() > 0.2) else None
+                else:
+                    kps[str(k)] = [int(rs.randint(5, w - 5)), int(rs.randint(5, h - 5))] if (k < n_kp and rs.rand() > 0.25) else None
+            if cat != "aeroplane":
+                kps["0"] = [int(w // 3), int(h // 2)]
             with open(f"{root}/ImageAnnotation/{cat}/img{i}.json", "w") as f:
-                json.dump({"kps": kps, "image_width": w, "image_height": h}, f)
+                json.dump({"kps": kps, "image_width": w, "image_height": h, "azimuth_id": (3 * i + len(cat)) % 8,
+                           "bndbox": [w // 10, h // 8, w - w // 7, h - h // 9]}, f)          # read by eval_spair.load_spair_data only
         for pi in range(n_pairs):
             a, b = rs.choice(n_img, 2, replace=False)
             (wa, ha), (wb, hb) = sizes[(cat, a)], sizes[(cat, b)]
@@ -454,7 +466,8 @@ def gen_spair():
             os.makedirs(f"{tmp}/data/SPair-71k/features/{cat}")
             base = frs.standard_normal((1, C, P, P)).astype(np.float32)
             for i in range(n_img):
-                m = 0.7 * base + 0.3 * frs.standard_normal((1, C, P, P)).astype(np.float32)
+                mix = 0.93 if cat == "aeroplane" else 0.7
+                m = mix * base + (1 - mix) * frs.standard_normal((1, C, P, P)).astype(np.float32)
                 torch.save(torch.from_numpy(m), f"{tmp}/data/SPair-71k/features/{cat}/img{i}_dino.pt")
                 out[f"feat.{cat}.{i}"] = m
         cwd = os.getcwd()
@@ -470,6 +483,38 @@ def gen_spair():
                                       SOFT_EVAL_WINDOW=5, KPT_RESULT=False, TOTAL_SAVE_RESULT=0, MUTUAL_NN=False, TEST_SAMPLE=0,
                                       BBOX_THRE=True)
             p10, p05, p01, results = PT.eval(args, PT.DummyAggregationNetwork(), tmp, split="test")
+            # geo-aware metrics (pck_train.py:68-80,169-192,231-243; logger.py log_geo_stats -> the real utils/eval_spair.py)
+            import importlib.util
+            import utils.logger as UL
+            del sys.modules["utils.eval_spair"]
+            es = importlib.util.spec_from_file_location("utils.eval_spair", f"{REF}/C_score/utils/eval_spair.py")
+            ES = importlib.util.module_from_spec(es)
+            sys.modules["utils.eval_spair"] = ES
+            es.loader.exec_module(ES)
+            UL.get_img_result, UL.convert_all_results = ES.get_img_result, ES.convert_all_results
+            lines = []
+            UL.logger = PT.logger = types.SimpleNamespace(info=lambda m: lines.append(str(m)))
+            _cp = PT.compute_pck
+            for tag, kpt in (("geo", False), ("geokpt", True)):
+                geo_scores = []
+                PT.compute_pck = lambda *a, **k: (lambda r: (geo_scores.append(r[1]), r)[1])(_cp(*a, **k))
+                del lines[:]
+                ga = argparse.Namespace(**{**vars(args), "COMPUTE_GEOAWARE_METRICS": True, "KPT_RESULT": kpt})
+                g10, g05, g01, _ = PT.eval(ga, PT.DummyAggregationNetwork(), tmp, split="test")
+                out[f"{tag}.pck"] = np.array([g10, g05, g01], np.float64)
+                out[f"{tag}.scores"] = np.array(geo_scores, np.float64)
+                out[f"{tag}.log"] = np.array([l for l in lines if "geo" in l.lower()])
+            PT.compute_pck = _cp
+            PT.logger = UL.logger = sys.modules["loguru"].logger
+            import utils.utils_geoware as UG
+            out["geo.table.spair"] = np.array(json.dumps(UG.SPAIR_GEO_AWARE, sort_keys=True))
+            out["geo.table.ap10k"] = np.array(json.dumps(UG.AP10K_GEO_AWARE))
+            conv = ES.convert_all_results(results)
+            out["post.img"] = np.concatenate([ES.get_img_result(conv)[0].numpy(), ES.get_img_result(conv, geo=True)[0].numpy(),
+                                              ES.get_img_result(conv, cls="cat", geo=True)[0].numpy()])
+            out["post.std"] = np.concatenate([ES.get_std_result(conv)[0].numpy(), ES.get_std_result(conv, geo=True)[0].numpy()])
+            out["post.n"] = np.array([ES.get_img_result(conv)[1], ES.get_img_result(conv, geo=True)[1], ES.get_std_result(conv)[1],
+                                      ES.get_std_result(conv, geo=True)[1]])
             # two-encoder variant (pck_train_two.py): a second map per image with a different channel count and scale
             import pck_train_two as PT2
             C2 = 24

@@ -144,6 +144,14 @@ def test_extract_feature_and_pck_train_on_device(small_towers, tmp_path):
     p10, p05, p01, results = PT.eval(eval_args(root, 16), PT.DummyAggregationNetwork(), str(tmp_path), split="test")
     np.testing.assert_allclose([p10, p05, p01], z["eval.pck"], atol=1e-7)
     np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), z["eval.pred"], atol=5e-3)
+    # geometry-aware metrics (COMPUTE_GEOAWARE_METRICS): per-category geo_score of the reference's run
+    ga = eval_args(root, 16)
+    ga.COMPUTE_GEOAWARE_METRICS = True
+    scores = []
+    spy = lambda *a, **k: (lambda r: (scores.append(r[1]), r)[1])(PT.compute_pck(*a, **k))
+    g = PT.eval(ga, PT.DummyAggregationNetwork(), str(tmp_path), split="test", _compute=spy)
+    np.testing.assert_allclose(g[:3], z["geo.pck"], atol=1e-7)
+    np.testing.assert_allclose(np.array(scores, np.float64), z["geo.scores"], rtol=0, atol=1e-12)
     # two-encoder evaluator (pck_train_two.py) on the same tree, against the reference's own eval()
     from law_of_vision_representation_in_mllms_amd.C_score import pck_train_two as PT2
     q10, q05, q01, results2 = PT2.eval(eval_args_two(root, 16), PT2.DummyAggregationNetwork(), str(tmp_path), split="test")
