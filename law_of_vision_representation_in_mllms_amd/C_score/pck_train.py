@@ -264,7 +264,17 @@ def build_parser(two=False):
     else:
         p.add_argument('--MODEL', type=str, default='clip')
     p.add_argument('--NUM_PATCHES', type=int, default=7)
-    p.add_argument('--DATA_DIR', type=str, default='data/SPair-71k')
+    p.add_argument('--AP10K_EVAL_SUBSET', type=str, default='intra-species')   # intra-species | cross-species | cross-family
+    # flags of the training half (pck_train.py:404-422): accepted so that the reference's command lines and yaml files parse;
+    # training itself is not built (main() raises without DO_EVAL)
+    for name, typ, default in (('WD', float, 1e-3), ('BZ', int, 1), ('SCHEDULER', str, None), ('SCHEDULER_P1', float, 0.3),
+                               ('EVAL_EPOCH', int, 5000), ('LOAD', str, None), ('DENSE_OBJ', int, 1), ('GAUSSIAN_AUGMENT', float, 0.1),
+                               ('FEAT_MAP_DROPOUT', float, 0.2), ('PROJ_DIM', int, 768), ('SELF_CONTRAST_WEIGHT', float, 0),
+                               ('SOFT_TRAIN_WINDOW', int, 0)):
+        p.add_argument(f'--{name}', type=typ, default=default)
+    for name in ('NOT_WANDB', 'PAIR_AUGMENT'):
+        p.add_argument(f'--{name}', action='store_true', default=False)
+    p.add_argument('--DATA_DIR', type=str, default=None)       # extension: dataset root (default ./data/<set>, as the reference)
     return p
 
 

@@ -544,6 +544,162 @@ def gen_spair():
     print("spair_host.npz  eval pck:", out["eval.pck"])
 
 
+# ----------------------------------------------------------------------------- mini AP-10k / PF-Pascal trees
+def gen_nextsets():
+    """Synthetic AP-10k- and PF-Pascal-shaped trees and what the reference's loaders / eval() produce on them
+    (utils_dataset.py:151-204, 278-371, 125-147; pck_train.py eval with EVAL_DATASET = ap10k / pascal).  The AP-10k json
+    files are committed under tests/golden/mini_ap10k; the PF-Pascal csv + image sizes travel inside nextsets.npz (the loader
+    only reads the JPEG headers, the test writes blank images of those sizes)."""
+    import json
+    import shutil
+    from PIL import Image
+    sys.path.insert(0, f"{REF}/C_score")
+    _stub_modules()
+    import utils.utils_dataset as UD
+    import pck_train as PT
+    import utils.logger as UL
+    rs = np.random.RandomState(51)
+    out = {}
+    P, C = 16, 24
+    root = f"{HERE}/mini_ap10k"
+    shutil.rmtree(root, ignore_errors=True)
+    fam = {"Felidae": {"cat": 3, "lion": 2}, "Canidae": {"dog": 3}}
+    W, H = 600, 450
+    base_kps = np.stack([rs.randint(60, W - 60, 17), rs.randint(60, H - 60, 17)], 1)
+    images = []                                                  # (family, species, id)
+    for f, sp in fam.items():
+        for s_, n in sp.items():
+            os.makedirs(f"{root}/ImageAnnotation/{f}/{s_}")
+            for i in range(n):
+                w, h = (W, H) if i else (W, H + 90)             # first image of each species: another aspect ratio
+                kp = []
+                for k in range(17):
+                    v = 2 if rs.rand() > 0.2 else 0
+                    x, y = (base_kps[k] + rs.randint(-16, 17, 2)).tolist()
+                    kp += [x if v else 0, y if v else 0, v]
+                name = f"{len(images):06d}"
+                with open(f"{root}/ImageAnnotation/{f}/{s_}/{name}.json", "w") as fh:
+                    json.dump({"bbox": [40, 30, int(w * 0.8), int(h * 0.7)], "width": w, "height": h, "keypoints": kp}, fh)
+                images.append((f, s_, name))
+    jp = lambda im: f"data/ap-10k/ImageAnnotation/{im[0]}/{im[1]}/{im[2]}.json"
+
+    def write_pairs(split, cat, cand, n):
+        os.makedirs(f"{root}/PairAnnotation/{split}", exist_ok=True)
+        for i in range(n):
+            a, b = rs.choice(len(cand), 2, replace=False)
+            with open(f"{root}/PairAnnotation/{split}/{i:03d}-{cand[a][2]}-{cand[b][2]}:{cat}.json", "w") as fh:
+                json.dump({"src_json_path": jp(cand[a]), "trg_json_path": jp(cand[b])}, fh)
+    for f, sp in fam.items():
+        for s_ in sp:
+            write_pairs("test", s_, [im for im in images if im[1] == s_], 3)
+    write_pairs("test_cross_species", "Felidae", [im for im in images if im[0] == "Felidae"], 3)
+    write_pairs("test_cross_family", "all", images, 4)
+    frs = np.random.RandomState(52)
+    fbase = frs.standard_normal((1, C, P, P)).astype(np.float32)
+    for im in images:
+        out[f"ap10k.feat.{im[0]}.{im[1]}.{im[2]}"] = 0.93 * fbase + 0.07 * frs.standard_normal((1, C, P, P)).astype(np.float32)
+
+    # PF-Pascal: two classes, csv rows + image sizes
+    pcls = {"cat": 8, "dog": 12}
+    pimgs, rows = {}, []
+    pbase = np.stack([rs.randint(50, 400, 20), rs.randint(50, 300, 20)], 1)
+    for c, cid in pcls.items():
+        for i in range(3):
+            pimgs[f"PF-dataset-PASCAL/JPEGImages/{c}_{i:03d}.jpg"] = (int(rs.randint(420, 520)), int(rs.randint(330, 420)))
+        names = [n for n in pimgs if f"/{c}_" in n]
+        for i in range(3):
+            a, b = rs.choice(3, 2, replace=False)
+            nk = int(rs.randint(5, 13))
+            pa = pbase[:nk] + rs.randint(-10, 11, (nk, 2))
+            pb = pbase[:nk] + rs.randint(-10, 11, (nk, 2))
+            j = lambda v: ";".join(str(int(x)) for x in v)
+            rows.append([names[a], names[b], cid, j(pa[:, 0]), j(pa[:, 1]), j(pb[:, 0]), j(pb[:, 1])])
+    csv = "source_image,target_image,class,XA,YA,XB,YB\n" + "\n".join(",".join(str(x) for x in r) for r in rows) + "\n"
+    out["pascal.csv"] = np.array(csv)
+    out["pascal.images"] = np.array(list(pimgs))
+    out["pascal.sizes"] = np.array([pimgs[n] for n in pimgs], np.int64)
+    for n in pimgs:
+        out[f"pascal.feat.{os.path.basename(n)[:-4]}"] = 0.93 * fbase + 0.07 * frs.standard_normal((1, C, P, P)).astype(np.float32)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copytree(root, f"{tmp}/data/ap-10k")
+        for im in images:
+            d = f"{tmp}/data/ap-10k/features/{im[0]}/{im[1]}"
+            os.makedirs(d, exist_ok=True)
+            torch.save(torch.from_numpy(out[f"ap10k.feat.{im[0]}.{im[1]}.{im[2]}"]), f"{d}/{im[2]}_dino.pt")
+        pr = f"{tmp}/data/PF-dataset-PASCAL"
+        os.makedirs(f"{pr}/JPEGImages")
+        os.makedirs(f"{pr}/features")
+        for c in pcls:
+            os.makedirs(f"{pr}/Annotations/{c}")
+        with open(f"{pr}/test_pairs_pf_pascal.csv", "w") as fh:
+            fh.write(csv)
+        for n, (w, h) in pimgs.items():
+            Image.new("RGB", (w, h)).save(f"{tmp}/data/{n}")
+            torch.save(torch.from_numpy(out[f"pascal.feat.{os.path.basename(n)[:-4]}"]), f"{pr}/features/{os.path.basename(n)[:-4]}_dino.pt")
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            PT.load_img_and_kps = lambda idx, files, kps, img_size=224, edge=False: (None, kps[idx])
+            PT.device = "cpu"
+            _gpd = PT.get_patch_descriptors
+            PT.get_patch_descriptors = lambda *a, **k: _gpd(*a, **{**k, "device": "cpu"})
+            lines = []
+            PT.logger = UL.logger = types.SimpleNamespace(info=lambda m: lines.append(str(m)))
+            base = dict(NUM_PATCHES=P, COMPUTE_GEOAWARE_METRICS=True, ADAPT_FLIP=False, EVAL_DATASET="ap10k", TRAIN_DATASET="spair",
+                        ANNO_SIZE=840, ENSEMBLE=1, MODEL="dino", SOFT_EVAL=True, SOFT_EVAL_WINDOW=5, KPT_RESULT=True,
+                        TOTAL_SAVE_RESULT=0, MUTUAL_NN=False, TEST_SAMPLE=0, BBOX_THRE=True, AP10K_EVAL_SUBSET="intra-species")
+            _cp = PT.compute_pck
+            for subset in ("intra-species", "cross-species", "cross-family"):
+                a = argparse.Namespace(**{**base, "AP10K_EVAL_SUBSET": subset})
+                d, cats, split = UD.get_dataset_info(a, "test")
+                out[f"ap10k.{subset}.cats"] = np.array(cats)
+                out[f"ap10k.{subset}.split"] = np.array(split)
+                for c in cats:
+                    files, kps, thr, used = UD.load_ap10k_data(d, 840, c, split, 0)
+                    out[f"ap10k.{subset}.{c}.files"] = np.array(files)
+                    out[f"ap10k.{subset}.{c}.kps"] = kps.numpy()
+                    out[f"ap10k.{subset}.{c}.thr"] = np.array(thr, np.float64)
+                    out[f"ap10k.{subset}.{c}.used"] = used.numpy()
+                scores = []
+                PT.compute_pck = lambda *aa, **k: (lambda r: (scores.append(r[1]), r)[1])(_cp(*aa, **k))
+                del lines[:]
+                r = PT.eval(a, PT.DummyAggregationNetwork(), tmp, split="test")
+                out[f"ap10k.{subset}.pck"] = np.array(r[:3], np.float64)
+                out[f"ap10k.{subset}.scores"] = np.array(scores, np.float64)
+                out[f"ap10k.{subset}.pred"] = np.stack([x["src_kpts_pred"] for x in r[3]]).astype(np.float32)
+                out[f"ap10k.{subset}.log"] = np.array(list(lines))
+            PT.compute_pck = _cp
+            # the sub-sampled draw (TEST_SAMPLE > 0: np.random.seed(42) + choice WITH replacement)
+            files, kps, thr, used = UD.load_ap10k_data("data/ap-10k", 840, "all", "test_cross_family", 6)
+            out["ap10k.sub.files"] = np.array(files)
+            # PF-Pascal: no bbox thresholds, alphas (0.1, 0.05, 0.15)
+            pa = argparse.Namespace(**{**base, "EVAL_DATASET": "pascal", "COMPUTE_GEOAWARE_METRICS": False, "BBOX_THRE": False, "KPT_RESULT": False})
+            d, cats, split = UD.get_dataset_info(pa, "test")
+            out["pascal.cats"] = np.array(cats)
+            for c in cats:
+                files, kps, thr, used = UD.load_pascal_data(d, 840, c, split, 0)
+                assert thr is None
+                out[f"pascal.{c}.files"] = np.array(files)
+                out[f"pascal.{c}.kps"] = kps.numpy()
+                out[f"pascal.{c}.used"] = used.numpy()
+            for tag, kpt in (("img", False), ("kpt", True)):
+                pa.KPT_RESULT = kpt
+                del lines[:]
+                r = PT.eval(pa, PT.DummyAggregationNetwork(), tmp, split="test")
+                out[f"pascal.{tag}.pck"] = np.array(r[:3], np.float64)
+                out[f"pascal.{tag}.log"] = np.array(list(lines))
+            out["pascal.pred"] = np.stack([x["src_kpts_pred"] for x in r[3]]).astype(np.float32)
+        finally:
+            os.chdir(cwd)
+            PT.logger = UL.logger = sys.modules["loguru"].logger
+    out["meta"] = np.array([P, C], np.int64)
+    np.savez_compressed(f"{HERE}/nextsets.npz", **out)
+    for k in out:
+        if k.endswith(".pck"):
+            print(k, out[k])
+
+
 # ----------------------------------------------------------------------------- Stable-Diffusion feature tower
 SD_CASES = {   # tag: (linear_projection, up_ft_index, ensemble, t, batch, image side, weight seed)
     "conv_up0": (False, 0, 1, 100, 2, 64, 11),
@@ -893,7 +1049,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets}[w]()
