@@ -32,7 +32,7 @@ _state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64, k
 class args_c:
     def __init__(self, img_size=None, synthetic_weights=False):
         self.mm_vision_select_layer = -2
-        self.img_size = img_size
+        self.vit_img_size = img_size
         self.synthetic_weights = synthetic_weights
 
 

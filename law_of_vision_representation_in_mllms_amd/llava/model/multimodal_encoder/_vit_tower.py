@@ -92,7 +92,9 @@ class HipViTTower(nn.Module):
         self.vision_tower_name = vision_tower
         self.select_layer = args.mm_vision_select_layer
         self.select_feature = getattr(args, "mm_vision_select_feature", self.DEFAULT_SELECT_FEATURE)
-        self._img_size = getattr(args, "img_size", None)     # C-score path runs DINOv2 at 224 or 336
+        # C-score path runs DINOv2 at 224 or 336.  NOT `args.img_size`: that is the diffusion towers' field, and LLaVA's
+        # ModelArguments always carries it (default 768, train.py:87) — the reference's ViT towers ignore it
+        self._img_size = getattr(args, "vit_img_size", None)
         self._synthetic = bool(getattr(args, "synthetic_weights", False)) or os.environ.get("VISREP_SYNTHETIC_WEIGHTS") == "1"
         self._device = getattr(args, "device", None)
         if not delay_load:

@@ -16,7 +16,7 @@ def build_vision_tower(vision_tower_cfg, **kwargs):
 
 
 def build_diffusion_vision_tower(vision_tower_cfg, **kwargs):
-    # SD1.5 / SD2.1 UNet featurizer runs on the HIP path; IMSD / SDXL / DiT / SD3 raise NotImplementedError on load
+    # SD1.5 / SD2.1 / SDXL / image-variations UNets, DiT-XL/2 and SD3-medium featurizers, all on the HIP path
     return DiffVisionTower(args=vision_tower_cfg)
 
 

@@ -251,3 +251,27 @@ def test_fused_pipelines_equal_the_file_route(small_towers, tmp_path):
     got = PL.c_score_from_tower(a, extract, str(tmp_path), batch=3)
     np.testing.assert_allclose(got[:3], want[:3], atol=1e-7)
     np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in got[3]]), np.stack([r["src_kpts_pred"] for r in want[3]]), atol=0.5)
+
+
+def test_feature_dump_with_a_registry_tower(small_towers, tmp_path):
+    """llava/feature/extract.py end to end on the device: registry -> DINOv2 tower -> one [N, C] bf16 file per image."""
+    import json
+    from law_of_vision_representation_in_mllms_amd.llava.feature import extract as FX
+    rs = np.random.RandomState(8)
+    os.makedirs(tmp_path / "imgs" / "coco")
+    entries = []
+    for i in range(3):
+        Image.fromarray(rs.randint(0, 255, (90 + 10 * i, 120, 3), dtype=np.uint8)).save(tmp_path / "imgs" / "coco" / f"im{i}.jpg")
+        entries.append({"image": f"coco/im{i}.jpg"})
+    with open(tmp_path / "d.json", "w") as f:
+        json.dump(entries, f)
+    a = SimpleNamespace(vision_tower='facebook/dinov2-large', mm_vision_select_layer=-2, mm_vision_select_feature='patch', img_size=768,
+                        data_path=str(tmp_path / "d.json"), image_folder=str(tmp_path / "imgs"), image_aspect_ratio='pad',
+                        per_device_train_batch_size=2, feature_dir=str(tmp_path / "feats"))
+    assert FX.inference(a, a, a) == 3
+    spec = small_towers['facebook/dinov2-large']                   # img_size = 768 is the diffusion towers' field: ignored here
+    for i in range(3):
+        got = torch.load(tmp_path / "feats" / "coco" / f"im{i}.pt")
+        px = FX.load_image(str(tmp_path / "imgs" / "coco" / f"im{i}.jpg"), a.image_processor, 'pad')[None].to(torch.bfloat16)
+        assert got.shape == (9, 128) and got.dtype == torch.bfloat16
+        assert rel(got, tower_oracle(spec, px.float(), 'patch')[0]) < 2e-2
