@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 110
+#define VISREP_VERSION 111
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
@@ -80,6 +80,13 @@ int visrep_layernorm(const void* x, int ldx, const float* gamma, const float* be
 int visrep_layernorm_stats(const void* x, int ldx, void* rt, int rows, int d, float eps, void* stream);
 int visrep_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* ln_rt, const float* ln_s, void* C,
                         int ldc, int M, int N, int K, int epilogue, int act, void* stream);
+/* Residual GEMM (VISREP_EPI_RESID of visrep_gemm_bf16) that ALSO leaves the LayerNorm statistics of its output rows in
+ * rt[m] = (rstd, -mean * rstd) over the N columns — what the next block's visrep_gemm_bf16_ln consumes, so that LayerNorm never
+ * reads the residual stream again (HF blocks: x = x + attn(ln1(x)); x = x + mlp(ln2(x))).  The 256x256 kernel emits per-row partial
+ * sums of the bf16-rounded outputs from its epilogue (partial: scratch of M * N / 64 float2) which are reduced in a fixed order;
+ * shapes routed elsewhere (split-K, 128x128 tail rows) run visrep_layernorm_stats on the rows they wrote.  N <= 2048. */
+int visrep_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
+                                 const void* resid, const float* ls, void* rt, void* partial, float eps, void* stream);
 
 /* ---- multi-head self-attention forward (HF CLIPAttention / Dinov2SelfAttention / SiglipAttention: softmax(QK^T
  * scale) V, fp32 softmax).  qk: [B*T, 2*H*64] bf16 (Q | K, head-major columns); vt: V^T as written by

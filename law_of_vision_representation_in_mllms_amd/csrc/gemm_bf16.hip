@@ -302,13 +302,40 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
 }
 }  // namespace
 
+namespace {
+// the statistics-emitting epilogue exists in the 256x256 v2 kernel only
+bool v2_emits_stats(const GemmArgs& a, int variant) {
+    return a.stat_rt && a.stat_partial && a.epi == EPI_RESID && !a.conv && variant == 2 && visrep_gemm_v2_supports(a) && a.N % 128 == 0;
+}
+// rows [0, a.M) of a finished residual GEMM -> a.stat_rt: from the epilogue's partial sums, else by reading the rows back
+int finish_stats(const GemmArgs& a, bool from_partials, hipStream_t s) {
+    if (!a.stat_rt) return 0;
+    if (from_partials) return visrep_ln_stats_finalize(a.stat_partial, a.N / 64, a.stat_rt, a.M, a.N, a.stat_eps, s);
+    return visrep_layernorm_stats(a.C, a.ldc, a.stat_rt, a.M, a.N, a.stat_eps, s);
+}
+int run_one(const GemmArgs& a, hipStream_t s, int variant) {
+    GemmArgs b = a;
+    const bool emit = v2_emits_stats(a, variant);
+    if (emit) b.stat_slots = a.N / 64; else b.stat_partial = nullptr;
+    const int rc = dispatch_one(b, s, variant);
+    return rc ? rc : finish_stats(a, emit, s);
+}
+int run_split_k(const GemmArgs& a, hipStream_t s) {              // 1 = handled, 0 = not eligible, < 0 = error
+    const int sk = try_split_k(a, s);
+    if (sk <= 0) return sk;
+    const int rc = finish_stats(a, false, s);
+    return rc ? rc : 1;
+}
+}  // namespace
+
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
     if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
+    if (a.stat_rt && a.epi != EPI_RESID) return visrep_set_error(VISREP_ERR_ARG, "gemm: row statistics are an EPI_RESID feature");
     const int variant = g_visrep_gemm_variant;
     {
-        const int sk = try_split_k(a, s);
+        const int sk = run_split_k(a, s);
         if (sk) return sk < 0 ? sk : 0;
     }
     // Tile quantisation: the persistent 256x256 kernels run one block per CU, so T tiles cost ceil(T / CUs) tile-times.
@@ -330,12 +357,13 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 else tail.C = a.C + (size_t)m1 * a.ldc;
                 if (a.resid) tail.resid = a.resid + (size_t)m1 * a.ldc;
                 if (a.ln_rt) tail.ln_rt = a.ln_rt + m1;
-                const int rc = dispatch_one(head, s, variant);
+                if (a.stat_rt) tail.stat_rt = a.stat_rt + m1;
+                const int rc = run_one(head, s, variant);
                 if (rc) return rc;
-                const int sk = try_split_k(tail, s);                     // the tail has few tiles: split its K loop when it pays
-                return sk ? (sk < 0 ? sk : 0) : dispatch_one(tail, s, 1);
+                const int sk = run_split_k(tail, s);                     // the tail has few tiles: split its K loop when it pays
+                return sk ? (sk < 0 ? sk : 0) : run_one(tail, s, 1);
             }
         }
     }
-    return dispatch_one(a, s, variant);
+    return run_one(a, s, variant);
 }

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
                 int m0, n0; tw.decode(ti, m0, n0); ++ti;
                 const int mb = m0 + grp * 128, nb = n0 + wn * 64;
                 if (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, fg);
-                else gemm_epilogue_rowmajor<EPI, 8, 4>(p, acc, mb, nb, fr, fg);
+                else gemm_epilogue_rowmajor<EPI, 8, 4, true>(p, acc, mb, nb, fr, fg);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll

@@ -24,9 +24,25 @@ VR_DEV void store_b64(void* ptr, u32x2 v) { asm volatile("global_store_dwordx2 %
 VR_DEV void store_b128(void* ptr, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
 VR_DEV void drain_visible_loads() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0), expcnt / lgkmcnt untouched
 
+// sum of v over the lanes that differ from this one in lane bits 4 (RBLK == 16 only) and 5: the lanes that hold the other column
+// groups of the same accumulator row.  gfx950 lane-swap VALU ops: no LDS traffic, nothing for the waitcnt pass to see.
+template <int RBLK> VR_DEV float sum_over_hg(float v) {
+    if (RBLK == 16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 template <typename ACC> struct AccGeom { static constexpr int QN = sizeof(ACC) / 16, RBLK = QN == 1 ? 16 : 32; };
 
-template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, typename ACC>
+// HAS_ST (EPI_RESID): also emit, per output row and per wave tile (NJ * RBLK columns = one "slot"), the sum and the sum of squares
+// of the bf16-ROUNDED outputs -> p.stat_partial[m * p.stat_slots + slot]; ln_stats_finalize turns the slots of a row into the
+// (rstd, -mean * rstd) the next LayerNorm-folded GEMM wants, so that LayerNorm never reads the residual stream again.
+template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK, NC = NJ * QN;   // NC column groups of 4 per lane
     float4 bv[NC], lv[(HAS_LS || HAS_LN) ? NC : 1];           // lv: LayerScale gamma, or the LN column sums s[n]
@@ -87,6 +103,7 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
             const int i = i0 + ii;
+            float st1 = 0.f, st2 = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int j = c / QN, q = c % QN, n = col(c);
@@ -114,39 +131,61 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
                     } else {
                         u32x2 o = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
                         store_b64(p.C + orow[ii] * p.ldc + n, o);
+                        if (HAS_ST) {
+                            const float r0 = bf_lo(o[0]), r1 = bf_hi(o[0]), r2 = bf_lo(o[1]), r3 = bf_hi(o[1]);
+                            st1 += (r0 + r1) + (r2 + r3);
+                            st2 = __builtin_fmaf(r0, r0, __builtin_fmaf(r1, r1, __builtin_fmaf(r2, r2, __builtin_fmaf(r3, r3, st2))));
+                        }
                     }
+                }
+            }
+            if (HAS_ST) {                                     // all lanes take part in the lane swaps; one lane per row stores
+                st1 = sum_over_hg<RBLK>(st1);
+                st2 = sum_over_hg<RBLK>(st2);
+                if (hg == 0 && ok[ii]) {
+                    u32x2 o = {__builtin_bit_cast(unsigned, st1), __builtin_bit_cast(unsigned, st2)};
+                    store_b64(p.stat_partial + orow[ii] * p.stat_slots + nb / (NJ * RBLK), o);
                 }
             }
         }
     }
 }
 
-template <int EPI, int NI, int NJ, int ACT, typename ACC>
+template <int EPI, int NI, int NJ, int ACT, bool STATS, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     const bool interior = mb + NI * AccGeom<ACC>::RBLK <= p.M;
-    if (EPI == EPI_RESID && p.ls) {                          // LayerScale towers (DINOv2): its own path keeps the others lean
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false>(p, acc, mb, nb, fr, hg);
+    if (STATS && EPI == EPI_RESID && p.stat_partial) {       // residual GEMM that also emits the next LayerNorm's row statistics
+        if (p.ls) {
+            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, true>(p, acc, mb, nb, fr, hg);
+            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, true>(p, acc, mb, nb, fr, hg);
+        } else {
+            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, true>(p, acc, mb, nb, fr, hg);
+            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, true>(p, acc, mb, nb, fr, hg);
+        }
+    } else if (EPI == EPI_RESID && p.ls) {                   // LayerScale towers (DINOv2): its own path keeps the others lean
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, false>(p, acc, mb, nb, fr, hg);
     } else if ((EPI == EPI_BIAS || EPI == EPI_ACT) && p.ln_rt) {   // LayerNorm folded into this GEMM
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true, false>(p, acc, mb, nb, fr, hg);
     } else {
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, false>(p, acc, mb, nb, fr, hg);
     }
 }
 
-template <int EPI, int NI, int NJ, typename ACC>
+// STATS: only the kernel the dispatcher routes statistics-emitting residual GEMMs to (v2) compiles that epilogue
+template <int EPI, int NI, int NJ, bool STATS = false, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     if (EPI == EPI_ACT) {
         switch (p.act) {
-            case ACT_QUICK_GELU: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_QUICK_GELU>(p, acc, mb, nb, fr, hg); break;
-            case ACT_GELU_ERF: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_ERF>(p, acc, mb, nb, fr, hg); break;
-            case ACT_GELU_TANH: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_TANH>(p, acc, mb, nb, fr, hg); break;
-            default: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, hg); break;
+            case ACT_QUICK_GELU: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_QUICK_GELU, false>(p, acc, mb, nb, fr, hg); break;
+            case ACT_GELU_ERF: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_ERF, false>(p, acc, mb, nb, fr, hg); break;
+            case ACT_GELU_TANH: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_GELU_TANH, false>(p, acc, mb, nb, fr, hg); break;
+            default: gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE, false>(p, acc, mb, nb, fr, hg); break;
         }
     } else {
-        gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, hg);
+        gemm_epilogue_rowmajor_act<EPI, NI, NJ, ACT_NONE, STATS>(p, acc, mb, nb, fr, hg);
     }
 }
 

@@ -96,6 +96,25 @@ __global__ __launch_bounds__(256) void layernorm_stats_rows(const bf16_t* __rest
     if (lane == 0) rt[row] = float2{rstd, -mean * rstd};
 }
 
+// Row statistics from the partial sums a residual GEMM's epilogue left behind (gemm_epilogue.h, HAS_ST): slot k of row m holds
+// (sum, sum of squares) of 64 output columns; summed here in slot order (deterministic), var = E[x^2] - mean^2 in fp32.
+__global__ __launch_bounds__(256) void ln_stats_finalize_rows(const float2* __restrict__ part, int slots, float2* __restrict__ rt, int M,
+                                                              float inv_d, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float4* src = reinterpret_cast<const float4*>(part + (size_t)row * slots);   // slots is even: two slots per 16-B load
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < slots / 2; ++k) {
+        const float4 v = src[k];
+        s1 += v.x; s2 += v.y;
+        s1 += v.z; s2 += v.w;
+    }
+    const float mean = s1 * inv_d;
+    const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    rt[row] = float2{rstd, -mean * rstd};
+}
+
 // ------------------------------------------------------------------------------------------------ im2col
 // pixels [B, 3, H, W] (fp32 or bf16) -> cols [B*gh*gw, Kpad] bf16 with k = c*p*p + i*p + j (Conv2d weight order),
 // zero-filled for k >= 3*p*p.  One thread per 8 output elements (16-B store).
@@ -161,6 +180,13 @@ extern "C" int visrep_layernorm_stats(const void* x, int ldx, void* rt, int rows
     if (d % 8 || d > 2048 || (ldx % 8)) return visrep_set_error(VISREP_ERR_SHAPE, "layernorm_stats: need d % 8 == 0, d <= 2048");
     hipLaunchKernelGGL(layernorm_stats_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (float2*)rt, rows, d, eps);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "layernorm_stats: launch failed");
+}
+
+int visrep_ln_stats_finalize(const float2* partial, int slots, float2* rt, int rows, int d, float eps, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (slots <= 0 || (slots & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "ln_stats_finalize: slot count must be even");
+    hipLaunchKernelGGL(ln_stats_finalize_rows, dim3((rows + 255) / 256), dim3(256), 0, s, partial, slots, rt, rows, 1.0f / (float)d, eps);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "ln_stats_finalize: launch failed");
 }
 
 extern "C" int visrep_im2col(const void* pixels, int pixel_dtype, void* cols, int B, int Himg, int Wimg, int patch, int Kpad,

@@ -73,6 +73,17 @@ extern "C" int visrep_gemm_bf16_ln(const void* A, int lda, const void* W, int ld
     return visrep_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+extern "C" int visrep_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                                            int K, const void* resid, const float* ls, void* rt, void* partial, float eps, void* stream) {
+    if (!A || !W || !C || !resid || !rt || !partial) return visrep_set_error(VISREP_ERR_ARG, "gemm_resid_stats: null pointer");
+    if (N > 2048) return visrep_set_error(VISREP_ERR_SHAPE, "gemm_resid_stats: N <= 2048");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.resid = (const bf16_t*)resid; a.ls = ls;
+    a.stat_rt = (float2*)rt; a.stat_partial = (float2*)partial; a.stat_eps = eps;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.epi = EPI_RESID;
+    return visrep_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc,
                                    int Cout, int stride, int pad_mode, int upsample, int epilogue, const void* resid, void* stream) {
     if (!x || !Wt || !out) return visrep_set_error(VISREP_ERR_ARG, "conv3x3: null pointer");
@@ -97,7 +108,7 @@ extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, co
 namespace {
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Ws {
-    size_t h, qk, vt, mlp, rt, total;
+    size_t h, qk, vt, mlp, rt, part, total;
     int ldvt;
 };
 Ws layout(const visrep_vit_config* c, int B) {
@@ -113,6 +124,7 @@ Ws layout(const visrep_vit_config* c, int B) {
     const size_t cols_b = up((size_t)B * (c->tokens - c->has_cls), 128) * c->kpad * 2;
     w.mlp = off; off += up(mlp_b > cols_b ? mlp_b : cols_b, 256);   // im2col columns alias the MLP buffer
     w.rt = off;  off += up((Mp + 8) * sizeof(float2), 256);         // folded-LayerNorm row statistics (zero past M)
+    w.part = off; off += up(Mp * (c->d / 64) * sizeof(float2), 256);  // per-row partial sums left by the residual GEMM epilogues
     w.total = off;
     return w;
 }
@@ -160,13 +172,16 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
     float2* rt = (float2*)(base + L.rt);
     if (hipMemsetAsync(rt, 0, (up(M, 128) + 8) * sizeof(float2), s) != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward: memset failed");
 
+    float2* part = (float2*)(base + L.part);
     const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
+    bool rt_ready = false;        // rt already holds the statistics of x (left by the previous layer's fc2 GEMM)
     for (int l = 0; l < n_layers; ++l) {
         const visrep_vit_layer& W = w->layers[l];
-        const bool fold = W.sqkv && W.s1;     // LayerNorm folded into the QK / V / fc1 GEMMs: only its statistics are computed
+        const bool fold = W.sqkv && W.s1;     // LayerNorm folded into the QK / V / fc1 GEMMs: only its statistics are computed,
+        const bool fold_next = l + 1 < n_layers && w->layers[l + 1].sqkv && w->layers[l + 1].s1;   // and those by the GEMM that writes x
         GemmArgs a{};
         if (fold) {
-            VR_TRY(visrep_layernorm_stats(x, d, rt, M, d, c->eps, stream));
+            if (!rt_ready) VR_TRY(visrep_layernorm_stats(x, d, rt, M, d, c->eps, stream));
             a.A = x; a.ln_rt = rt; a.ln_s = W.sqkv;
         } else {
             VR_TRY(visrep_layernorm(x, d, W.ln1_g, W.ln1_b, h, d, M, d, c->eps, stream));
@@ -184,10 +199,10 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
         // out projection + LayerScale + residual (in place on x)
         a.A = h; a.ln_rt = nullptr; a.ln_s = nullptr;
         a.W = (const bf16_t*)W.wo; a.N = d; a.C = x; a.ldc = d; a.bias = W.bo; a.epi = EPI_RESID; a.resid = x; a.ls = W.ls1;
+        if (fold) { a.stat_rt = rt; a.stat_partial = part; a.stat_eps = c->eps; }   // LN2's statistics come out of this GEMM
         VR_TRY(visrep_gemm_dispatch(a, s));
         GemmArgs f{};
         if (fold) {
-            VR_TRY(visrep_layernorm_stats(x, d, rt, M, d, c->eps, stream));
             f.A = x; f.ln_rt = rt; f.ln_s = W.s1;
         } else {
             VR_TRY(visrep_layernorm(x, d, W.ln2_g, W.ln2_b, h, d, M, d, c->eps, stream));
@@ -199,6 +214,8 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
         f.ln_rt = nullptr; f.ln_s = nullptr;
         f.A = mlp; f.lda = c->mlp; f.K = c->mlp; f.W = (const bf16_t*)W.w2; f.ldw = c->mlp; f.N = d; f.C = x; f.ldc = d;
         f.bias = W.b2; f.epi = EPI_RESID; f.act = 0; f.resid = x; f.ls = W.ls2;
+        if (fold_next) { f.stat_rt = rt; f.stat_partial = part; f.stat_eps = c->eps; }   // the next layer's LN1
+        rt_ready = fold_next;
         VR_TRY(visrep_gemm_dispatch(f, s));
     }
     return 0;

@@ -21,6 +21,14 @@ struct GemmArgs {
     // C = rstd[m] * (A W^T - mean[m] * s[n]) + bias'[n] with ln_rt[m] = (rstd, -mean * rstd), ln_s[n] = sum_k W[n, k]
     const float2* ln_rt;  // [M] per-row statistics (visrep_layernorm_stats) or null
     const float* ln_s;    // [N]
+    // EPI_RESID that also produces the LayerNorm statistics of its OUTPUT rows (the next block's folded LayerNorm):
+    // stat_rt[m] = (rstd, -mean * rstd) over the N output columns.  The 256x256 kernel (v2) writes per-wave-tile partial sums to
+    // stat_partial[m * stat_slots + slot] from its epilogue and ln_stats_finalize reduces them in slot order; every other route
+    // (split-K, 128x128 tail rows, v3) runs the read-only statistics pass on the rows it produced.  Set by visrep_vit_forward.
+    float2* stat_rt;      // [M] or null
+    float2* stat_partial; // [M, N / 64] scratch (v2 slot width = 64 columns)
+    int stat_slots;       // filled in by the dispatcher
+    float stat_eps;
     int M, N, K, lda, ldw, ldc;
     int epi, act;
     int patches, tokens, cls_off;   // EPI_PATCH row remap
@@ -33,6 +41,7 @@ struct GemmArgs {
 };
 
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s);
+int visrep_ln_stats_finalize(const float2* partial, int slots, float2* rt, int rows, int d, float eps, hipStream_t s);
 bool visrep_gemm_v2_supports(const GemmArgs& a);
 int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v3_supports(const GemmArgs& a);

@@ -39,14 +39,16 @@ class VitEngine:
     """
 
     def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, fuse_ln: Optional[bool] = None):
-        """fuse_ln (default off; VISREP_FUSE_LN=1 turns it on): fold every block's LayerNorm into the GEMMs that consume it -
-        gamma into the weight rows, beta into the bias, the per-row mean / rstd into the GEMM epilogue
-        (visrep_layernorm_stats + the ln_rt / ln_s epilogue) - so the normalised activations are never written to HBM.
-        Measured +0.3 % on the ViT-L/14-336 forward (the read-only statistics pass and the heavier epilogues eat most of the
-        saved write), so it stays opt-in until the statistics come out of the preceding residual GEMM's epilogue."""
+        """fuse_ln (default on; VISREP_FUSE_LN=0 turns it off): fold every block's LayerNorm into the GEMMs that consume it -
+        gamma into the weight rows, beta into the bias, the per-row mean / rstd into the GEMM epilogue (ln_rt / ln_s) - so the
+        normalised activations are never written to HBM, and take the row statistics from the epilogue of the residual GEMM that
+        produced the rows (visrep_gemm_bf16_resid_stats) - so LayerNorm never reads the residual stream either; only layer 0's
+        first LayerNorm runs the read-only statistics pass.  Measured on ViT-L/14-336, batch 256: the two LayerNorm passes per
+        layer (19.7 ms of kernel time per 4 forwards) are replaced by 15.2 ms of heavier epilogues + partial-sum reduction:
+        +0.8 % kernel time, +1.4 % on the bench line (profiles/round1_fold_stats.md)."""
         self.lib = _lib.require_gpu()
         import os
-        self.fuse_ln = (os.environ.get("VISREP_FUSE_LN", "0") == "1") if fuse_ln is None else bool(fuse_ln)
+        self.fuse_ln = (os.environ.get("VISREP_FUSE_LN", "1") != "0") if fuse_ln is None else bool(fuse_ln)
         self.spec = spec
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         if spec.d != spec.heads * 64:

@@ -146,6 +146,41 @@ def test_gemm_with_folded_layernorm(M, N, K, epi, gemm_variant):
         assert rel_err(out, ref_act(want, act)) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K,ls", [(4096, 1024, 256, False), (4000, 1024, 256, True), (16640, 1024, 256, False), (16640 + 77, 1024, 512, True),
+                                       (300, 1024, 1024, False), (1000, 256, 1024, True), (70000, 512, 128, False)])
+def test_residual_gemm_emits_the_next_layernorm_statistics(M, N, K, ls):
+    """x <- x + ls o (A W^T + b) with the LayerNorm statistics of the NEW rows as a by-product: same x bit for bit as the plain
+    residual GEMM, statistics equal to the read-only pass over it.  Shapes cover the 256x256 kernel's epilogue partials (interior and
+    edge row tiles), the head / 128x128-tail split, the split-K route and a width the 256-wide kernel does not take."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    gamma = (torch.randn(N, generator=g) * 0.2 + 1).to(DEV) if ls else None
+    x0 = bf(torch.randn(M, N, generator=g) * 1.5 + torch.randn(M, 1, generator=g) + 3 * (torch.arange(N) % 97 == 0).float()).to(DEV)
+    lib = _lib.load()
+    engine.ensure_scratch(torch.device(DEV))
+    gp = _lib.ptr(gamma) if ls else None
+    plain = x0.clone()
+    _lib.check(lib.visrep_gemm_bf16(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), _lib.ptr(plain), N, M, N, K, _lib.EPI_RESID, 0, _lib.ptr(plain), gp,
+                                    _lib.stream_ptr()), "gemm")
+    rt_ref = torch.zeros(M, 2, dtype=torch.float32, device=DEV)
+    _lib.check(lib.visrep_layernorm_stats(_lib.ptr(plain), N, _lib.ptr(rt_ref), M, N, 1e-5, _lib.stream_ptr()), "stats")
+    for rep in range(2):                                                  # twice: bit-identical statistics run to run
+        x = x0.clone()
+        rt = torch.full((M + 8, 2), float("nan"), dtype=torch.float32, device=DEV)
+        part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=DEV)
+        _lib.check(lib.visrep_gemm_bf16_resid_stats(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), _lib.ptr(x), N, M, N, K, _lib.ptr(x), gp, _lib.ptr(rt),
+                                                    _lib.ptr(part), 1e-5, _lib.stream_ptr()), "gemm_resid_stats")
+        assert torch.equal(x, plain)
+        assert torch.isnan(rt[M:]).all() and torch.isfinite(rt[:M]).all()
+        torch.testing.assert_close(rt[:M, 0], rt_ref[:, 0], rtol=2e-5, atol=0)
+        torch.testing.assert_close(rt[:M, 1], rt_ref[:, 1], rtol=2e-4, atol=2e-5)
+        if rep:
+            assert torch.equal(rt[:M], first)
+        first = rt[:M].clone()
+
+
 def test_gemm_rejects_bad_shapes():
     a = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(100, 64, dtype=torch.bfloat16, device=DEV)
