@@ -135,13 +135,41 @@ def main():
             return e0.elapsed_time(e1) / reps * 1e-3
 
         o1 = torch.empty(M, m, dtype=torch.bfloat16, device=dev)
-        o2 = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+        o2 = torch.zeros(M, d, dtype=torch.bfloat16, device=dev)
         oqk = torch.empty(M, 2 * d, dtype=torch.bfloat16, device=dev)
+        lib = _lib.load()
+        sp = _lib.stream_ptr
+        if eng.fuse_ln:
+            # the launches of the default forward: LayerNorm folded into fc1 / Q|K (per-row statistics applied in the epilogue),
+            # residual GEMMs that also emit the next LayerNorm's statistics
+            rt = torch.zeros((M + 127) // 128 * 128 + 8, 2, dtype=torch.float32, device=dev)
+            part = torch.empty(M, d // 64, 2, dtype=torch.float32, device=dev)
+            _lib.check(lib.visrep_layernorm_stats(_lib.ptr(x), d, _lib.ptr(rt), M, d, 1e-5, sp()), "stats")
+            s1, sqk = w1.float().sum(1).contiguous(), wqk.float().sum(1).contiguous()
+            bqk = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+
+            def fc1():
+                _lib.check(lib.visrep_gemm_bf16_ln(_lib.ptr(x), d, _lib.ptr(w1), d, _lib.ptr(b1), _lib.ptr(rt), _lib.ptr(s1), _lib.ptr(o1), m, M, m, d,
+                                                   _lib.EPI_ACT, _lib.ACT["quick_gelu"], sp()), "gemm_ln")
+
+            def qk():
+                _lib.check(lib.visrep_gemm_bf16_ln(_lib.ptr(x), d, _lib.ptr(wqk), d, _lib.ptr(bqk), _lib.ptr(rt), _lib.ptr(sqk), _lib.ptr(oqk), 2 * d, M,
+                                                   2 * d, d, _lib.EPI_BIAS, 0, sp()), "gemm_ln")
+
+            def resid(a, w, K):
+                return lambda: _lib.check(lib.visrep_gemm_bf16_resid_stats(_lib.ptr(a), K, _lib.ptr(w), K, None, _lib.ptr(o2), d, M, d, K, _lib.ptr(o2), None,
+                                                                           _lib.ptr(rt), _lib.ptr(part), 1e-5, sp()), "gemm_resid_stats")
+            fc2, out_proj = resid(hmlp, w2, m), resid(x, wo, d)
+        else:
+            fc1 = lambda: engine.gemm(x, w1, b1, _lib.EPI_ACT, act="quick_gelu", out=o1)
+            qk = lambda: engine.gemm(x, wqk, None, _lib.EPI_BIAS, out=oqk)
+            fc2 = lambda: engine.gemm(hmlp, w2, None, _lib.EPI_RESID, resid=o2, out=o2)
+            out_proj = lambda: engine.gemm(x, wo, None, _lib.EPI_RESID, resid=o2, out=o2)
         shapes = {
-            "fc1 (M x 4096 x 1024, bias+QuickGELU)": (lambda: engine.gemm(x, w1, b1, _lib.EPI_ACT, act="quick_gelu", out=o1), 2.0 * M * m * d),
-            "fc2 (M x 1024 x 4096, bias+residual)": (lambda: engine.gemm(hmlp, w2, None, _lib.EPI_RESID, resid=o2, out=o2), 2.0 * M * m * d),
-            "qk  (M x 2048 x 1024, bias)": (lambda: engine.gemm(x, wqk, None, _lib.EPI_BIAS, out=oqk), 2.0 * M * 2 * d * d),
-            "out (M x 1024 x 1024, bias+residual)": (lambda: engine.gemm(x, wo, None, _lib.EPI_RESID, resid=o2, out=o2), 2.0 * M * d * d),
+            "fc1 (M x 4096 x 1024, bias+QuickGELU)": (fc1, 2.0 * M * m * d),
+            "fc2 (M x 1024 x 4096, bias+residual)": (fc2, 2.0 * M * m * d),
+            "qk  (M x 2048 x 1024, bias)": (qk, 2.0 * M * 2 * d * d),
+            "out (M x 1024 x 1024, bias+residual)": (out_proj, 2.0 * M * d * d),
         }
         for name, (fn, fl) in shapes.items():
             sec = time_kernel(fn)
