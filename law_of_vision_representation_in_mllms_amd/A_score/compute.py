@@ -44,25 +44,54 @@ def _shard(n, rank, world):
     return list(range(rank, n, world))
 
 
-def _score_batch(other, ref):
+def _score_batch(other, ref, other_scale=None, ref_scale=None):
     """[n, Nt, D] x [n, Nr, D] -> [n] on the device: the HIP kernel (no CPU fallback; tests may monkeypatch this hook)."""
     from .. import ascore_ops
-    return ascore_ops.max_cos_mean(other, ref)
+    return ascore_ops.max_cos_mean(other, ref, other_scale, ref_scale)
+
+
+def _row_scales(x):
+    """Per-row normalisation factors of a token stack, computed once and handed to every _score_batch call that uses the stack
+    (hook: a stand-in that returns None makes _score_batch compute them itself)."""
+    from .. import ascore_ops
+    return ascore_ops.row_scales(x)
+
+
+def _stack(tensors, ids, device):
+    return torch.stack([tensors[i].reshape(-1, tensors[i].shape[-1]) for i in ids]).to(device)
 
 
 def per_image_scores(other_tensors, ref_tensors, idx, device="cuda"):
     """{image index: mean_t max_s cos} for the images in idx (compute.py:54-72 for one reference)."""
-    out = {}
-    by_other = {}
+    return per_image_scores_multi(other_tensors, [ref_tensors], idx, device)[0]
+
+
+def per_image_scores_multi(other_tensors, ref_sets, idx, device="cuda", ref_cache=None):
+    """One {image index: score} per reference set.  Every stack of tokens goes to the device once and is normalised once: the
+    encoder's tokens serve all references, and with `ref_cache` (a dict kept by the caller) a reference stack serves all encoders
+    - the reference script re-normalises both inside its innermost loop (compute.py:54-56)."""
+    outs = [{} for _ in ref_sets]
+    groups = {}
     for i in idx:
-        by_other.setdefault((tuple(other_tensors[i].shape), tuple(ref_tensors[i].shape)), []).append(i)
-    for _, ids in by_other.items():
-        o = torch.stack([other_tensors[i].reshape(-1, other_tensors[i].shape[-1]) for i in ids]).to(device)
-        r = torch.stack([ref_tensors[i].reshape(-1, ref_tensors[i].shape[-1]) for i in ids]).to(device)
-        s = _score_batch(o, r).double().cpu()
-        for j, i in enumerate(ids):
-            out[i] = float(s[j])
-    return out
+        key = (tuple(other_tensors[i].shape),) + tuple(tuple(rs[i].shape) for rs in ref_sets)
+        groups.setdefault(key, []).append(i)
+    for ids in groups.values():
+        o = _stack(other_tensors, ids, device)
+        o_scale = _row_scales(o)
+        for k, rs in enumerate(ref_sets):
+            ck = (k, id(rs), tuple(ids))
+            if ref_cache is not None and ck in ref_cache:
+                r, r_scale = ref_cache[ck]
+            else:
+                r = _stack(rs, ids, device)
+                r_scale = _row_scales(r) if r.dtype == o.dtype else None        # mixed dtypes take the fp32 path inside the op
+                if ref_cache is not None:
+                    ref_cache[ck] = (r, r_scale)
+            same = r.dtype == o.dtype
+            s = _score_batch(o, r, o_scale if same else None, r_scale if same else None).double().cpu()
+            for j, i in enumerate(ids):
+                outs[k][i] = float(s[j])
+    return outs
 
 
 def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True):
@@ -80,6 +109,7 @@ def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True):
         raise ValueError("Failed to load tensors from 'clip336' or 'clip224' subfolder")
 
     results = {}
+    ref_cache = {}                                                  # reference stacks + their row factors, shared by all encoders
     for subfolder in subs:
         other_tensors = load_tensors(subfolder, n_images)
         if not other_tensors:
@@ -87,8 +117,7 @@ def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True):
             continue
         n = min(len(clip336_tensors), len(clip224_tensors), len(other_tensors))       # zip() semantics, compute.py:51
         idx = _shard(n, rank, world)
-        s336 = per_image_scores(other_tensors, clip336_tensors, idx, device)
-        s224 = per_image_scores(other_tensors, clip224_tensors, idx, device)
+        s336, s224 = per_image_scores_multi(other_tensors, [clip336_tensors, clip224_tensors], idx, device, ref_cache)
         if dist:
             acc = torch.tensor([sum(s336.values()), sum(s224.values()), float(len(idx))], dtype=torch.float64, device=device)
             dist.all_reduce(acc)

@@ -66,6 +66,8 @@ SIGNATURES = {
     "visrep_vit_forward": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _i, _vp, _i, _i, _vp, _vp]),
     "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "visrep_ascore_row_scale": (_i, [_vp, C.c_long, _i, _i, _vp, _vp]),
+    "visrep_ascore_maxcos_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_cscore_transfer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "visrep_pck_count": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
 }

@@ -1,30 +1,58 @@
-"""Device entry point of the A score (visrep_ascore_maxcos).  See csrc/ascore.hip; reference A_score/compute.py:54-72."""
+"""Device entry points of the A score (visrep_ascore_maxcos*).  See csrc/ascore.hip; reference A_score/compute.py:54-72."""
 from __future__ import annotations
+
+from typing import Optional
 
 import torch
 
 from . import _lib
 
 
-@torch.no_grad()
-def max_cos_mean(other: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
-    """scores[i] = mean_t max_s cos(other[i, t], ref[i, s]);  other [n, Nt, D], ref [n, Nr, D] on the GPU.
+def _typed(x: torch.Tensor):
+    """bf16 inputs run the bf16 MFMA path (products exact, fp32 accumulate); anything else is upcast to fp32 and runs the
+    exact-fp32 MFMA path (the parity definition of SURVEY.md F4)."""
+    if x.dtype == torch.bfloat16 and x.shape[-1] % 16 == 0:
+        return x.contiguous(), _lib.BF16
+    return x.float().contiguous(), _lib.F32
 
-    bf16 inputs run the bf16 MFMA path (products exact, fp32 accumulate); anything else is upcast to fp32 and
-    runs the exact-fp32 MFMA path (the parity definition of SURVEY.md F4).
-    """
+
+@torch.no_grad()
+def row_scales(x: torch.Tensor) -> torch.Tensor:
+    """The per-row factor 1/(|x|+1e-10) / max(|x|/(|x|+1e-10), 1e-8) of [n, N, D] tokens -> fp32 [n, N] (compute.py:12-15 + the
+    eps clamp of F.cosine_similarity).  Pass it to max_cos_mean when a tensor is scored more than once - the clip336 / clip224
+    reference sets against every encoder, an encoder's tokens against both references."""
+    lib = _lib.require_gpu()
+    if x.dim() != 3:
+        raise ValueError("expected [n, N, D]")
+    x, dt = _typed(x)
+    out = torch.empty(x.shape[:2], dtype=torch.float32, device=x.device)
+    _lib.check(lib.visrep_ascore_row_scale(_lib.ptr(x), x.shape[0] * x.shape[1], x.shape[2], dt, _lib.ptr(out), _lib.stream_ptr()), "visrep_ascore_row_scale")
+    return out
+
+
+@torch.no_grad()
+def max_cos_mean(other: torch.Tensor, ref: torch.Tensor, other_scale: Optional[torch.Tensor] = None,
+                 ref_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scores[i] = mean_t max_s cos(other[i, t], ref[i, s]);  other [n, Nt, D], ref [n, Nr, D] on the GPU.
+    other_scale / ref_scale: row_scales() of the same tensors (same dtype path), or None to compute them in this call."""
     lib = _lib.require_gpu()
     if other.dim() != 3 or ref.dim() != 3 or other.shape[0] != ref.shape[0] or other.shape[2] != ref.shape[2]:
         raise ValueError("expected other [n, Nt, D] and ref [n, Nr, D]")
     if other.dtype == torch.bfloat16 and ref.dtype == torch.bfloat16 and other.shape[2] % 16 == 0:
         dt = _lib.BF16
     else:
+        if (other_scale is not None and other.dtype == torch.bfloat16) or (ref_scale is not None and ref.dtype == torch.bfloat16):
+            raise ValueError("precomputed scales of a bf16 tensor cannot be used on the fp32 path (mixed dtypes)")
         other, ref, dt = other.float(), ref.float(), _lib.F32
     other, ref = other.contiguous(), ref.contiguous()
     n, Nt, D = other.shape
     Nr = ref.shape[1]
+    for sc, rows in ((other_scale, Nt), (ref_scale, Nr)):
+        if sc is not None and (sc.dtype != torch.float32 or tuple(sc.shape) != (n, rows) or not sc.is_contiguous() or sc.device != other.device):
+            raise ValueError("scale must be the contiguous fp32 [n, N] tensor row_scales() returned for this tensor")
     scores = torch.empty(n, dtype=torch.float32, device=other.device)
     ws = torch.empty(lib.visrep_ascore_workspace_bytes(n, Nt, Nr), dtype=torch.uint8, device=other.device)
-    rc = lib.visrep_ascore_maxcos(_lib.ptr(other), _lib.ptr(ref), n, Nt, Nr, D, dt, _lib.ptr(scores), _lib.ptr(ws), _lib.stream_ptr())
-    _lib.check(rc, "visrep_ascore_maxcos")
+    rc = lib.visrep_ascore_maxcos_scaled(_lib.ptr(other), _lib.ptr(ref), _lib.ptr(other_scale), _lib.ptr(ref_scale), n, Nt, Nr, D, dt,
+                                         _lib.ptr(scores), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, "visrep_ascore_maxcos_scaled")
     return scores

@@ -274,14 +274,21 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
 }
 
 template <typename T>
-int run(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, float* scores, float* ws, hipStream_t s) {
+int row_scales(const void* x, long rows, int D, float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const T*)x, rows, D, scale);
+    return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+}
+
+// c_other / c_ref: row scales computed earlier (visrep_ascore_row_scale) or null -> computed here into the workspace
+template <typename T>
+int run(const void* other, const void* ref, const float* c_other_in, const float* c_ref_in, int n_img, int Nt, int Nr, int D, float* scores,
+        float* ws, hipStream_t s) {
     float* c_other = ws;
     float* c_ref = c_other + (size_t)n_img * Nt;
     float* partial = c_ref + (size_t)n_img * Nr;
-    const long ro = (long)n_img * Nt, rr = (long)n_img * Nr;
-    hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((ro + 3) / 4)), dim3(256), 0, s, (const T*)other, ro, D, c_other);
-    hipLaunchKernelGGL(ascore_row_scale<T>, dim3((unsigned)((rr + 3) / 4)), dim3(256), 0, s, (const T*)ref, rr, D, c_ref);
-    AScoreArgs a{other, ref, c_other, c_ref, partial, n_img, Nt, Nr, D};
+    if (!c_other_in && row_scales<T>(other, (long)n_img * Nt, D, c_other, s)) return VISREP_ERR_LAUNCH;
+    if (!c_ref_in && row_scales<T>(ref, (long)n_img * Nr, D, c_ref, s)) return VISREP_ERR_LAUNCH;
+    AScoreArgs a{other, ref, c_other_in ? c_other_in : c_other, c_ref_in ? c_ref_in : c_ref, partial, n_img, Nt, Nr, D};
     int ntt = (Nt + 63) / 64;
     if (sizeof(T) == 2 && D % 64 == 0) {                       // production path: LDS-tiled MFMA kernel, 128-row target tiles
         ntt = (Nt + A_BM - 1) / A_BM;
@@ -301,19 +308,36 @@ extern "C" size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr) {
     return sizeof(float) * ((size_t)n_img * Nt + (size_t)n_img * Nr + (size_t)n_img * ((Nt + 63) / 64));
 }
 
-extern "C" int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, int dtype,
-                                    float* scores, void* workspace, void* stream) {
+extern "C" int visrep_ascore_row_scale(const void* x, long rows, int D, int dtype, float* scale, void* stream) {
+    if (rows <= 0) return 0;
+    if (!x || !scale) return visrep_set_error(VISREP_ERR_ARG, "ascore_row_scale: null pointer");
+    if (dtype == VISREP_BF16 && D > 0 && D % 16 == 0) {
+        return row_scales<bf16_t>(x, rows, D, scale, (hipStream_t)stream) ? visrep_set_error(VISREP_ERR_LAUNCH, "ascore_row_scale: launch failed") : 0;
+    }
+    if (dtype == VISREP_F32 && D > 0 && D % 8 == 0) {
+        return row_scales<float>(x, rows, D, scale, (hipStream_t)stream) ? visrep_set_error(VISREP_ERR_LAUNCH, "ascore_row_scale: launch failed") : 0;
+    }
+    return visrep_set_error(VISREP_ERR_SHAPE, "ascore_row_scale: VISREP_BF16 with D % 16 == 0 or VISREP_F32 with D % 8 == 0");
+}
+
+extern "C" int visrep_ascore_maxcos_scaled(const void* other, const void* ref, const float* other_scale, const float* ref_scale, int n_img,
+                                           int Nt, int Nr, int D, int dtype, float* scores, void* workspace, void* stream) {
     if (n_img <= 0) return 0;
     if (Nt <= 0 || Nr <= 0 || D <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "ascore: empty tensor");
     if (dtype == VISREP_BF16) {
         if (D % 16) return visrep_set_error(VISREP_ERR_SHAPE, "ascore: bf16 path needs D % 16 == 0");
-        const int rc = run<bf16_t>(other, ref, n_img, Nt, Nr, D, scores, (float*)workspace, (hipStream_t)stream);
+        const int rc = run<bf16_t>(other, ref, other_scale, ref_scale, n_img, Nt, Nr, D, scores, (float*)workspace, (hipStream_t)stream);
         return rc ? visrep_set_error(rc, "ascore: launch failed") : 0;
     }
     if (dtype == VISREP_F32) {
         if (D % 8) return visrep_set_error(VISREP_ERR_SHAPE, "ascore: fp32 path needs D % 8 == 0");
-        const int rc = run<float>(other, ref, n_img, Nt, Nr, D, scores, (float*)workspace, (hipStream_t)stream);
+        const int rc = run<float>(other, ref, other_scale, ref_scale, n_img, Nt, Nr, D, scores, (float*)workspace, (hipStream_t)stream);
         return rc ? visrep_set_error(rc, "ascore: launch failed") : 0;
     }
     return visrep_set_error(VISREP_ERR_ARG, "ascore: dtype must be VISREP_BF16 or VISREP_F32");
+}
+
+extern "C" int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, int dtype, float* scores,
+                                    void* workspace, void* stream) {
+    return visrep_ascore_maxcos_scaled(other, ref, nullptr, nullptr, n_img, Nt, Nr, D, dtype, scores, workspace, stream);
 }

@@ -28,12 +28,20 @@ def a_scores_from_features(features: Dict[str, torch.Tensor], refs=("clip336", "
     if any(r not in features for r in refs):
         raise ValueError("Failed to load tensors from 'clip336' or 'clip224' subfolder")          # the reference's error (compute.py:34-35)
     results = {}
+    scales = {}                                                     # row factors: once per feature set, not once per (encoder, reference)
+
+    def scale_of(key, n):
+        if key not in scales:
+            scales[key] = AC._row_scales(features[key])
+        sc = scales[key]
+        return None if sc is None else sc[:n]
     for name, other in features.items():
         totals = []
         for r in refs:
             ref = features[r]
             n = min(other.shape[0], ref.shape[0])
-            s = AC._score_batch(other[:n], ref[:n]).double().cpu()
+            same = other.dtype == ref.dtype
+            s = AC._score_batch(other[:n], ref[:n], scale_of(name, n) if same else None, scale_of(r, n) if same else None).double().cpu()
             totals.append(sum(float(s[i]) for i in range(n)) / n)
         results[name] = (totals[0] + totals[1]) / 2
     if verbose:

@@ -47,6 +47,28 @@ def test_ascore_vs_oracle(dtype, Nt, Nr, D):
     assert ((got - want).abs() / want.abs()).max().item() < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_ascore_precomputed_row_scales(dtype):
+    """row_scales = the two normalisations of compute.py:12-15,64-65 per row; scores with factors handed in are bit-identical."""
+    g = torch.Generator().manual_seed(9)
+    o = (torch.randn(5, 70, 128, generator=g) * 3).to(dtype)
+    r = torch.randn(5, 33, 128, generator=g).to(dtype)
+    o[1, 3] = 0                                                       # a zero row: the eps clamps decide
+    od, rd = o.to(DEV), r.to(DEV)
+    so, sr = ascore_ops.row_scales(od), ascore_ops.row_scales(rd)
+    nrm = o.float().norm(dim=-1)
+    want = (1.0 / (nrm + 1e-10)) / torch.clamp(nrm / (nrm + 1e-10), min=1e-8)
+    torch.testing.assert_close(so.cpu(), want, rtol=2e-6, atol=0)
+    base = ascore_ops.max_cos_mean(od, rd)
+    assert torch.equal(ascore_ops.max_cos_mean(od, rd, so, sr), base)
+    assert torch.equal(ascore_ops.max_cos_mean(od, rd, so, None), base) and torch.equal(ascore_ops.max_cos_mean(od, rd, None, sr), base)
+    with pytest.raises(ValueError):
+        ascore_ops.max_cos_mean(od, rd, so[:, :5], sr)
+    if dtype == torch.bfloat16:
+        with pytest.raises(ValueError):                               # bf16 factors on the mixed-dtype (fp32) path
+            ascore_ops.max_cos_mean(od, rd.float(), so, None)
+
+
 def test_ascore_self_is_one():
     x = torch.randn(2, 300, 512)
     got = ascore_ops.max_cos_mean(x.to(DEV), x.to(DEV)).cpu()
