@@ -20,6 +20,7 @@ Not built (fail loudly): training (`DO_EVAL` false), ADAPT_FLIP
 import argparse
 import os
 import pickle
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -80,11 +81,13 @@ def build_feature_bank(args, aggre_net, files, num_patches, dev, models=None):
         if f not in uniq:
             uniq[f] = len(uniq)
         slot.append(uniq[f])
-    maps = []
-    for f in uniq:
+    def load(f):
         per_model = [aggre_net(torch.load(_feature_path(f, False, args.ENSEMBLE, m), map_location="cpu")).reshape(-1, num_patches ** 2).float()
                      for m in models]
-        maps.append(torch.cat(per_model, 0) if len(per_model) > 1 else per_model[0])
+        return torch.cat(per_model, 0) if len(per_model) > 1 else per_model[0]
+    # each distinct map is read ONCE (the reference reloads both maps of every pair, pck_train.py:31-39), a few files in flight
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        maps = list(pool.map(load, uniq))
     return torch.stack(maps).to(dev), np.asarray(slot, dtype=np.int32)
 
 
