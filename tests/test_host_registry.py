@@ -41,9 +41,10 @@ def test_diffusion_spec_tables_and_image_processor():
     from law_of_vision_representation_in_mllms_amd import sd_weights as SW
     from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM import diffusion_encoder as DE
     assert DE.feature_hid_size_mapping['runwayml/stable-diffusion-v1-5'] == 1280
-    assert list(DE.build_featurelizer_mapping) == ['lambdalabs/sd-image-variations-diffusers', 'stabilityai/stable-diffusion-2-1',
-                                                   'runwayml/stable-diffusion-v1-5', 'stabilityai/stable-diffusion-xl-base-1.0',
-                                                   'facebook/DiT-XL-2-512', 'stabilityai/stable-diffusion-3-medium-diffusers']
+    assert sorted(DE.build_featurelizer_mapping) == sorted(['lambdalabs/sd-image-variations-diffusers', 'stabilityai/stable-diffusion-2-1',
+                                                            'runwayml/stable-diffusion-v1-5', 'stabilityai/stable-diffusion-xl-base-1.0',
+                                                            'facebook/DiT-XL-2-512', 'stabilityai/stable-diffusion-3-medium-diffusers'])
+    assert DE.feature_hid_size_mapping['runwayml/stable-diffusion-v1-5_feature'] == 1280 and len(DE.feature_hid_size_mapping) == 7
     u = SW.SD_SPECS['runwayml/stable-diffusion-v1-5'].unet
     table = dict(SW.unet_param_table(u, n_up_blocks=1))
     assert table['up_blocks.0.resnets.2.conv1.weight'] == (1280, 2560, 3, 3)          # 1280 + skip 1280
