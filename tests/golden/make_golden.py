@@ -1014,7 +1014,27 @@ def gen_policy():
         ok, picked = ns["validate_run"](b, list(tm), top)
         out[f"val.{i}.benchmark"], out[f"val.{i}.train"], out[f"val.{i}.top"] = np.array(b), np.array(tm), np.array(top)
         out[f"val.{i}.ok"], out[f"val.{i}.picked"] = np.array(bool(ok)), np.array(picked.to_list())
+    # policy/prediction.py: the leave-k-out search, run as the script it is (csv path replaced, subset sizes bounded to keep it short)
+    psrc = open(f"{REF}/policy/prediction.py").read().replace("/Users/shijiayang/Desktop/Vision_Feature_AC_private/visualizations/ablations_t.csv", csv)
+    assert "range(2, len(all_models) + 1)" in psrc
+    sizes = [2, 3, 11, 12]
+    psrc = psrc.replace("range(2, len(all_models) + 1)", repr(sizes))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                exec(compile(psrc, "prediction.py", "exec"), {"__name__": "__main__"})
+            hits = pd.read_csv("benchmark_train_model_performance_all.csv")
+        finally:
+            os.chdir(cwd)
+    out["pred.sizes"] = np.array(sizes)
+    out["pred.benchmark"] = hits["Benchmark"].to_numpy().astype(str)
+    out["pred.train"] = hits["Train Models"].to_numpy().astype(str)               # str(tuple) as pandas wrote it
+    out["pred.test_mse"] = hits["Test MSE"].to_numpy(np.float64)
+    out["pred.train_mse"] = hits["Train MSE"].to_numpy(np.float64)
     np.savez_compressed(f"{HERE}/policy.npz", **out)
+    print("policy.npz  prediction hits:", len(hits))
     print("policy.npz  R2(AC, poly):", np.round(out["fit.AC.polynomial"], 4))
 
 
