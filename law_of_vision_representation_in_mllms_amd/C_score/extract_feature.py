@@ -87,6 +87,19 @@ def _dift_maps(px, post_noise=None, ddim_noise=None):
 
 
 def _load_pixels(image_path, size):
+    """extract_feature.py:65-67: RGB, resize((s, s)) (PIL bicubic), PILToTensor, (x / 255 - 0.5) * 2 in float32.  The arithmetic is
+    done in numpy: the same correctly-rounded float32 operations, without torch's intra-op thread pool waking up for a 150k-element
+    tensor (on a 256-core host that cost more than the JPEG decode: 29 ms per image serial, profiles/round1_pipeline.md)."""
+    img = Image.open(image_path).convert('RGB').resize((size, size))
+    a = np.asarray(img).transpose(2, 0, 1).astype(np.float32)               # PILToTensor layout: [3, H, W]
+    return torch.from_numpy((a / np.float32(255.0) - np.float32(0.5)) * np.float32(2.0))
+
+
+def _load_pixels_worker(image_path, size):
+    """_load_pixels for the decode pool, with the arithmetic as torch ops: inside a pool thread they run inline (no intra-op
+    fan-out) and release the GIL, whereas the numpy steps of _load_pixels make eight threads queue on the GIL.  Measured on a
+    256-core host, 1024 JPEGs -> DINOv2-L maps -> files: torch-in-pool 690-790 images/s, numpy-in-pool 180-210, and on the calling
+    thread torch 34 vs numpy 200-310 (profiles/round1_pipeline.md).  Same bits either way (tests/test_host_preprocess.py)."""
     img = Image.open(image_path).convert('RGB').resize((size, size))
     a = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)           # PILToTensor: uint8 [3, H, W]
     return (a / 255.0 - 0.5) * 2
@@ -95,8 +108,16 @@ def _load_pixels(image_path, size):
 def _load_pixels_device(image_path, size, device="cuda"):
     """Same values as _load_pixels, but only the JPEG decode runs on the host: Pillow-exact bicubic resize and the
     (x / 255 - 0.5) * 2 arithmetic run on the GPU (device_preprocess)."""
+    return _finish_on_device(_decode_rgb(image_path, size), size, device)
+
+
+def _decode_rgb(image_path, size=None):
+    """JPEG -> uint8 [H, W, 3] on the host (the part that runs on the decode pool)."""
+    return np.array(Image.open(image_path).convert('RGB'))
+
+
+def _finish_on_device(a, size, device="cuda"):
     from .. import device_preprocess as DP
-    a = np.array(Image.open(image_path).convert('RGB'))
     dev = torch.from_numpy(a).to(device)
     return DP.to_tensor(DP.resize_u8(dev, (size, size)), (0, 0, size, size), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
 
@@ -117,20 +138,22 @@ def extract_features(image_path):
     return _to_maps(_state.dift.forward(px))
 
 
-def _prefetched(chunks, load, workers):
-    """Yield (chunk, pixel batch) with JPEG decode (+ resize) of chunk i+1 running on a thread pool while the GPU works on chunk i
-    (PIL releases the GIL while decoding; the reference decodes, runs and saves one image at a time)."""
+def _prefetched(chunks, load, workers, finish=None):
+    """Yield (chunk, pixel batch) with `load` (JPEG decode, + resize on the host path) of chunk i+1 running on a thread pool while
+    the GPU works on chunk i (PIL releases the GIL while decoding; the reference decodes, runs and saves one image at a time).
+    `finish` (device resize + normalise of one decoded image) runs on the calling thread, which owns the HIP stream."""
     from concurrent.futures import ThreadPoolExecutor
+    done = (lambda x: x) if finish is None else (lambda x: finish(x, _state.img_size))
     if workers <= 1 or not chunks:
         for chunk in chunks:
-            yield chunk, torch.stack([load(p, _state.img_size) for p, _ in chunk])
+            yield chunk, torch.stack([done(load(p, _state.img_size)) for p, _ in chunk])
         return
     with ThreadPoolExecutor(max_workers=workers) as pool:
         submit = lambda chunk: [pool.submit(load, p, _state.img_size) for p, _ in chunk]
         pending = submit(chunks[0])
         for i, chunk in enumerate(chunks):
             nxt = submit(chunks[i + 1]) if i + 1 < len(chunks) else None
-            yield chunk, torch.stack([f.result() for f in pending])
+            yield chunk, torch.stack([done(f.result()) for f in pending])
             pending = nxt
 
 
@@ -148,14 +171,31 @@ def process_images(input_dir, output_dir, workers=8):
     d = torch.distributed
     if d.is_available() and d.is_initialized():
         todo = todo[d.get_rank()::d.get_world_size()]                        # image-sharded across ranks, no collective
-    load = _load_pixels_device if getattr(_state, "device_preprocess", False) else _load_pixels
+    on_device = getattr(_state, "device_preprocess", False)           # decode on the pool, resize + normalise on the GPU
     chunks = [todo[s:s + _state.batch] for s in range(0, len(todo), _state.batch)]
-    for chunk, px in _prefetched(chunks, load, 1 if getattr(_state, "device_preprocess", False) else workers):
-        maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
-        for (_, out), m in zip(chunk, maps):
-            os.makedirs(os.path.dirname(out), exist_ok=True)
-            torch.save(m.unsqueeze(0).clone(), out)
-            print(f'Saved features to {out}')
+    from concurrent.futures import ThreadPoolExecutor
+
+    def save(m, out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        torch.save(m, out)
+    # the 1-MB-per-image pickles are written by a small pool behind the GPU (they were most of the loop's wall-clock:
+    # profiles/round1_pipeline.md); at most two batches of maps are in flight
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, 8))) as writers:
+        inflight = []
+        stream = (_prefetched(chunks, _decode_rgb, workers, _finish_on_device) if on_device
+                  else _prefetched(chunks, _load_pixels_worker if workers > 1 else _load_pixels, workers))
+        for chunk, px in stream:
+            maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
+            batch = [writers.submit(save, m.unsqueeze(0).clone(), out) for (_, out), m in zip(chunk, maps)]
+            for (_, out) in chunk:
+                print(f'Saved features to {out}')
+            inflight.append(batch)
+            if len(inflight) > 2:
+                for f in inflight.pop(0):
+                    f.result()
+        for batch in inflight:
+            for f in batch:
+                f.result()                                             # re-raises a failed write
 
 
 if __name__ == "__main__":

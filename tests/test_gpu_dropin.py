@@ -135,6 +135,14 @@ def test_extract_feature_and_pck_train_on_device(small_towers, tmp_path):
     assert f.shape == (1, 128, 3, 3)
     one = EF.extract_features(str(src / "im1.jpg"))
     assert rel(one, f) < 1e-2
+    # resize + normalise on the device (decode on the pool): bit-identical pixels, so bit-identical files
+    EF._state.device_preprocess = True
+    try:
+        EF.process_images(str(tmp_path / "JPEGImages"), str(tmp_path / "features_dev"), workers=4)
+    finally:
+        EF._state.device_preprocess = False
+    for i in range(3):
+        assert torch.equal(torch.load(tmp_path / "features_dev" / "cat" / f"im{i}_dino.pt"), torch.load(tmp_path / "features" / "cat" / f"im{i}_dino.pt"))
     spec = small_towers['facebook/dinov2-large']
     px = EF._load_pixels(str(src / "im1.jpg"), 42).unsqueeze(0)
     want = tower_oracle(spec, px, 'patch').permute(0, 2, 1).reshape(1, 128, 3, 3)

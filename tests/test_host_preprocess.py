@@ -23,3 +23,18 @@ def test_coeff_tables_shape_and_sum():
     assert b.shape == (224, 2) and k.shape == (224, ks) and ks == 13
     assert np.all(np.abs(k.sum(1) - (1 << 22)) <= ks)             # rows sum to 1.0 in 22-bit fixed point, up to rounding
     assert b[0, 0] == 0 and b[-1].sum() == 640
+
+
+def test_c_path_loader_is_the_reference_expression(tmp_path):
+    """extract_feature.py:65-67: resize((s, s)) -> PILToTensor -> (x / 255 - 0.5) * 2, bit for bit (the loader does it in numpy)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from law_of_vision_representation_in_mllms_amd.C_score import extract_feature as EF
+    rs = np.random.RandomState(4)
+    Image.fromarray(rs.randint(0, 256, (90, 130, 3), dtype=np.uint8)).save(tmp_path / "a.jpg")
+    img = Image.open(tmp_path / "a.jpg").convert('RGB').resize((56, 56))
+    want = (torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1) / 255.0 - 0.5) * 2
+    for load in (EF._load_pixels, EF._load_pixels_worker):                # calling-thread and decode-pool forms of the same expression
+        got = load(str(tmp_path / "a.jpg"), 56)
+        assert got.dtype == torch.float32 and got.shape == (3, 56, 56) and torch.equal(got, want)
