@@ -35,7 +35,7 @@ class SimpleImageProcessor:
             img = img.crop((l, t, l + self.crop, t + self.crop))
         a = np.asarray(img, dtype=np.float32) / 255.0
         a = (a - np.asarray(self.image_mean, np.float32)) / np.asarray(self.image_std, np.float32)
-        return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))   # numpy copy: a torch op here would wake the intra-op pool per image
 
     def preprocess(self, images, return_tensors="pt"):
         if not isinstance(images, (list, tuple)):
