@@ -98,6 +98,8 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
 def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models):
     if getattr(args, "ADAPT_FLIP", False):
         raise NotImplementedError("ADAPT_FLIP is not built (the reference's get_distance only accepts 60x60 maps; SURVEY §8f N4)")
+    if getattr(args, "TOTAL_SAVE_RESULT", 0):
+        raise NotImplementedError("TOTAL_SAVE_RESULT > 0 asks for the matplotlib match visualisations (utils_visualization.py), which are not built")
     geo = bool(getattr(args, "COMPUTE_GEOAWARE_METRICS", False))
     P = args.NUM_PATCHES
     N = len(files) // 2

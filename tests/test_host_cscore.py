@@ -137,6 +137,9 @@ def test_unsupported_modes_fail_loudly(tmp_path, cpu_ops):
     a.ADAPT_FLIP = True
     with pytest.raises(NotImplementedError):
         PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+    a.ADAPT_FLIP, a.TOTAL_SAVE_RESULT = False, 5                      # qualitative PNGs of the first pairs: not built, says so
+    with pytest.raises(NotImplementedError, match="TOTAL_SAVE_RESULT"):
+        PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
 
 
 def _worker(rank, world, tmp, port, q):
