@@ -44,6 +44,40 @@ def flops_per_image(spec, n_layers):
     return n_layers * per_layer + patch
 
 
+def timed_steps(step, steps, warmup, dist=None, device=None):
+    """The measurement protocol: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by device-sync + barrier + device-sync on
+    both sides; returns (seconds = MAX over ranks, last step's result).  `device` None = host-only stepping (the gloo test of this
+    function); with a device, torch.cuda.synchronize fences the HIP stream."""
+    def sync():
+        if device is not None:
+            torch.cuda.synchronize(device)
+
+    def fence():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+    result = None
+    for _ in range(warmup):
+        result = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        result = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, result
+
+
+def aggregate_value(world, per_rank_units, steps, seconds):
+    """Whole-job throughput: units of ALL ranks (weak scaling: every rank steps over its own batch) / max-over-ranks time."""
+    return world * per_rank_units * steps / seconds
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,29 +118,11 @@ def main():
     def step():
         return eng.forward(px, n_layers=N_LAYERS, out=out)[:, 1:]        # feature_select 'patch' (clip_encoder.py:31-32)
 
-    for _ in range(args.warmup):
-        step()
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        feats = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, feats = timed_steps(step, args.steps, args.warmup, dist, dev)
     assert torch.isfinite(feats.float()).all()
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
+    value = aggregate_value(world, B, args.steps, dt)
     fl_img = flops_per_image(spec, N_LAYERS)
 
     # ---- roofline of the dominant kernel, timed with HIP events on the launch stream
