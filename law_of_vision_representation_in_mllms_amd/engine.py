@@ -85,15 +85,16 @@ class VitEngine:
             """Linear(LayerNorm(x)) = rstd * (x (g o W)^T - mean * s) + (W b + bias): (g o W in bf16, s over the ROUNDED rows, b')."""
             Wb = Wm.detach().float().to(torch.bfloat16).float()               # the weights the unfused path multiplies with
             Wf = (Wb * g.detach().float()[None]).to(torch.bfloat16)
-            return Wf, Wf.float().sum(1), Wb @ b.detach().float() + bias.detach().float()
+            shift = Wb @ b.detach().float()                                  # beta pushed through the linear map
+            return Wf, Wf.float().sum(1), shift if bias is None else shift + bias.detach().float()
 
         for i, L in enumerate(weights["layers"]):
             ent = self._layers[i]
             L = dict(L)
             extra = {"sqkv": None, "s1": None}
             if self.fuse_ln:
-                L["wqkv"], extra["sqkv"], L["bqkv"] = fold(L["wqkv"], L["bqkv"], L["ln1_g"], L["ln1_b"])
-                L["w1"], extra["s1"], L["b1"] = fold(L["w1"], L["b1"], L["ln2_g"], L["ln2_b"])
+                L["wqkv"], extra["sqkv"], L["bqkv"] = fold(L["wqkv"], L.get("bqkv"), L["ln1_g"], L["ln1_b"])
+                L["w1"], extra["s1"], L["b1"] = fold(L["w1"], L.get("b1"), L["ln2_g"], L["ln2_b"])
             for k in ("wqkv", "wo", "w1", "w2"):
                 setattr(ent, k, mat(L[k]).data_ptr())
             for k in ("ln1_g", "ln1_b", "bqkv", "bo", "ls1", "ln2_g", "ln2_b", "b1", "b2", "ls2"):
