@@ -28,15 +28,22 @@ def normalize_feat(feat, epsilon=1e-10):
 
 
 def load_tensors(subfolder, n=100):
-    # compute.py:18-28: tensor_1.pt .. tensor_100.pt; any error -> message + empty list (encoder skipped by the caller)
+    """compute.py:18-28: tensor_1.pt .. tensor_100.pt; any error -> message + empty list (encoder skipped by the caller).
+    The files are read a few at a time; results are consumed in index order, so the FIRST missing / broken file is the one reported,
+    as in the reference's sequential loop."""
+    from concurrent.futures import ThreadPoolExecutor
+    paths = [os.path.join(base_folder, subfolder, f"tensor_{i}.pt") for i in range(1, n + 1)]
     tensors = []
-    for i in range(1, n + 1):
-        tensor_path = os.path.join(base_folder, subfolder, f"tensor_{i}.pt")
-        try:
-            tensors.append(torch.load(tensor_path, map_location="cpu"))
-        except Exception as e:
-            print(f"Error loading {tensor_path}: {e}")
-            return []
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        futures = [pool.submit(torch.load, p, map_location="cpu") for p in paths]
+        for tensor_path, fut in zip(paths, futures):
+            try:
+                tensors.append(fut.result())
+            except Exception as e:
+                print(f"Error loading {tensor_path}: {e}")
+                for f in futures:
+                    f.cancel()
+                return []
     return tensors
 
 
