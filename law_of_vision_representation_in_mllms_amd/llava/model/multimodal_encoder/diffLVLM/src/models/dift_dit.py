@@ -5,7 +5,6 @@ forward computes the 2x2-unfolded block output [B, 4*D, h/2, w/2] and then falls
 (dift_dit.py:196), so `DiffVisionTower.forward` cannot work with it as committed; this class returns that tensor.
 `prompt` is unused by the reference (class-unconditional, timestep-only conditioning) and here.
 """
-import json
 import os
 
 import torch

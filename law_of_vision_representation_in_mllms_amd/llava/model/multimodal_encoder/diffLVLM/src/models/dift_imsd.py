@@ -15,7 +15,7 @@ from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder._v
 from law_of_vision_representation_in_mllms_amd.sd_engine import SdEngine
 from law_of_vision_representation_in_mllms_amd.sd_weights import SD_SPECS, SdSpec, synthetic_unet, synthetic_vae
 
-from .dift_sd import _json, _load_dir, spec_from_checkpoint
+from .dift_sd import _load_dir, spec_from_checkpoint
 
 IMSD_ID = 'lambdalabs/sd-image-variations-diffusers'
 
@@ -37,7 +37,6 @@ class IMSDFeaturizer:
         synthetic = os.environ.get("VISREP_SYNTHETIC_WEIGHTS") == "1" if synthetic is None else synthetic
         root = None if synthetic else _find_local_checkpoint(sd_id)
         if root is not None:
-            import json
             self.spec, _ = spec_from_checkpoint(sd_id, root, need_text=False)
             self._wu, self._wv = _load_dir(os.path.join(root, "unet")), _load_dir(os.path.join(root, "vae"))
             from transformers import CLIPVisionConfig

@@ -16,7 +16,6 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional
 
-import numpy as np
 import torch
 
 from . import _lib

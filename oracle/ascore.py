@@ -11,7 +11,6 @@ divides each operand by max(||x||, 1e-8) before the dot product).
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 

@@ -1,8 +1,6 @@
 """GPU tests of the drop-in surface: tower classes, '.'-fusion + mm_projector (encode_images), feature dump, A_score.compute
 and C_score.extract_feature / pck_train on device — each against the CPU oracle on the same inputs."""
-import argparse
 import os
-import shutil
 import sys
 from types import SimpleNamespace
 

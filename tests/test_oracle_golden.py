@@ -1,5 +1,4 @@
 """Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz, made by make_golden.py)."""
-import ast
 import os
 
 import numpy as np

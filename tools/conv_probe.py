@@ -1,7 +1,7 @@
 """TFLOP/s of the implicit-GEMM 3x3 convolution at the SD1.5 VAE / UNet shapes (batch 4)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from law_of_vision_representation_in_mllms_amd import _lib, sd_engine as SE
+from law_of_vision_representation_in_mllms_amd import sd_engine as SE
 dev = torch.device("cuda:0")
 SE.ensure_scratch(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
