@@ -227,7 +227,7 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     else if (nd == 2) hipLaunchKernelGGL(attn_fwd<2>, grid, block, lds, st, a);
     else {
         static bool attr = false;                           // 96 KB of dynamic LDS needs the opt-in once
-        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         hipLaunchKernelGGL(attn_fwd<3>, grid, block, lds, st, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "attention: launch failed");
