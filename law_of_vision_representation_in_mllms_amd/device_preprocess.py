@@ -36,12 +36,34 @@ def _bicubic(x: float) -> float:
     return 0.0
 
 
+def _sinc(x: float) -> float:
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x
+
+
+def _lanczos(x: float) -> float:                      # Pillow's lanczos_filter: truncated sinc, a = 3
+    return _sinc(x) * _sinc(x / 3) if -3.0 <= x < 3.0 else 0.0
+
+
+def _bilinear(x: float) -> float:
+    x = -x if x < 0.0 else x
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+# name -> (kernel, support) as in Pillow's Resample.c (BICUBIC: PIL's default for Image.resize; LANCZOS: the GeoAware-SC image loader,
+# C_score/utils/utils_correspondence.py:75-114)
+FILTERS = {"bicubic": (_bicubic, 2.0), "lanczos": (_lanczos, 3.0), "bilinear": (_bilinear, 1.0)}
+
+
 @lru_cache(maxsize=256)
-def pil_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
-    """(bounds int32 [out, 2] = (xmin, count), kk int32 [out, ksize], ksize) of Pillow's bicubic filter for one axis."""
+def pil_coeffs(in_size: int, out_size: int, filter: str = "bicubic") -> Tuple[np.ndarray, np.ndarray, int]:
+    """(bounds int32 [out, 2] = (xmin, count), kk int32 [out, ksize], ksize) of one of Pillow's resampling filters for one axis."""
+    kernel, base_support = FILTERS[filter]
     scale = float(in_size) / out_size
     filterscale = scale if scale >= 1.0 else 1.0
-    support = 2.0 * filterscale
+    support = base_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), np.int32)
     kk = np.zeros((out_size, ksize), np.int32)
@@ -55,7 +77,7 @@ def pil_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int
         if xmax > in_size:
             xmax = in_size
         xmax -= xmin
-        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        w = [kernel((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = 0.0
         for v in w:
             ww += v
@@ -66,14 +88,14 @@ def pil_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int
     return bounds, kk, ksize
 
 
-def resample_reference(img: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
+def resample_reference(img: np.ndarray, size: Tuple[int, int], filter: str = "bicubic") -> np.ndarray:
     """The same two fixed-point passes in numpy (host check of the tables; not used by the product path)."""
     ow, oh = size
     out = img
     for axis, (n_in, n_out) in ((1, (img.shape[1], ow)), (0, (img.shape[0], oh))):
         if n_in == n_out:
             continue
-        bounds, kk, _ = pil_coeffs(n_in, n_out)
+        bounds, kk, _ = pil_coeffs(n_in, n_out, filter)
         src = np.moveaxis(out.astype(np.int64), axis, 0)
         dst = np.empty((n_out,) + src.shape[1:], np.uint8)
         for xx in range(n_out):
@@ -87,16 +109,17 @@ def resample_reference(img: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
 _TABLES = {}
 
 
-def _device_tables(n_in, n_out, device):
-    key = (n_in, n_out, str(device))
+def _device_tables(n_in, n_out, device, filter="bicubic"):
+    key = (n_in, n_out, str(device), filter)
     if key not in _TABLES:
-        bounds, kk, ksize = pil_coeffs(n_in, n_out)
+        bounds, kk, ksize = pil_coeffs(n_in, n_out, filter)
         _TABLES[key] = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
     return _TABLES[key]
 
 
-def resize_u8(img: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
-    """img uint8 [H, W, 3] on the GPU -> uint8 [OH, OW, 3], bit-identical to PIL `Image.resize((OW, OH), BICUBIC)`."""
+def resize_u8(img: torch.Tensor, size: Tuple[int, int], filter: str = "bicubic") -> torch.Tensor:
+    """img uint8 [H, W, 3] on the GPU -> uint8 [OH, OW, 3], bit-identical to PIL `Image.resize((OW, OH), <filter>)`
+    (filter: "bicubic" = PIL's default, "lanczos", "bilinear" - the kernel only sees coefficient tables)."""
     lib = _lib.require_gpu()
     if img.dtype != torch.uint8 or img.dim() != 3:
         raise ValueError("resize_u8 wants a uint8 [H, W, C] tensor")
@@ -104,18 +127,63 @@ def resize_u8(img: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
     H, W, C = img.shape
     cur = img.contiguous()
     if W != ow:                                                   # horizontal pass: line = row
-        b, k, ks = _device_tables(W, ow, cur.device)
+        b, k, ks = _device_tables(W, ow, cur.device, filter)
         nxt = torch.empty(H, ow, C, dtype=torch.uint8, device=cur.device)
         rc = lib.visrep_resample_u8(_lib.ptr(cur), _lib.ptr(nxt), H, ow, C, W * C, C, ow * C, C, _lib.ptr(b), _lib.ptr(k), ks, _lib.stream_ptr())
         _lib.check(rc, "visrep_resample_u8")
         cur = nxt
     if H != oh:                                                   # vertical pass: line = column
-        b, k, ks = _device_tables(H, oh, cur.device)
+        b, k, ks = _device_tables(H, oh, cur.device, filter)
         nxt = torch.empty(oh, ow, C, dtype=torch.uint8, device=cur.device)
         rc = lib.visrep_resample_u8(_lib.ptr(cur), _lib.ptr(nxt), ow, oh, C, C, ow * C, C, ow * C, _lib.ptr(b), _lib.ptr(k), ks, _lib.stream_ptr())
         _lib.check(rc, "visrep_resample_u8")
         cur = nxt
     return cur
+
+
+def geoaware_geometry(width: int, height: int, target_res: int):
+    """(resized (w, h), (top, left) of the image inside the target_res square) of the GeoAware-SC loader
+    (utils_correspondence.py:75-114): long side -> target_res, short side np.around(), centred with floor-divided offsets."""
+    if height <= width:
+        w, h = target_res, int(np.around(target_res * height / width))
+        return (w, h), ((w - h) // 2, 0)
+    w, h = int(np.around(target_res * width / height)), target_res
+    return (w, h), (0, (h - w) // 2)
+
+
+def geoaware_resize(img: torch.Tensor, target_res: int = 224, edge: bool = False) -> torch.Tensor:
+    """Device twin of utils_correspondence.resize(img, target_res, resize=True, edge=...): uint8 [H, W, 3] on the GPU ->
+    uint8 [target_res, target_res, 3]: LANCZOS resize of the long side to target_res, then zero padding (edge=False) or
+    edge replication (edge=True, np.pad mode='edge') of the short side.  Bit-identical to the PIL + numpy original."""
+    H, W, _ = img.shape
+    (w, h), (top, left) = geoaware_geometry(W, H, target_res)
+    small = resize_u8(img, (w, h), "lanczos")
+    if not edge:
+        canvas = torch.zeros(target_res, target_res, 3, dtype=torch.uint8, device=img.device)
+        canvas[top:top + h, left:left + w] = small
+        return canvas
+    if H <= W:                                                 # rows are missing: replicate the first / last row
+        tp = (target_res - h) // 2
+        rows = torch.cat([small[:1].expand(tp, -1, -1), small, small[-1:].expand(target_res - h - tp, -1, -1)], 0)
+        return rows.contiguous()
+    lp = (target_res - w) // 2
+    return torch.cat([small[:, :1].expand(-1, lp, -1), small, small[:, -1:].expand(-1, target_res - w - lp, -1)], 1).contiguous()
+
+
+def geoaware_resize_reference(img: np.ndarray, target_res: int = 224, edge: bool = False) -> np.ndarray:
+    """geoaware_resize in numpy over resample_reference (host check; not used by the product path)."""
+    H, W, _ = img.shape
+    (w, h), (top, left) = geoaware_geometry(W, H, target_res)
+    small = resample_reference(img, (w, h), "lanczos")
+    if not edge:
+        canvas = np.zeros((target_res, target_res, 3), np.uint8)
+        canvas[top:top + h, left:left + w] = small
+        return canvas
+    if H <= W:
+        tp = (target_res - h) // 2
+        return np.pad(small, [(tp, target_res - h - tp), (0, 0), (0, 0)], mode='edge')
+    lp = (target_res - w) // 2
+    return np.pad(small, [(0, 0), (lp, target_res - w - lp), (0, 0)], mode='edge')
 
 
 def to_tensor(img: torch.Tensor, box: Tuple[int, int, int, int], mean: Sequence[float], std: Sequence[float], dtype=torch.float32,

@@ -700,6 +700,31 @@ def gen_nextsets():
             print(k, out[k])
 
 
+# ----------------------------------------------------------------------------- GeoAware-SC image loader (LANCZOS resize + pad)
+def gen_georesize():
+    """utils_correspondence.resize (C_score/utils/utils_correspondence.py:75-114) on small random images: landscape / portrait /
+    square, zero padding and edge padding; plus PIL's LANCZOS and BILINEAR resampling on their own."""
+    from PIL import Image
+    sys.path.insert(0, f"{REF}/C_score")
+    _stub_modules()
+    import utils.utils_correspondence as UC
+    rs = np.random.RandomState(61)
+    out = {}
+    cases = [("land", 71, 50), ("port", 45, 83), ("square", 60, 60), ("wide", 120, 33), ("up", 20, 31)]
+    T = 48
+    for tag, w, h in cases:
+        a = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        a[: h // 3] = rs.randint(0, 2, (h // 3, w, 3)) * 255                 # hard edges: the filter's negative lobes clip
+        out[f"{tag}.in"] = a
+        for edge in (False, True):
+            out[f"{tag}.edge{int(edge)}"] = np.asarray(UC.resize(Image.fromarray(a), T, resize=True, to_pil=True, edge=edge))
+        out[f"{tag}.lanczos"] = np.asarray(Image.fromarray(a).resize((37, 29), Image.Resampling.LANCZOS))
+        out[f"{tag}.bilinear"] = np.asarray(Image.fromarray(a).resize((37, 29), Image.Resampling.BILINEAR))
+    out["target"] = np.array(T)
+    np.savez_compressed(f"{HERE}/georesize.npz", **out)
+    print("georesize.npz", len(out))
+
+
 # ----------------------------------------------------------------------------- Stable-Diffusion feature tower
 SD_CASES = {   # tag: (linear_projection, up_ft_index, ensemble, t, batch, image side, weight seed)
     "conv_up0": (False, 0, 1, 100, 2, 64, 11),
@@ -1069,7 +1094,7 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize}[w]()

@@ -38,3 +38,20 @@ def test_c_path_loader_is_the_reference_expression(tmp_path):
     for load in (EF._load_pixels, EF._load_pixels_worker):                # calling-thread and decode-pool forms of the same expression
         got = load(str(tmp_path / "a.jpg"), 56)
         assert got.dtype == torch.float32 and got.shape == (3, 56, 56) and torch.equal(got, want)
+
+
+def test_lanczos_bilinear_tables_and_geoaware_loader_match_reference():
+    """Pillow's LANCZOS / BILINEAR resampling and the GeoAware-SC loader (utils_correspondence.resize: LANCZOS long side -> target,
+    zero or edge padding) restated on the host, bit for bit against outputs of PIL / the reference function (georesize.npz)."""
+    import os
+    import numpy as np
+    from law_of_vision_representation_in_mllms_amd import device_preprocess as DP
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "georesize.npz"))
+    T = int(z["target"])
+    for tag in ("land", "port", "square", "wide", "up"):
+        a = z[f"{tag}.in"]
+        assert np.array_equal(DP.resample_reference(a, (37, 29), "lanczos"), z[f"{tag}.lanczos"]), tag
+        assert np.array_equal(DP.resample_reference(a, (37, 29), "bilinear"), z[f"{tag}.bilinear"]), tag
+        for edge in (False, True):
+            assert np.array_equal(DP.geoaware_resize_reference(a, T, edge), z[f"{tag}.edge{int(edge)}"]), (tag, edge)
+    assert DP.geoaware_geometry(500, 375, 840) == ((840, 630), (105, 0)) and DP.geoaware_geometry(375, 500, 840) == ((630, 840), (0, 105))
