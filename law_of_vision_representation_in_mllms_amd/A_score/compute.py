@@ -147,7 +147,12 @@ def main(argv=None):
     ap.add_argument("--subfolders", nargs="*", default=None)
     ap.add_argument("--n-images", type=int, default=100)
     a = ap.parse_args(argv)
-    compute(a.base_folder, a.subfolders, a.n_images)
+    from .. import dist_env
+    owned = dist_env.init_from_env()                                  # under torchrun: one process per GPU, images sharded over ranks
+    try:
+        return compute(a.base_folder, a.subfolders, a.n_images, device="cuda" if torch.cuda.is_available() else "cpu")
+    finally:
+        dist_env.finalize(owned)
 
 
 if __name__ == "__main__":

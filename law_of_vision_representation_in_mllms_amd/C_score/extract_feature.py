@@ -199,5 +199,10 @@ def process_images(input_dir, output_dir, workers=8):
 
 
 if __name__ == "__main__":
-    configure(feature)
-    process_images(input_path, output_path)
+    from .. import dist_env
+    _owned = dist_env.init_from_env()                                 # under torchrun: images sharded rank::world
+    try:
+        configure(feature)
+        process_images(input_path, output_path)
+    finally:
+        dist_env.finalize(_owned)

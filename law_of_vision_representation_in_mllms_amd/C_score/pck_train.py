@@ -233,10 +233,17 @@ def main(args, _eval=None):
     aggre_net = DummyAggregationNetwork()
     if not args.DO_EVAL:
         raise NotImplementedError("training is out of scope of the scoring path; run with DO_EVAL (configs/eval_zero_shot_spair.yaml)")
-    with torch.no_grad():
-        pck_010, pck_005, pck_001, result = (_eval or eval)(args, aggre_net, save_path, split='test')
-    with open(save_path + '/result.pkl', 'wb') as f:
-        pickle.dump(result, f)
+    from .. import dist_env
+    owned = dist_env.init_from_env()                                  # under torchrun: pairs of every category sharded over ranks
+    try:
+        with torch.no_grad():
+            pck_010, pck_005, pck_001, result = (_eval or eval)(args, aggre_net, save_path, split='test')
+        d = _dist()
+        if d is None or d.get_rank() == 0:
+            with open(save_path + '/result.pkl', 'wb') as f:
+                pickle.dump(result, f)
+    finally:
+        dist_env.finalize(owned)
     return pck_010, pck_005, pck_001
 
 
