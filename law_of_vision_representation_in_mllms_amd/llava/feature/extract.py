@@ -123,16 +123,12 @@ def build_parser():
 
 def main(argv=None):
     args, _ignored = build_parser().parse_known_args(argv)
-    if "RANK" in os.environ and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
+    from ... import dist_env
+    owned = dist_env.init_from_env()                                  # under torchrun / deepspeed launchers: one process per GPU
     try:
-        n = inference(args, args, args)
-        if dist.is_initialized():
-            dist.barrier()
-        return n
+        return inference(args, args, args)
     finally:
-        cleanup()
+        dist_env.finalize(owned)                                      # barrier + teardown (extract.py:259-260)
 
 
 if __name__ == "__main__":
