@@ -226,20 +226,25 @@ def main(args, _eval=None):
         args.SAMPLE = None
     save_path = f'./results_{args.EVAL_DATASET}/pck_train_{args.NOTE}_sample_{args.EPOCH}_{args.SAMPLE}_lr_{args.LR}'
     os.makedirs(save_path, exist_ok=True)
-    get_logger(save_path + '/result.log')
-    logger.info(args)
-    if not args.DUMMY_NET:
-        raise NotImplementedError("the supervised AggregationNetwork post-processor is outside the zero-shot C score (SURVEY §8f N4)")
-    aggre_net = DummyAggregationNetwork()
-    if not args.DO_EVAL:
-        raise NotImplementedError("training is out of scope of the scoring path; run with DO_EVAL (configs/eval_zero_shot_spair.yaml)")
     from .. import dist_env
     owned = dist_env.init_from_env()                                  # under torchrun: pairs of every category sharded over ranks
+    d = _dist()
+    lead = d is None or d.get_rank() == 0
     try:
+        if lead:
+            get_logger(save_path + '/result.log')                     # one log file, one result.pkl: rank 0's
+        else:
+            import logging
+            get_logger().setLevel(logging.WARNING)
+        logger.info(args)
+        if not args.DUMMY_NET:
+            raise NotImplementedError("the supervised AggregationNetwork post-processor is outside the zero-shot C score (SURVEY §8f N4)")
+        aggre_net = DummyAggregationNetwork()
+        if not args.DO_EVAL:
+            raise NotImplementedError("training is out of scope of the scoring path; run with DO_EVAL (configs/eval_zero_shot_spair.yaml)")
         with torch.no_grad():
             pck_010, pck_005, pck_001, result = (_eval or eval)(args, aggre_net, save_path, split='test')
-        d = _dist()
-        if d is None or d.get_rank() == 0:
+        if lead:
             with open(save_path + '/result.pkl', 'wb') as f:
                 pickle.dump(result, f)
     finally:
