@@ -19,6 +19,7 @@ def init_from_env() -> bool:
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver stack
     if torch.cuda.is_available():
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
