@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 112
+#define VISREP_VERSION 200
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
@@ -53,7 +53,8 @@ int visrep_debug_gemm_timing_buffer(void* dev_u64x16);
 /* ---- optional device scratch owned by the caller (e.g. one torch tensor kept alive for the process).  With it,
  * visrep_gemm_bf16 splits the K loop of problems that have few output tiles but a deep reduction (the diffusion towers'
  * 3x3 convolutions at 12x12 / 24x24 resolution) across CUs and reduces the fp32 partial planes in slice order, i.e.
- * deterministically.  Not thread-safe against concurrent GEMMs on other streams: one scratch per process.  (NULL, 0) detaches. */
+ * deterministically.  The registration is per DEVICE (the current one at the call; a process driving several GPUs registers one
+ * buffer on each); the planes are not keyed by stream: at most one stream per device runs GEMMs at a time.  (NULL, 0) detaches. */
 int visrep_set_scratch(void* ptr, size_t bytes);
 
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
@@ -134,6 +135,27 @@ size_t visrep_vit_workspace_bytes(const visrep_vit_config* cfg, int B);
 /* hidden: [B, tokens, d] bf16 — receives hidden_states[n_layers] (the residual stream lives in it). */
 int visrep_vit_forward(const visrep_vit_config* cfg, const visrep_vit_weights* w, const void* pixels, int pixel_dtype, void* hidden,
                        int B, int n_layers, void* workspace, void* stream);
+
+/* ---- reference-precision (fp32) tower path.  The reference builds the C-score CLIP / OpenCLIP / DINOv2 towers with no dtype cast and
+ * fp32 pixels (C_score/extract_feature.py:36-45,49-50,80-87): every tensor and accumulation here is fp32 (v_mfma_f32_32x32x2_f32 = an
+ * exact fmaf chain, 157 TFLOP/s peak), so images -> tower -> A / C scores can be held to the 1e-4 bar against the fp32 reference
+ * chain.  A parity mode, ~1/20 of the bf16 engine's rate.
+ * visrep_gemm_f32: C = epi(alpha * A W^T + bias); A [M,K] (lda), W [N,K] (w_kn = 0, nn.Linear) or [K,N] (w_kn = 1), all fp32, rows
+ * 16-byte aligned (pointers, leading dimensions, batch strides % 4 floats); epilogue BIAS / ACT / RESID (C = resid + ls * (..), resid
+ * may alias C).  Batched over nb1 x nb2 problems with element strides strides6 = {A1, A2, W1, W2, C1, C2} (NULL when nb1 = nb2 = 1):
+ * replaces torch.matmul(q, k.transpose) / torch.matmul(attn, v) of HF's eager attention as well as F.linear. */
+int visrep_gemm_f32(const float* A, int lda, const float* W, int ldw, int w_kn, const float* bias, float* C, int ldc, int M, int N, int K,
+                    int epilogue, int act, const float* resid, const float* ls, float alpha, int nb1, int nb2, const long* strides6,
+                    void* stream);
+/* nn.LayerNorm in fp32 (two-pass variance); y may alias x */
+int visrep_layernorm_f32(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int d, float eps, void* stream);
+/* in-place softmax over the first `cols` entries of every row (ld >= cols) */
+int visrep_softmax_rows_f32(float* x, int ld, long rows, int cols, void* stream);
+/* composed fp32 forward = visrep_vit_forward with fp32 pixels, fp32 MATRICES in the weight struct (sqkv / s1 ignored) and an fp32
+ * hidden [B, tokens, d]; any head width that is a multiple of 4. */
+size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B);
+int visrep_vit_forward_f32(const visrep_vit_config* cfg, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
+                           void* workspace, void* stream);
 
 /* ---- A score (A_score/compute.py:12-15,54-72): scores[img] = mean_t max_s cos(other[img][t], ref[img][s]).
  * other [n_img,Nt,D], ref [n_img,Nr,D] contiguous, dtype VISREP_BF16 (D%16==0) or VISREP_F32 (D%8==0);

@@ -64,6 +64,11 @@ SIGNATURES = {
     "visrep_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
     "visrep_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
     "visrep_vit_forward": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "visrep_gemm_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, C.POINTER(C.c_long), _vp]),
+    "visrep_layernorm_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "visrep_softmax_rows_f32": (_i, [_vp, _i, _l, _i, _vp]),
+    "visrep_vit_f32_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
+    "visrep_vit_forward_f32": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _vp]),
     "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_ascore_row_scale": (_i, [_vp, C.c_long, _i, _i, _vp, _vp]),
@@ -82,9 +87,13 @@ def load(build_if_missing: bool = True):
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH) and build_if_missing:
+        if build_if_missing and not os.environ.get("VISREP_LIB"):
+            # (re)build when the library is missing OR older than its sources (content hash, see build.py); builders in other
+            # processes - the ranks of one launch - are serialised there with a file lock.  Without hipcc an existing library is
+            # used as it is (a deployment box), and a missing one is the error below.
             from . import build
-            build.build_lib()
+            if build.have_sources() and (os.path.exists(build._hipcc_or_none() or "") or not os.path.exists(LIB_PATH)):
+                build.build_lib()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m law_of_vision_representation_in_mllms_amd.build` "
                                "(there is no CPU fallback for the scoring path)")

@@ -1,60 +1,148 @@
 """Build libvisrep_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc.  In-tree output so the
-built library travels with the repo snapshot to the GPU box.  `python -m law_of_vision_representation_in_mllms_amd.build`."""
+built library travels with the repo snapshot to the GPU box.  `python -m law_of_vision_representation_in_mllms_amd.build`.
+
+One object per translation unit (compiled in parallel, cached under csrc/.obj by a content hash of the source, the headers and
+the flags), then one link.  Staleness of the library is decided by the same content hash (libvisrep_hip.srchash beside the
+library), not by mtimes - a snapshot copy of the tree (gpurun) does not have to preserve them.
+Concurrent callers - every rank of a `torch.distributed.run` launch reaches `_lib.load()` at the same time - are serialised
+with an exclusive file lock, every temporary carries the pid, and the library is moved into place with one atomic rename: a
+rank either loads the previous complete library or the new complete one, never a half-written file.
+"""
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip", "cscore.hip", "visrep_abi.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip",
+           "cscore.hip", "f32ops.hip", "visrep_abi.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
-
-
-def build_ablation_lib() -> str:
-    """Separate library with the GEMM-v2 timing ablation knobs compiled in (tools/gemm_ablate.py only)."""
-    out = os.path.join(PKG, "libvisrep_hip_ablate.so")
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-DVISREP_GEMM_ABLATE"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
-    subprocess.run(cmd, check=True, capture_output=True)
-    return out
-
-
-def build_attn_ablation_lib(mask: int) -> str:
-    """Library with -DVISREP_ATTN_ABLATE=mask (tools/attn_ablate.py only; results are wrong for mask != 0)."""
-    out = os.path.join(PKG, f"libvisrep_hip_attn{mask}.so")
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + [f"-DVISREP_ATTN_ABLATE={mask}"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
-    subprocess.run(cmd, check=True, capture_output=True)
-    return out
-
-
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+def _hipcc() -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libvisrep_hip.so")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    return hipcc
+
+
+def _hipcc_or_none():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return hipcc if os.path.exists(hipcc) else None
+
+
+def _digest(files, extra=()) -> str:
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(list(CFLAGS) + list(extra)).encode())
+    return h.hexdigest()
+
+
+def have_sources() -> bool:
+    return all(os.path.exists(os.path.join(CSRC, f)) for f in SOURCES + HEADERS)
+
+
+def source_hash(defines=()) -> str:
+    return _digest(SOURCES + HEADERS, defines)
+
+
+def _hash_file(out: str) -> str:
+    return os.path.splitext(out)[0] + ".srchash"
+
+
+def _stale(out: str = LIB, defines=()) -> bool:
+    if not os.path.exists(out) or not os.path.exists(_hash_file(out)):
+        return True
+    with open(_hash_file(out)) as fh:
+        return fh.read().strip() != source_hash(defines)
+
+
+def _compile(src: str, objdir: str, defines, verbose: bool) -> str:
+    """src -> objdir/src.<hash>.o unless that exact (source, headers, flags) combination was compiled before."""
+    path = os.path.join(CSRC, src)
+    key = _digest([src] + HEADERS, defines)[:16]
+    obj = os.path.join(objdir, f"{src}.{key}.o")
+    if os.path.exists(obj):
+        return obj
+    for old in os.listdir(objdir):                         # drop this unit's superseded objects
+        if old.startswith(src + ".") and old.endswith(".o"):
+            os.remove(os.path.join(objdir, old))
+    tmp = f"{obj}.{os.getpid()}.tmp"
+    cmd = [_hipcc()] + CFLAGS + list(defines) + ["-c", path, "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libvisrep_hip.so")
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+        raise RuntimeError(f"hipcc failed on {src}")
+    os.replace(tmp, obj)
+    return obj
+
+
+def _build(out: str, defines=(), tag: str = "", verbose: bool = False) -> str:
+    objdir = os.path.join(OBJ, tag) if tag else OBJ
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)                  # one builder at a time (per object directory), across processes
+        try:
+            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(lambda s: _compile(s, objdir, defines, verbose), SOURCES))
+            if not _stale(out, defines):
+                return out                                # another process linked it while this one waited for the lock
+            tmp = f"{out}.{os.getpid()}.tmp"
+            cmd = [_hipcc()] + LDFLAGS + objs + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc failed linking {os.path.basename(out)}")
+            os.replace(tmp, out)
+            with open(f"{_hash_file(out)}.{os.getpid()}.tmp", "w") as fh:
+                fh.write(source_hash(defines))
+            os.replace(f"{_hash_file(out)}.{os.getpid()}.tmp", _hash_file(out))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return out
+
+
+def build_ablation_lib() -> str:
+    """Separate library with the GEMM-v2 timing ablation knobs compiled in (tools/gemm_ablate.py only)."""
+    return _build(os.path.join(PKG, "libvisrep_hip_ablate.so"), ["-DVISREP_GEMM_ABLATE"], "ablate")
+
+
+def build_attn_ablation_lib(mask: int) -> str:
+    """Library with -DVISREP_ATTN_ABLATE=mask (tools/attn_ablate.py only; results are wrong for mask != 0)."""
+    return _build(os.path.join(PKG, f"libvisrep_hip_attn{mask}.so"), [f"-DVISREP_ATTN_ABLATE={mask}"], f"attn{mask}")
+
+
+def build_variant_lib(name: str, defines) -> str:
+    """Diagnostic build with extra -D flags (tools/ only): libvisrep_hip_<name>.so, loaded through VISREP_LIB."""
+    return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), list(defines), name)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    if force:
+        for f in (os.listdir(OBJ) if os.path.isdir(OBJ) else []):
+            if f.endswith(".o"):
+                os.remove(os.path.join(OBJ, f))
+        if os.path.exists(_hash_file(LIB)):
+            os.remove(_hash_file(LIB))
+    return _build(LIB, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,10 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     layout "pc": bank is position-major [n_images, P*P, C] - the towers' own [N, C] token layout; a keypoint's descriptor is one
     contiguous row, which is what the kernel wants (C and split multiples of 4).
     """
+    if soft_eval and window < 0:
+        # utils_correspondence.py:326-329: a negative window selects apply_gaussian_kernel (sigma = -window), which is hard-wired
+        # to 60 x 60 maps (np.linspace(0, 59, 60), l.285-288) and cannot run on any other grid in the reference either
+        raise NotImplementedError("SOFT_EVAL_WINDOW < 0 (Gaussian-kernel soft-argmax, 60x60 maps only in the reference) is not built")
     lib = _lib.require_gpu()
     if layout not in ("cp", "pc"):
         raise ValueError("layout must be 'cp' ([n, C, P*P]) or 'pc' ([n, P*P, C])")

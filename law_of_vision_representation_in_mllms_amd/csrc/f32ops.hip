@@ -1,0 +1,370 @@
+// Reference-precision (fp32) tower path for gfx950.
+//
+// Why it exists: the reference builds the C-score CLIP / OpenCLIP / DINOv2 towers WITHOUT a dtype cast and feeds them fp32
+// pixels (C_score/extract_feature.py:36-45,49-50,80-87) - only SigLIP and the diffusion towers run in bf16 there.  The bf16
+// MFMA engine perturbs features by ~1e-2 relative, which moves the A score by ~1e-3 and can flip PCK hits; this path keeps every
+// tensor and every accumulation in fp32 so that images -> tower -> scores can be compared with the fp32 reference chain at 1e-4.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 - fp32 operands, fp32 accumulate, bitwise a chain of fmaf (MI355X_MICROARCH.md, "Matrix
+// cores"): 157 TFLOP/s peak, 1/16 of the bf16 rate.  A parity mode, not the throughput mode: one simple LDS-staged kernel
+// (128x128x16 tiles, 4 waves, register prefetch of the next K-step) serves every contraction of the forward - patch embedding,
+// QKV / out / MLP projections with fused bias / activation / LayerScale + residual, and, batched over (image, head), Q K^T and
+// P V - so the softmax sees fp32 scores exactly like HF's eager attention (modeling_clip.py eager_attention_forward).
+#include <math.h>
+
+#include "common.h"
+#include "visrep_internal.h"
+
+namespace {
+
+struct GemmF32Args {
+    const float* A; const float* W; float* C;
+    const float* bias; const float* resid; const float* ls;
+    int M, N, K, lda, ldw, ldc;
+    int w_kn;            // 0: W is [N, K] (nn.Linear layout); 1: W is [K, N] (plain matrix product A B)
+    int epi, act;        // EPI_BIAS / EPI_ACT / EPI_RESID
+    float alpha;         // C = epi(alpha * A W + bias)
+    int nb2;             // batches: blockIdx.z = b1 * nb2 + b2, element strides below
+    long sA1, sA2, sW1, sW2, sC1, sC2;
+};
+
+constexpr int FBM = 128, FBN = 128, FBK = 16, FLD = 132;   // FLD: LDS row stride (floats); 132 * 4 B keeps 16-B alignment, 2-way write conflicts at most
+
+VR_DEV float act_f32(float x, int act) {
+    switch (act) {
+        case ACT_QUICK_GELU: return x * (1.0f / (1.0f + expf(-1.702f * x)));          // x * sigmoid(1.702 x) (HF QuickGELUActivation)
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_GELU_TANH: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+        default: return x;
+    }
+}
+
+// 16 consecutive k of one operand row -> 4 registers (float4) per chunk; rows / columns past the edge are clamped by the caller,
+// the K tail is zero-filled element by element (never reads past a row's K elements)
+VR_DEV float4 load_k4(const float* row, int k, int K) {
+    if (k + 3 < K) return *reinterpret_cast<const float4*>(row + k);
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) v.x = row[k];
+    if (k + 1 < K) v.y = row[k + 1];
+    if (k + 2 < K) v.z = row[k + 2];
+    return v;
+}
+VR_DEV float4 load_n4(const float* row, int n, int N, bool kvalid) {
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!kvalid) return v;
+    if (n + 3 < N) return *reinterpret_cast<const float4*>(row + n);
+    if (n < N) v.x = row[n];
+    if (n + 1 < N) v.y = row[n + 1];
+    if (n + 2 < N) v.z = row[n + 2];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
+    __shared__ __attribute__((aligned(16))) float As[2][FBK][FLD];
+    __shared__ __attribute__((aligned(16))) float Ws[2][FBK][FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z - b1 * p.nb2;
+    const float* A = p.A + b1 * p.sA1 + b2 * p.sA2;
+    const float* W = p.W + b1 * p.sW1 + b2 * p.sW2;
+    float* C = p.C + b1 * p.sC1 + b2 * p.sC2;
+    const float* R = p.resid ? p.resid + b1 * p.sC1 + b2 * p.sC2 : nullptr;
+    const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
+
+    // staging map, k-contiguous operands: thread -> (row r + 64 j, k chunk c); 4 lanes cover one row's 64 B
+    const int sr = tid >> 2, sc = tid & 3;
+    // staging map, [K, N] operand: thread -> (k row kr + 8 j, 4 columns at 4 * nc)
+    const int kr = tid >> 5, nc = tid & 31;
+    const float* arow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + sr + 64 * j;
+        arow[j] = A + (size_t)(m < p.M ? m : p.M - 1) * p.lda;
+    }
+    const float* wrow[2] = {nullptr, nullptr};
+    if (!p.w_kn) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + sr + 64 * j;
+            wrow[j] = W + (size_t)(n < p.N ? n : p.N - 1) * p.ldw;
+        }
+    }
+    float4 ra[2], rw[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ra[j] = load_k4(arow[j], k0 + 4 * sc, p.K);
+        if (!p.w_kn) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rw[j] = load_k4(wrow[j], k0 + 4 * sc, p.K);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + kr + 8 * j;
+                rw[j] = load_n4(W + (size_t)(k < p.K ? k : 0) * p.ldw, n0 + 4 * nc, p.N, k < p.K);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = sr + 64 * j;
+            As[buf][4 * sc + 0][r] = ra[j].x; As[buf][4 * sc + 1][r] = ra[j].y;
+            As[buf][4 * sc + 2][r] = ra[j].z; As[buf][4 * sc + 3][r] = ra[j].w;
+        }
+        if (!p.w_kn) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = sr + 64 * j;
+                Ws[buf][4 * sc + 0][r] = rw[j].x; Ws[buf][4 * sc + 1][r] = rw[j].y;
+                Ws[buf][4 * sc + 2][r] = rw[j].z; Ws[buf][4 * sc + 3][r] = rw[j].w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&Ws[buf][kr + 8 * j][4 * nc]) = rw[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{};
+
+    const int nk = (p.K + FBK - 1) / FBK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * FBK);                 // next K-step in flight under this step's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < FBK / 2; ++kk) {                  // one MFMA k-step = 2 k: lane half `hi` supplies k = 2 kk + hi
+            const float a0 = As[buf][2 * kk + hi][wm * 64 + lq], a1 = As[buf][2 * kk + hi][wm * 64 + 32 + lq];
+            const float w0 = Ws[buf][2 * kk + hi][wn * 64 + lq], w1 = Ws[buf][2 * kk + hi][wn * 64 + 32 + lq];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stash(buf ^ 1);                        // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column n = .. + lq and rows (r & 3) + 8 (r >> 2) + 4 hi of each 32x32 accumulator
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + 32 * j + lq;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float lv = p.ls ? p.ls[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (p.epi == EPI_ACT) v = act_f32(v, p.act);
+                if (p.epi == EPI_RESID) v = R[(size_t)m * p.ldc + n] + lv * v;
+                C[(size_t)m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// LayerNorm over the last dimension, fp32 throughout, two-pass variance (mean first, then the centred squares) - one wave per row
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                            const float* __restrict__ b, float* __restrict__ y, int ldy, int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; q += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    float* yr = y + (size_t)row * ldy;
+    for (int c = lane; c < d; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+}
+
+// in-place softmax over `cols` of every row (max-subtracted, expf, one division per element) - one wave per row
+__global__ __launch_bounds__(256) void softmax_f32_kernel(float* __restrict__ x, int ld, long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float e = expf(xr[c] - m); xr[c] = e; s += e; }
+    s = wave_sum(s);
+    for (int c = lane; c < cols; c += 64) xr[c] = xr[c] / s;
+}
+
+// patch gather for the patch-embedding GEMM: cols[b * P + p][c * ps * ps + ky * ps + kx] = px[b][c][gy * ps + ky][gx * ps + kx], zero pad to kpad
+__global__ void im2col_f32_kernel(const float* __restrict__ px, float* __restrict__ cols, int B, int img, int ps, int kpad) {
+    const int grid = img / ps, P = grid * grid, kk = 3 * ps * ps;
+    const long total = (long)B * P * kpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kpad);
+        const long bp = i / kpad;
+        float v = 0.f;
+        if (k < kk) {
+            const int b = (int)(bp / P), pi = (int)(bp % P), gy = pi / grid, gx = pi % grid;
+            const int c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
+            v = px[(((size_t)b * 3 + c) * img + gy * ps + ky) * img + gx * ps + kx];
+        }
+        cols[i] = v;
+    }
+}
+
+// token rows of the embedding: x[b, cls_off + p] = patches[b * P + p] + pos[cls_off + p];  x[b, 0] = cls + pos[0] (CLS towers)
+__global__ void embed_finish_f32_kernel(const float* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos,
+                                        float* __restrict__ x, int B, int T, int P, int d) {
+    const int cls_off = T - P;
+    const long total = (long)B * T * d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const long bt = i / d;
+        const int b = (int)(bt / T), t = (int)(bt % T);
+        const float pv = pos[(size_t)t * d + c];
+        x[i] = (t < cls_off) ? cls[c] + pv : patches[((size_t)b * P + (t - cls_off)) * d + c] + pv;
+    }
+}
+
+int launch_gemm_f32(const GemmF32Args& a, int nb, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || nb <= 0) return 0;
+    if ((a.lda & 3) || (a.ldw & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || (a.sA1 & 3) || (a.sA2 & 3) || (a.sW1 & 3) || (a.sW2 & 3))
+        return visrep_set_error(VISREP_ERR_SHAPE, "gemm_f32: operand rows must be 16-byte aligned (pointers, leading dimensions and batch strides % 4 floats)");
+    dim3 grid((a.N + FBN - 1) / FBN, (a.M + FBM - 1) / FBM, nb);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "gemm_f32: launch failed");
+}
+
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+struct WsF32 { size_t h, qkv, sc, mlp, total; int lds; };
+WsF32 layout_f32(const visrep_vit_config* c, int B) {
+    WsF32 w;
+    const size_t M = (size_t)B * c->tokens;
+    w.lds = (c->tokens + 3) / 4 * 4;
+    size_t off = 0;
+    w.h = off;   off += up256(M * c->d * 4);
+    w.qkv = off; off += up256(M * 3 * c->d * 4);
+    w.sc = off;  off += up256((size_t)B * c->heads * c->tokens * w.lds * 4);
+    const size_t mlp_b = M * c->mlp * 4;
+    const size_t P = (size_t)c->tokens - c->has_cls;
+    const size_t emb_b = up256((size_t)B * P * c->kpad * 4) + (size_t)B * P * c->d * 4;    // im2col columns + patch rows alias the MLP buffer
+    w.mlp = off; off += up256(mlp_b > emb_b ? mlp_b : emb_b);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+#define VR_TRY(x) do { const int rc_ = (x); if (rc_) return rc_; } while (0)
+
+extern "C" int visrep_gemm_f32(const float* A, int lda, const float* W, int ldw, int w_kn, const float* bias, float* C, int ldc, int M, int N, int K,
+                               int epilogue, int act, const float* resid, const float* ls, float alpha, int nb1, int nb2, const long* strides6,
+                               void* stream) {
+    if (!A || !W || !C) return visrep_set_error(VISREP_ERR_ARG, "gemm_f32: null pointer");
+    if (epilogue != VISREP_EPI_BIAS && epilogue != VISREP_EPI_ACT && epilogue != VISREP_EPI_RESID)
+        return visrep_set_error(VISREP_ERR_ARG, "gemm_f32: epilogue must be BIAS, ACT or RESID");
+    if (epilogue == VISREP_EPI_RESID && !resid) return visrep_set_error(VISREP_ERR_ARG, "gemm_f32: EPI_RESID needs resid");
+    if (nb1 < 1 || nb2 < 1 || (nb1 * nb2 > 1 && !strides6)) return visrep_set_error(VISREP_ERR_ARG, "gemm_f32: batch counts >= 1; strides needed when batched");
+    GemmF32Args a{};
+    a.A = A; a.W = W; a.C = C; a.bias = bias; a.resid = resid; a.ls = ls;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.w_kn = w_kn; a.epi = epilogue; a.act = act; a.alpha = alpha; a.nb2 = nb2;
+    if (strides6) { a.sA1 = strides6[0]; a.sA2 = strides6[1]; a.sW1 = strides6[2]; a.sW2 = strides6[3]; a.sC1 = strides6[4]; a.sC2 = strides6[5]; }
+    return launch_gemm_f32(a, nb1 * nb2, (hipStream_t)stream);
+}
+
+extern "C" int visrep_layernorm_f32(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int d, float eps, void* stream) {
+    if (!x || !g || !b || !y) return visrep_set_error(VISREP_ERR_ARG, "layernorm_f32: null pointer");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, g, b, y, ldy, rows, d, eps);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "layernorm_f32: launch failed");
+}
+
+extern "C" int visrep_softmax_rows_f32(float* x, int ld, long rows, int cols, void* stream) {
+    if (!x) return visrep_set_error(VISREP_ERR_ARG, "softmax_rows_f32: null pointer");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "softmax_rows_f32: launch failed");
+}
+
+extern "C" size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return layout_f32(cfg, B).total;
+}
+
+// The composed fp32 forward: same structure as visrep_vit_forward (HF CLIPVisionTransformer / Dinov2Model / SiglipVisionTransformer
+// up to hidden_states[n_layers]), every tensor fp32.  weights: the visrep_vit_weights struct with fp32 MATRICES (patch_w [d, kpad],
+// wqkv [3d, d], wo, w1, w2) - `sqkv` / `s1` (the bf16 path's folded-LayerNorm column sums) are ignored.
+extern "C" int visrep_vit_forward_f32(const visrep_vit_config* c, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
+                                      void* workspace, void* stream) {
+    if (!c || !w || !pixels || !hidden || !workspace) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32: null pointer");
+    if (B <= 0) return 0;
+    if (n_layers < 0 || n_layers > c->layers) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32: n_layers out of range");
+    if (c->d % c->heads || (c->d / c->heads) % 4 || c->d % 4 || c->mlp % 4 || c->kpad % 4)
+        return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward_f32: d, head width, mlp and kpad must be multiples of 4");
+    const int grid = c->image_size / c->patch;
+    if (grid * grid + (c->has_cls ? 1 : 0) != c->tokens) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward_f32: tokens != grid^2 + cls");
+    hipStream_t s = (hipStream_t)stream;
+    const WsF32 L = layout_f32(c, B);
+    char* base = (char*)workspace;
+    float* x = hidden;
+    float* h = (float*)(base + L.h);
+    float* qkv = (float*)(base + L.qkv);
+    float* sc = (float*)(base + L.sc);
+    float* mlp = (float*)(base + L.mlp);
+    const int d = c->d, T = c->tokens, P = grid * grid, M = B * T, H = c->heads, dh = d / H;
+
+    // ---- embeddings: conv(k = s = patch) = im2col + GEMM (+ bias), then CLS row / position add
+    float* cols = mlp;
+    float* prow = (float*)((char*)mlp + up256((size_t)B * P * c->kpad * 4));
+    hipLaunchKernelGGL(im2col_f32_kernel, dim3(2048), dim3(256), 0, s, pixels, cols, B, c->image_size, c->patch, c->kpad);
+    GemmF32Args g{};
+    g.A = cols; g.lda = c->kpad; g.W = (const float*)w->patch_w; g.ldw = c->kpad; g.C = prow; g.ldc = d; g.bias = w->patch_b;
+    g.M = B * P; g.N = d; g.K = c->kpad; g.epi = EPI_BIAS; g.alpha = 1.f; g.nb2 = 1;
+    VR_TRY(launch_gemm_f32(g, 1, s));
+    hipLaunchKernelGGL(embed_finish_f32_kernel, dim3(2048), dim3(256), 0, s, prow, w->cls, w->pos, x, B, T, P, d);
+    if (hipGetLastError() != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32: embedding launch failed");
+    if (c->pre_ln) VR_TRY(visrep_layernorm_f32(x, d, w->pre_ln_g, w->pre_ln_b, x, d, M, d, c->eps, stream));
+
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int l = 0; l < n_layers; ++l) {
+        const visrep_vit_layer& W = w->layers[l];
+        VR_TRY(visrep_layernorm_f32(x, d, W.ln1_g, W.ln1_b, h, d, M, d, c->eps, stream));
+        GemmF32Args a{};
+        a.alpha = 1.f; a.nb2 = 1;
+        a.A = h; a.lda = d; a.K = d; a.M = M; a.W = (const float*)W.wqkv; a.ldw = d; a.N = 3 * d; a.C = qkv; a.ldc = 3 * d; a.bias = W.bqkv; a.epi = EPI_BIAS;
+        VR_TRY(launch_gemm_f32(a, 1, s));
+        // scores[b, head] = scale * Q K^T   (batched over image b1 and head b2)
+        GemmF32Args q{};
+        q.A = qkv; q.lda = 3 * d; q.W = qkv + d; q.ldw = 3 * d; q.C = sc; q.ldc = L.lds; q.M = T; q.N = T; q.K = dh; q.epi = EPI_BIAS; q.alpha = scale;
+        q.nb2 = H; q.sA1 = (long)T * 3 * d; q.sA2 = dh; q.sW1 = (long)T * 3 * d; q.sW2 = dh; q.sC1 = (long)H * T * L.lds; q.sC2 = (long)T * L.lds;
+        VR_TRY(launch_gemm_f32(q, B * H, s));
+        VR_TRY(visrep_softmax_rows_f32(sc, L.lds, (long)B * H * T, T, stream));
+        // context[b, :, head] = P V
+        GemmF32Args v{};
+        v.A = sc; v.lda = L.lds; v.W = qkv + 2 * d; v.ldw = 3 * d; v.w_kn = 1; v.C = h; v.ldc = d; v.M = T; v.N = dh; v.K = T; v.epi = EPI_BIAS; v.alpha = 1.f;
+        v.nb2 = H; v.sA1 = (long)H * T * L.lds; v.sA2 = (long)T * L.lds; v.sW1 = (long)T * 3 * d; v.sW2 = dh; v.sC1 = (long)T * d; v.sC2 = dh;
+        VR_TRY(launch_gemm_f32(v, B * H, s));
+        // out projection + LayerScale + residual (in place on x)
+        a.A = h; a.W = (const float*)W.wo; a.N = d; a.C = x; a.ldc = d; a.bias = W.bo; a.epi = EPI_RESID; a.resid = x; a.ls = W.ls1;
+        VR_TRY(launch_gemm_f32(a, 1, s));
+        VR_TRY(visrep_layernorm_f32(x, d, W.ln2_g, W.ln2_b, h, d, M, d, c->eps, stream));
+        GemmF32Args f{};
+        f.alpha = 1.f; f.nb2 = 1;
+        f.A = h; f.lda = d; f.K = d; f.M = M; f.W = (const float*)W.w1; f.ldw = d; f.N = c->mlp; f.C = mlp; f.ldc = c->mlp; f.bias = W.b1; f.epi = EPI_ACT; f.act = c->act;
+        VR_TRY(launch_gemm_f32(f, 1, s));
+        f.A = mlp; f.lda = c->mlp; f.K = c->mlp; f.W = (const float*)W.w2; f.ldw = c->mlp; f.N = d; f.C = x; f.ldc = d; f.bias = W.b2; f.epi = EPI_RESID; f.act = 0;
+        f.resid = x; f.ls = W.ls2;
+        VR_TRY(launch_gemm_f32(f, 1, s));
+    }
+    return 0;
+}

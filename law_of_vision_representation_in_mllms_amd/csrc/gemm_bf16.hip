@@ -219,8 +219,11 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
 }  // namespace
 
 int g_visrep_gemm_variant = 2;
-void* g_visrep_scratch = nullptr;
-size_t g_visrep_scratch_bytes = 0;
+// split-K scratch, one registration PER DEVICE (a process that drives several GPUs registers one buffer on each; a GEMM only ever
+// uses the buffer of the device it is launched on).  One stream per device at a time may run split-K GEMMs: the planes are not keyed
+// by stream (documented in include/visrep.h).
+void* g_visrep_scratch[VISREP_MAX_DEVICES] = {};
+size_t g_visrep_scratch_bytes[VISREP_MAX_DEVICES] = {};
 int g_visrep_gemm_dbg = 0;
 unsigned long long* g_visrep_gemm_dbg_buf = nullptr;
 
@@ -274,7 +277,12 @@ namespace {
 // blockIdx.y into fp32 planes in the caller's scratch (visrep_set_scratch) and reduce them in slice order with the epilogue
 // fused.  Returns 1 when the problem was handled this way, 0 when it was not eligible, < 0 on error.
 int try_split_k(const GemmArgs& a, hipStream_t s) {
-    if (!(g_visrep_scratch && a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
+    if (!(a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VISREP_MAX_DEVICES) return 0;
+    void* const scratch = g_visrep_scratch[dev];
+    const size_t scratch_bytes = g_visrep_scratch_bytes[dev];
+    if (!scratch) return 0;
     const int ncu = cu_count();
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     // the 128x128 kernel keeps two blocks per CU resident: 2 * ncu block slots; fill them when the tiles alone do not
@@ -283,9 +291,9 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
     int S = (int)(2L * ncu / tiles);
     if (S > kt / 4) S = kt / 4;                                   // at least 4 K-tiles per slice
     while (S > 1 && kt % S) --S;
-    if (S <= 1 || (size_t)S * a.M * a.N * sizeof(float) > g_visrep_scratch_bytes) return 0;
+    if (S <= 1 || (size_t)S * a.M * a.N * sizeof(float) > scratch_bytes) return 0;
     GemmArgs part = a;
-    part.C = reinterpret_cast<bf16_t*>(g_visrep_scratch);
+    part.C = reinterpret_cast<bf16_t*>(scratch);
     part.ldc = a.N;
     part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr; part.ln_rt = nullptr; part.ln_s = nullptr;
     part.kslice = a.K / S;
@@ -293,10 +301,10 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
     if (rc) return rc;
     if (a.epi == EPI_VT) {
         const long nthreads = (long)((a.M + 3) / 4) * a.N;
-        hipLaunchKernelGGL(splitk_reduce_vt, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+        hipLaunchKernelGGL(splitk_reduce_vt, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)scratch, S, a);
     } else {
         const long nthreads = (long)a.M * (a.N / 4);
-        hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)g_visrep_scratch, S, a);
+        hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, (const float*)scratch, S, a);
     }
     return hipGetLastError() == hipSuccess ? 1 : visrep_set_error(VISREP_ERR_LAUNCH, "gemm: split-K reduce launch failed");
 }

@@ -45,8 +45,10 @@ extern "C" size_t visrep_last_error(char* buf, size_t n) {
 extern "C" int visrep_set_scratch(void* ptr, size_t bytes) {
     if ((ptr == nullptr) != (bytes == 0)) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pass (ptr, bytes) or (NULL, 0)");
     if ((size_t)ptr & 15) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pointer must be 16-byte aligned");
-    g_visrep_scratch = ptr;
-    g_visrep_scratch_bytes = bytes;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VISREP_MAX_DEVICES) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: no current device");
+    g_visrep_scratch[dev] = ptr;              // registration of the CURRENT device only
+    g_visrep_scratch_bytes[dev] = bytes;
     return 0;
 }
 

@@ -50,5 +50,6 @@ extern int g_visrep_gemm_dbg;
 extern unsigned long long* g_visrep_gemm_dbg_buf;
 extern int g_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 3 = 256x256 persistent ping-pong kernels (when N % 256 == 0)
 int visrep_set_error(int code, const char* msg);
-extern void* g_visrep_scratch;       // caller-owned device scratch (visrep_set_scratch): split-K partial sums
-extern size_t g_visrep_scratch_bytes;
+constexpr int VISREP_MAX_DEVICES = 16;
+extern void* g_visrep_scratch[VISREP_MAX_DEVICES];       // caller-owned device scratch (visrep_set_scratch), per device: split-K partial sums
+extern size_t g_visrep_scratch_bytes[VISREP_MAX_DEVICES];

@@ -219,8 +219,8 @@ class DevicePreprocessor:
     def geometry(self, w, h):
         if self.square_resize:
             return (self.crop, self.crop), (0, 0, self.crop, self.crop)
-        s = self.resize_to / min(w, h)
-        nw, nh = max(self.resize_to, int(round(w * s))), max(self.resize_to, int(round(h * s)))
+        from .llava.model.multimodal_encoder.image_processing import shortest_edge_size
+        nw, nh = shortest_edge_size(w, h, self.resize_to)            # HF rule: the long side is truncated, not rounded
         return (nw, nh), ((nw - self.crop) // 2, (nh - self.crop) // 2, self.crop, self.crop)
 
     @torch.no_grad()

@@ -21,13 +21,17 @@ _SCRATCH = {}
 
 
 def ensure_scratch(device, nbytes: int = 64 << 20) -> None:
-    """One process-wide split-K scratch for visrep_gemm_bf16 (visrep_set_scratch): few-tile problems - the 128x128 tail
-    launches of the ViT GEMMs, the low-resolution convolutions of the diffusion towers - split their K loop over idle CUs.
-    S * M * N * 4 bytes <= 33.6 MB by construction of the split rule (S * tiles <= 2 * 256 block slots, 128x128 tiles)."""
-    if "buf" not in _SCRATCH:
+    """One split-K scratch PER DEVICE for visrep_gemm_bf16 (visrep_set_scratch registers it for the current device): few-tile
+    problems - the 128x128 tail launches of the ViT GEMMs, the low-resolution convolutions of the diffusion towers - split their K
+    loop over idle CUs.  S * M * N * 4 bytes <= 33.6 MB by construction of the split rule (S * tiles <= 2 * 256 block slots,
+    128x128 tiles).  The planes are not keyed by stream: one stream per device runs GEMMs at a time (every engine here does)."""
+    device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _SCRATCH:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _lib.check(_lib.require_gpu().visrep_set_scratch(_lib.ptr(buf), nbytes), "visrep_set_scratch")
-        _SCRATCH["buf"] = buf
+        with torch.cuda.device(idx):
+            _lib.check(_lib.require_gpu().visrep_set_scratch(_lib.ptr(buf), nbytes), "visrep_set_scratch")
+        _SCRATCH[idx] = buf
 
 
 class VitEngine:
@@ -143,6 +147,116 @@ class VitEngine:
                                              _lib.ptr(out), B, n_layers, _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, "visrep_vit_forward")
         return out
+
+
+class VitEngineF32:
+    """The same tower in reference precision: fp32 weights, activations and accumulation (csrc/f32ops.hip, visrep_vit_forward_f32).
+
+    The reference's C-score CLIP / OpenCLIP / DINOv2 towers run in fp32 (C_score/extract_feature.py:36-45,49-50: no dtype cast,
+    fp32 pixels); this engine is what makes images -> tower -> A / C score comparable with that chain at the 1e-4 bar.  About
+    1/20 of the bf16 engine's throughput (exact-fp32 MFMA peak is 157 TFLOP/s), any head width that is a multiple of 4.
+    forward() returns fp32 [B, tokens, d]; images are processed in chunks so that the fp32 score matrices stay below `max_ws_bytes`."""
+
+    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30):
+        self.lib = _lib.require_gpu()
+        self.spec = spec
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if spec.d % spec.heads or (spec.d // spec.heads) % 4 or spec.mlp % 4:
+            raise ValueError("fp32 engine: d / heads and mlp must be multiples of 4")
+        self.kpad = _round_up(3 * spec.patch * spec.patch, 4)
+        self.max_ws_bytes = int(max_ws_bytes)
+        self._keep = []
+        dev = self.device
+
+        def f32(t):
+            if t is None:
+                return None
+            x = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(x)
+            return x
+
+        pw = torch.zeros(spec.d, self.kpad, dtype=torch.float32)
+        pw[:, : 3 * spec.patch * spec.patch] = weights["patch_w"].float()
+        if weights["pos"].shape[0] != spec.tokens:
+            raise ValueError(f"position embedding has {weights['pos'].shape[0]} rows, spec wants {spec.tokens}")
+        self._patch_w = f32(pw)
+        self._vecs = {k: f32(weights.get(k)) for k in ("patch_b", "cls", "pos", "pre_ln_g", "pre_ln_b")}
+        n = len(weights["layers"])
+        self.n_layers = n
+        self._layers = (_lib.VitLayer * max(n, 1))()
+        for i, L in enumerate(weights["layers"]):
+            ent = self._layers[i]
+            for k in ("wqkv", "wo", "w1", "w2", "ln1_g", "ln1_b", "bqkv", "bo", "ls1", "ln2_g", "ln2_b", "b1", "b2", "ls2"):
+                v = f32(L.get(k))
+                setattr(ent, k, 0 if v is None else v.data_ptr())
+            ent.sqkv = 0
+            ent.s1 = 0
+        self._w = _lib.VitWeights()
+        self._w.patch_w = self._patch_w.data_ptr()
+        for k, v in self._vecs.items():
+            setattr(self._w, k, 0 if v is None else v.data_ptr())
+        self._w.layers = C.cast(self._layers, C.POINTER(_lib.VitLayer))
+        self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
+                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
+        self._ws: Dict[int, torch.Tensor] = {}
+
+    def chunk(self) -> int:
+        per = self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), 1)
+        return max(1, min(64, self.max_ws_bytes // max(per, 1)))
+
+    def workspace(self, B: int) -> torch.Tensor:
+        ws = self._ws.get(B)
+        if ws is None:
+            self._ws.clear()
+            ws = torch.empty(self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), B), dtype=torch.uint8, device=self.device)
+            self._ws[B] = ws
+        return ws
+
+    @torch.no_grad()
+    def forward(self, pixels: torch.Tensor, n_layers: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        s = self.spec
+        if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != s.image_size or pixels.shape[3] != s.image_size:
+            raise ValueError(f"Input image size {tuple(pixels.shape)} doesn't match tower ({s.image_size}*{s.image_size}).")
+        n_layers = self.n_layers if n_layers is None else n_layers
+        if not 0 <= n_layers <= self.n_layers:
+            raise ValueError("n_layers out of range")
+        px = pixels.to(device=self.device, dtype=torch.float32).contiguous()
+        B = px.shape[0]
+        if out is None:
+            out = torch.empty(B, s.tokens, s.d, dtype=torch.float32, device=self.device)
+        step = self.chunk()
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, step):
+                nb = min(step, B - b0)
+                ws = self.workspace(nb)
+                rc = self.lib.visrep_vit_forward_f32(C.byref(self._cfg), C.byref(self._w), _lib.ptr(px[b0:b0 + nb]), _lib.ptr(out[b0:b0 + nb]),
+                                                     nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
+                _lib.check(rc, "visrep_vit_forward_f32")
+        return out
+
+
+def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf16"):
+    """precision 'bf16' = the MFMA throughput engine; 'fp32' = the reference-precision engine."""
+    if precision in ("bf16", torch.bfloat16):
+        return VitEngine(spec, weights, device)
+    if precision in ("fp32", "float32", torch.float32):
+        return VitEngineF32(spec, weights, device)
+    raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+
+
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS, act: str = "none",
+             resid: Optional[torch.Tensor] = None, ls: Optional[torch.Tensor] = None, w_kn: bool = False, alpha: float = 1.0,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 C = epilogue(alpha * A @ W^T + bias) (w_kn: A @ W) on the exact-fp32 MFMA path."""
+    lib = _lib.require_gpu()
+    M, K = a.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    rc = lib.visrep_gemm_f32(_lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), int(w_kn), _lib.ptr(bias), _lib.ptr(out), out.stride(0), M, N, K,
+                             epilogue, _lib.ACT[act], _lib.ptr(resid), _lib.ptr(ls), float(alpha), 1, 1, None, _lib.stream_ptr())
+    _lib.check(rc, "visrep_gemm_f32")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ thin op wrappers

@@ -38,15 +38,16 @@ class _HiddenStates:
 class _EngineModule(nn.Module):
     """`self.vision_tower` of the reference towers: callable like the HF model, exposes .dtype/.device/.config."""
 
-    def __init__(self, engine, config):
+    def __init__(self, engine, config, dtype=torch.bfloat16):
         super().__init__()
         self.engine = engine
         self.config = config
-        self._anchor = nn.Parameter(torch.zeros(1, dtype=torch.bfloat16, device=engine.device), requires_grad=False)
+        self._dtype = dtype
+        self._anchor = nn.Parameter(torch.zeros(1, dtype=dtype, device=engine.device), requires_grad=False)
 
     @property
     def dtype(self):
-        return torch.bfloat16
+        return self._dtype
 
     @property
     def device(self):
@@ -64,6 +65,22 @@ def _find_local_checkpoint(name: str) -> Optional[str]:
         return snapshot_download(name, local_files_only=True)
     except Exception:
         return None
+
+
+def _processor_crop(path: str) -> Optional[int]:
+    """crop_size of the checkpoint's preprocessor_config.json (the input size the reference's AutoImageProcessor produces)."""
+    import json
+    f = os.path.join(path, "preprocessor_config.json")
+    if not os.path.exists(f):
+        return None
+    try:
+        with open(f) as fh:
+            c = json.load(fh).get("crop_size")
+    except (OSError, ValueError):
+        return None
+    if isinstance(c, dict):
+        c = c.get("height") or c.get("shortest_edge")
+    return int(c) if c else None
 
 
 def _load_state_dict(path: str):
@@ -97,6 +114,9 @@ class HipViTTower(nn.Module):
         self._img_size = getattr(args, "vit_img_size", None)
         self._synthetic = bool(getattr(args, "synthetic_weights", False)) or os.environ.get("VISREP_SYNTHETIC_WEIGHTS") == "1"
         self._device = getattr(args, "device", None)
+        # 'bf16' (default; what LLaVA runs the tower in: model.to(bfloat16)) or 'fp32' (what C_score/extract_feature.py runs the
+        # CLIP / OpenCLIP / DINOv2 towers in: no dtype cast, fp32 pixels) - VISREP_TOWER_PRECISION overrides
+        self._precision = os.environ.get("VISREP_TOWER_PRECISION") or getattr(args, "tower_precision", None) or "bf16"
         if not delay_load:
             self.load_model()
         else:
@@ -108,7 +128,7 @@ class HipViTTower(nn.Module):
         if path is not None:
             from transformers import AutoConfig
             cfg = AutoConfig.from_pretrained(path)
-            spec = VW.spec_from_hf_config(cfg, self.vision_tower_name)
+            spec = VW.spec_from_hf_config(cfg, self.vision_tower_name, crop_size=_processor_crop(path))
             sd = _load_state_dict(path)
             sd = {k: v for k, v in sd.items() if not k.startswith(("text_model.", "logit_", "text_projection", "visual_projection"))}
             return spec, VW.pack_hf_state_dict(sd, spec)
@@ -143,7 +163,9 @@ class HipViTTower(nn.Module):
         self.image_processor = self._make_image_processor(spec)
         cfg = SimpleNamespace(hidden_size=spec.d, image_size=spec.image_size, patch_size=spec.patch,
                               num_hidden_layers=spec.layers, num_attention_heads=spec.heads, intermediate_size=spec.mlp)
-        self.vision_tower = _EngineModule(engine.VitEngine(spec, w, self._device), cfg)
+        fp32 = self._precision in ("fp32", "float32")
+        self.vision_tower = _EngineModule(engine.make_engine(spec, w, self._device, "fp32" if fp32 else "bf16"), cfg,
+                                          torch.float32 if fp32 else torch.bfloat16)
         self.vision_tower.requires_grad_(False)
         self.is_loaded = True
 

@@ -12,6 +12,14 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+def shortest_edge_size(w: int, h: int, size: int):
+    """HF get_resize_output_image_size(default_to_square=False): short side -> size, long side -> int(size * long / short)
+    (truncation, not rounding: 500 x 375 -> 298 x 224, not 299)."""
+    short, long = (w, h) if w <= h else (h, w)
+    new_long = int(size * long / short)
+    return (size, new_long) if w <= h else (new_long, size)
+
+
 class SimpleImageProcessor:
     """resize (shortest edge, bicubic) -> center crop -> /255 -> normalise; `.preprocess(img, return_tensors='pt')`."""
 
@@ -28,8 +36,8 @@ class SimpleImageProcessor:
             img = img.resize((self.crop, self.crop), Image.BICUBIC)
         else:
             w, h = img.size
-            s = self.resize_to / min(w, h)
-            img = img.resize((max(self.resize_to, int(round(w * s))), max(self.resize_to, int(round(h * s)))), Image.BICUBIC)
+            nw, nh = shortest_edge_size(w, h, self.resize_to)
+            img = img.resize((nw, nh), Image.BICUBIC)
             w, h = img.size
             l, t = (w - self.crop) // 2, (h - self.crop) // 2
             img = img.crop((l, t, l + self.crop, t + self.crop))

@@ -79,8 +79,14 @@ def tiny_spec(family: str, act: Optional[str] = None, image_size: int = 28, patc
                    heads=heads, mlp=mlp, act=act or base.act, pos_grid=0)
 
 
-def spec_from_hf_config(cfg, name: str = "") -> ViTSpec:
-    """Build a spec from a HF CLIPVisionConfig / Dinov2Config / SiglipVisionConfig."""
+def spec_from_hf_config(cfg, name: str = "", crop_size: Optional[int] = None) -> ViTSpec:
+    """Build a spec from a HF CLIPVisionConfig / Dinov2Config / SiglipVisionConfig.
+
+    DINOv2: `cfg.image_size` (518 for facebook/dinov2-*) is the NATIVE position-embedding grid (37 x 37), not the input size the
+    reference runs: its AutoImageProcessor resizes to 256 and centre-crops to `crop_size` (224 by default,
+    dinov2_encoder.py:24,44-47) and HF interpolates the position embedding down to that grid.  So the tower is built at the
+    processor's crop size (`crop_size`, read from preprocessor_config.json by the caller; 224 when absent) and only `pos_grid`
+    keeps the native size."""
     mt = getattr(cfg, "model_type", "")
     if hasattr(cfg, "vision_config") and mt in ("clip", "siglip"):
         cfg = cfg.vision_config
@@ -92,7 +98,7 @@ def spec_from_hf_config(cfg, name: str = "") -> ViTSpec:
                        cfg.num_attention_heads, cfg.intermediate_size, act, cfg.layer_norm_eps,
                        True, True, False, False, "clip")
     if mt.startswith("dinov2"):
-        return ViTSpec(name, cfg.image_size, cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
+        return ViTSpec(name, int(crop_size or 224), cfg.patch_size, cfg.hidden_size, cfg.num_hidden_layers,
                        cfg.num_attention_heads, int(cfg.hidden_size * cfg.mlp_ratio), act, cfg.layer_norm_eps,
                        True, False, True, True, "dinov2", pos_grid=cfg.image_size // cfg.patch_size)
     if mt.startswith("siglip"):

@@ -27,7 +27,7 @@ def test_library_builds_loads_and_exports_everything():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(lib, s), s
-    assert _lib.load().visrep_version() == 112
+    assert _lib.load().visrep_version() == 200
 
 
 def test_error_reporting_without_gpu_work():

@@ -70,19 +70,21 @@ def test_tower_classes_match_oracle(small_towers):
 
 
 def test_projector_matches_reference_golden():
-    z = np.load(f"{G}/projector.npz")
-    # golden widths (48 -> 96) are not MFMA-tileable: the factory must refuse them loudly, not fall back
-    p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=48, hidden_size=96))
+    # golden widths (48 -> 96) are not bf16-MFMA-tileable: in bf16 the factory must refuse them loudly, not fall back
+    p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=48, hidden_size=96)).to(torch.bfloat16)
     with pytest.raises(ValueError, match="multiples of 64"):
         p(torch.zeros(2, 48).cuda())
     p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=128, hidden_size=256))
     x = torch.randn(2, 10, 128)
     want = OP.mlp_gelu(x, [p[0].weight, p[2].weight], [p[0].bias, p[2].bias])
-    assert rel(p(x.cuda()), want) < 1e-2
+    assert rel(p(x.cuda()), want) < 1e-5                                 # fp32 parameters: the exact-fp32 path
+    pb = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=128, hidden_size=256))
+    pb.load_state_dict(p.state_dict())
+    assert rel(pb.to(torch.bfloat16)(x.cuda()), want) < 1e-2              # bf16 parameters (LLaVA's model.to(bfloat16)): bf16 MFMA path
     # diffusion-tower widths (SD 1280, DiT 4608, SD3 6144 -> LLM width): only multiples of 64 are required
-    p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=1280, hidden_size=192))
+    p = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=1280, hidden_size=192)).to(torch.bfloat16)
     x = torch.randn(3, 5, 1280)
-    assert rel(p(x.cuda()), OP.mlp_gelu(x, [p[0].weight, p[2].weight], [p[0].bias, p[2].bias])) < 1e-2
+    assert rel(p(x.cuda()), OP.mlp_gelu(x, [p[0].weight.float(), p[2].weight.float()], [p[0].bias.float(), p[2].bias.float()])) < 1e-2
 
 
 def test_fusion_stack_encode_images_and_feature_dump(small_towers, tmp_path):
