@@ -79,9 +79,9 @@ def test_layernorm_and_softmax_f32():
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(37, 1024, generator=g) * 3 + 5)
     gam, bet = torch.randn(1024, generator=g), torch.randn(1024, generator=g)
-    xd = x.to(DEV)
+    xd, gd, bd = x.to(DEV), gam.to(DEV), bet.to(DEV)                       # named: raw pointers do not keep temporaries alive
     y = torch.empty_like(xd)
-    _lib.check(lib.visrep_layernorm_f32(_lib.ptr(xd), 1024, _lib.ptr(gam.to(DEV)), _lib.ptr(bet.to(DEV)), _lib.ptr(y), 1024, 37, 1024, 1e-5, _lib.stream_ptr()), "ln")
+    _lib.check(lib.visrep_layernorm_f32(_lib.ptr(xd), 1024, _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y), 1024, 37, 1024, 1e-5, _lib.stream_ptr()), "ln")
     want = torch.nn.functional.layer_norm(x.double(), (1024,), gam.double(), bet.double(), 1e-5)
     assert rel(y, want) < 1e-6
     s = torch.randn(50, 580, generator=g) * 4
