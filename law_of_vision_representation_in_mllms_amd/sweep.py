@@ -1,0 +1,453 @@
+"""The 13-setting A + C sweep: BASELINE.json configs[4] and the second half of its metric ("A+C score wall-clock 13 encoders").
+
+For every vision-representation setting of the paper (policy/fit.py:20: CLIP336, CLIP224, OpenCLIP, DINOv2, SDim, SD1.5, SDXL, DiT, SD3,
+SD2.1, SigLIP, CLIP224+DINOv2, CLIP336+DINOv2) the reference runs, as separate scripts with files in between,
+    images -> vision tower(s) ('.'-fusion = channel concat, llava_arch.py:278-285) -> mm_projector (mlp2x_gelu, multimodal_projector/
+    builder.py:40-47) -> tensor_{k}.pt -> A_score/compute.py against the CLIP336 and CLIP224 stacks, and
+    SPair-71k images -> tower -> <img>_<model>.pt maps -> C_score/pck_train.py (pck_train_two.py for the two-encoder settings).
+Here one launcher-aware driver does both legs per setting with every feature resident in HBM (the A features of all 13 settings are
+kept: 100 x 576 x 4096 bf16 = 0.47 GB each), one process per GPU:
+
+  image-sharded mode (default; the reference's own precedent, llava/feature/extract.py:198-214): images i = rank (mod world) for
+    towers, projector and A score; the per-category C-score feature bank is built from the rank's share of the category's images and
+    ALL-GATHERED (the one real exchange step of the path: every rank's pairs may touch any image), then pairs are sharded as in
+    C_score.pck_train.  Collectives: one all-gather per (setting, category), one all-reduce of three fp64 sums per setting (A) and the
+    integer hit counters per category (C).
+  encoder-sharded A score (BASELINE.json configs[2]; `a_scores_encoder_sharded`): the CLIP336 / CLIP224 reference stacks are produced
+    image-sharded and all-gathered in image chunks on the collective's own stream while the next chunk's towers run; each rank then
+    runs ITS OWN encoders (setting i on rank i mod world) over all images and scores them against the gathered references.
+
+Timing: per setting, `device sync + barrier` on both sides of [features + scores]; weight creation and engine construction are outside
+the timed region (as the weights of the headline bench are).  Everything numeric goes through the drop-in surfaces (tower registry,
+build_vision_projector, ascore_ops, C_score.pck_train._compute_pck), so the sweep measures the product path.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import time
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+CLIP336, CLIP224 = 'openai/clip-vit-large-patch14-336', 'openai/clip-vit-large-patch14'
+OPENCLIP, DINOV2, SIGLIP = 'laion/CLIP-ViT-L-14-laion2B-s32B-b82K', 'facebook/dinov2-large', 'google/siglip-base-patch16-224'
+SD15, SD21, SDXL = 'runwayml/stable-diffusion-v1-5', 'stabilityai/stable-diffusion-2-1', 'stabilityai/stable-diffusion-xl-base-1.0'
+IMSD, DIT, SD3 = 'lambdalabs/sd-image-variations-diffusers', 'facebook/DiT-XL-2-512', 'stabilityai/stable-diffusion-3-medium-diffusers'
+
+
+@dataclass(frozen=True)
+class Setting:
+    name: str                 # policy/fit.py:20 (train_models)
+    key: str                  # A_score/compute.py:10 subfolder name
+    towers: tuple             # registry ids (llava_arch.py:29-40); two ids = '.'-fusion / pck_train_two
+    size: int                 # input side: ViT towers their own resolution; diffusion towers C_score/extract_feature.py:56-63
+    batch: int                # images per tower launch
+
+
+# order of policy/fit.py:20; the two CLIP stacks come first there too, which is what the A score needs (its references)
+SETTINGS = (
+    Setting("CLIP336", "clip336", (CLIP336,), 336, 128),
+    Setting("CLIP224", "clip224", (CLIP224,), 224, 256),
+    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 256),
+    Setting("DINOv2", "dino", (DINOV2,), 224, 256),
+    Setting("SDim", "imsd", (IMSD,), 768, 4),
+    Setting("SD1.5", "sd1.5", (SD15,), 768, 4),
+    Setting("SDXL", "sdxl", (SDXL,), 512, 4),
+    Setting("DiT", "dit", (DIT,), 512, 8),
+    Setting("SD3", "sd3", (SD3,), 512, 4),
+    Setting("SD2.1", "sd2.1", (SD21,), 768, 4),
+    Setting("SigLIP", "siglip", (SIGLIP,), 224, 256),
+    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 256),
+    Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 128),
+)
+REFS = ("clip336", "clip224")
+SPAIR_CATEGORIES = ("aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "dog", "horse", "motorbike",
+                    "person", "pottedplant", "sheep", "train", "tvmonitor")
+
+
+# ------------------------------------------------------------------------------------------------ synthetic workloads
+@dataclass
+class SpairCategory:
+    name: str
+    files: List[str]          # 2 N names (source, target per pair) - distinct images are distinct names
+    slot: np.ndarray          # [2 N] index of each file among the category's distinct images
+    n_images: int
+    kps: torch.Tensor         # [2 N, K, 3] (x, y, visible) in the 840-px annotation frame
+    thresholds: np.ndarray    # [N] bbox thresholds
+
+
+def synthetic_spair(n_images: int = 1800, n_pairs: int = 12234, kmax: int = 20, seed: int = 5, categories: Sequence[str] = SPAIR_CATEGORIES):
+    """SPair-71k-shaped evaluation set (the dataset is absent offline): 18 categories, images reused across pairs as in SPair
+    (~1,800 distinct test images for 12,234 pairs), K ~ U{3..kmax} visible key points per pair, bbox thresholds U[150, 700]."""
+    rs = np.random.RandomState(seed)
+    nc = len(categories)
+    out = []
+    for c, name in enumerate(categories):
+        ni = n_images // nc + (1 if c < n_images % nc else 0)
+        npair = n_pairs // nc + (1 if c < n_pairs % nc else 0)
+        ni = max(ni, 2)
+        src, trg = rs.randint(0, ni, npair), rs.randint(0, ni, npair)
+        slot = np.stack([src, trg], 1).reshape(-1).astype(np.int32)
+        kps = np.zeros((2 * npair, kmax, 3), np.float32)
+        kps[:, :, :2] = rs.uniform(0, 839, (2 * npair, kmax, 2))
+        nk = rs.randint(3, kmax + 1, npair)
+        vis = (np.arange(kmax)[None] < nk[:, None]).astype(np.float32)
+        kps[0::2, :, 2] = vis
+        kps[1::2, :, 2] = vis * (rs.rand(npair, kmax) > 0.1)
+        files = [f"{name}/{i:05d}.jpg" for i in slot]
+        out.append(SpairCategory(name, files, slot, ni, torch.from_numpy(kps), rs.uniform(150, 700, npair)))
+    return out
+
+
+def synthetic_pixels(ids: Sequence[int], size: int, device, dtype=torch.bfloat16, seed: int = 0) -> torch.Tensor:
+    """[len(ids), 3, size, size] in [-1, 1): one generator draw per GLOBAL image id, so a rank's share of the images is the same
+    tensor whatever the world size (the sharded sweep reproduces the single-process numbers)."""
+    g = torch.Generator(device=device)
+    out = torch.empty(len(ids), 3, size, size, dtype=dtype, device=device)
+    for j, i in enumerate(ids):
+        g.manual_seed(seed * 1000003 + int(i))
+        out[j] = (torch.rand(3, size, size, generator=g, device=device) * 2 - 1).to(dtype)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ one setting's towers + projector
+class SettingModel:
+    """Tower(s) + mlp2x_gelu projector of one setting, built through the drop-in registry (llava_arch.build_function_mapping)."""
+
+    def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16"):
+        from .llava.model import llava_arch as LA
+        from .llava.model.multimodal_projector.builder import build_vision_projector
+        self.setting, self.device = setting, torch.device(device)
+        self.towers = []
+        env = {"VISREP_SYNTHETIC_WEIGHTS": "1", "VISREP_FAST_SYNTHETIC": "1"} if synthetic else {}
+        with _environ(env):
+            for tid in setting.towers:
+                cfg = SimpleNamespace(mm_vision_tower=tid, vision_tower=tid, mm_vision_select_layer=-2, mm_vision_select_feature='patch',
+                                      up_ft_index=0, t=1, prompt='', ensemble_size=1, img_size=setting.size,        # train.py:83-87 defaults
+                                      vit_img_size=setting.size, synthetic_weights=synthetic, device=self.device, tower_precision=precision)
+                self.towers.append(LA.build_function_mapping[tid](cfg))
+        self.width = sum(t.hidden_size for t in self.towers)
+        torch.manual_seed(7)                                             # same projector on every rank
+        self.projector = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=self.width, hidden_size=hidden))
+        self.projector = self.projector.to(torch.bfloat16)               # what LLaVA's model.to(bfloat16) leaves: the bf16 MFMA path
+        self.split = self.towers[0].hidden_size if len(self.towers) == 2 else 0
+
+    @torch.no_grad()
+    def tokens(self, px: torch.Tensor) -> torch.Tensor:
+        """[B, 3, s, s] -> tower tokens [B, N, C] ('.'-fusion: channel concat of the towers' tokens, llava_arch.py:278-285)."""
+        f = [t(px) for t in self.towers]
+        return f[0] if len(f) == 1 else torch.cat(f, dim=-1)
+
+    @torch.no_grad()
+    def project(self, tok: torch.Tensor) -> torch.Tensor:
+        return self.projector(tok)
+
+
+@contextlib.contextmanager
+def _environ(kv: Dict[str, str]):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update(kv)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# ------------------------------------------------------------------------------------------------ collectives helpers
+def _dist():
+    d = torch.distributed
+    return d if d.is_available() and d.is_initialized() else None
+
+
+def _fence(device):
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    d = _dist()
+    if d is not None:
+        d.barrier()
+        if device is not None and torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, async_op: bool = False):
+    """local = rows i = rank (mod world) of a [n_total, ...] tensor -> the full tensor in global row order on every rank.
+    Rows are padded to ceil(n_total / world) per rank so the collective is one equal-size all-gather (RCCL all_gather over xGMI).
+    async_op: returns (handle, finish) - the gather runs on the collective's own stream; finish() waits and reorders."""
+    d = _dist()
+    per = (n_total + world - 1) // world
+    if d is None or world == 1:
+        return (None, lambda: local) if async_op else local
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    h = d.all_gather(parts, pad, async_op=async_op)
+
+    def finish():
+        if h is not None:
+            h.wait()
+        stacked = torch.stack(parts, 1)                               # [per, world, ...]: row j of rank r is global row j * world + r
+        return stacked.reshape((per * world,) + tuple(local.shape[1:]))[:n_total].contiguous()
+    return (h, finish) if async_op else finish()
+
+
+# ------------------------------------------------------------------------------------------------ A leg
+def _a_hooks():
+    from . import ascore_ops
+    return ascore_ops.max_cos_mean, ascore_ops.row_scales
+
+
+def a_features(model, n_images: int, ids: Sequence[int], pixels: Callable) -> torch.Tensor:
+    """projected features [len(ids), N, D] of the images `ids` (global ids)."""
+    out = []
+    B = model.setting.batch
+    for s in range(0, len(ids), B):
+        chunk = ids[s:s + B]
+        out.append(model.project(model.tokens(pixels(chunk, model.setting.size))))
+    return torch.cat(out, 0) if out else None
+
+
+def a_score_of(feat: torch.Tensor, refs: Dict[str, tuple], device, hooks=None) -> float:
+    """A_score/compute.py:51-81 for one encoder over this rank's images (all ranks' sums are all-reduced): mean over images of
+    mean_t max_s cos against clip336 and clip224, then the mean of the two."""
+    score, scales = hooks or _a_hooks()
+    n = 0 if feat is None else feat.shape[0]
+    acc = torch.zeros(3, dtype=torch.float64)
+    if n:
+        fs = scales(feat)
+        for k, r in enumerate(REFS):
+            ref, rs = refs[r]
+            s = score(feat, ref[:n], fs, rs[:n] if rs is not None else None).double().cpu()
+            acc[k] = float(sum(float(s[i]) for i in range(n)))
+        acc[2] = n
+    d = _dist()
+    if d is not None:
+        acc = acc.to(device)
+        d.all_reduce(acc)
+        acc = acc.cpu()
+    return float((acc[0] / acc[2] + acc[1] / acc[2]) / 2)
+
+
+# ------------------------------------------------------------------------------------------------ C leg
+def _c_args(P: int, window: int = 5):
+    return SimpleNamespace(NUM_PATCHES=P, SOFT_EVAL=True, SOFT_EVAL_WINDOW=window, ANNO_SIZE=840, EVAL_DATASET='spair', TRAIN_DATASET='spair',
+                           KPT_RESULT=False, ENSEMBLE=1, BBOX_THRE=True, ADAPT_FLIP=False, TOTAL_SAVE_RESULT=0, COMPUTE_GEOAWARE_METRICS=False,
+                           MODEL="fused")
+
+
+def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int):
+    """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set with the per-category bank built in HBM: this rank's share
+    of the category's distinct images -> tokens [n, P^2, C] fp32 -> all-gather -> _compute_pck (pairs sharded, counters all-reduced)."""
+    from .C_score import pck_train as PT
+    from .C_score.utils.logger import log_weighted_pcks, update_stats
+    aggre = PT.DummyAggregationNetwork()
+    pcks, pcks_05, pcks_01, weights, kpt_weights = ([] for _ in range(5))
+    args = None
+    B = model.setting.batch
+    for ci, cat in enumerate(spair):
+        ids = list(range(rank, cat.n_images, world))
+        local = []
+        for s in range(0, len(ids), B):
+            gids = [ci * 100000 + i for i in ids[s:s + B]]
+            local.append(model.tokens(pixels(gids, model.setting.size)).float())
+        if local:
+            loc = torch.cat(local, 0)
+        else:
+            probe = model.tokens(pixels([ci * 100000], model.setting.size)).float()
+            loc = probe[:0]
+        bank = all_gather_rows(loc.contiguous(), cat.n_images, rank, world)
+        P = int(round(bank.shape[1] ** 0.5))
+        if P * P != bank.shape[1]:
+            raise ValueError(f"{model.setting.name}: {bank.shape[1]} tokens is not a square map")
+        if args is None:
+            args = _c_args(P)
+        layout = "pc"
+        if bank.shape[2] % 4 or model.split % 4:
+            bank, layout = bank.transpose(1, 2).contiguous(), "cp"
+        pck, _, _, img_correct = PT._compute_pck(args, ".", aggre, cat.files, cat.kps, cat.name, None, cat.thresholds,
+                                                 (bank, cat.slot, model.split, layout), models=("fused",))
+        update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, pck, img_correct)
+        del bank
+    import logging
+    quiet = logging.getLogger("visrep.sweep")
+    return log_weighted_pcks(args, quiet, pcks, pcks_05, pcks_01, weights)
+
+
+# ------------------------------------------------------------------------------------------------ the sweep
+def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spair: Optional[Sequence[SpairCategory]] = None,
+              device="cuda", build: Optional[Callable[[Setting], object]] = None, pixels: Optional[Callable] = None, a_hooks=None,
+              hidden: int = 4096, precision: str = "bf16", do_a: bool = True, do_c: bool = True, verbose: bool = False) -> dict:
+    """Runs the sweep on this process' share (one process per GPU; world size from torch.distributed).  Returns
+    {"wall_s", "setup_s", "per_setting": {name: {"a_s", "c_s", "A", "pck": [..3], "images"}}, "images", "img_s_per_gpu", ...}.
+    build / pixels / a_hooks: injection points for the CPU tests (stand-in towers; the oracle as the score kernels)."""
+    d = _dist()
+    rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
+    dev = torch.device(device)
+    import logging
+    clog = logging.getLogger("visrep.cscore")
+    old_level = clog.level
+    clog.setLevel(logging.WARNING)                                       # 18 per-category lines x 13 settings are not a bench output
+    try:
+        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world)
+    finally:
+        clog.setLevel(old_level)
+
+
+def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world):
+    build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision))
+    pixels = pixels or (lambda ids, size: synthetic_pixels(ids, size, dev))
+    if spair is None and do_c:
+        spair = synthetic_spair()
+    per, refs, pending = {}, {}, []
+    _, scales_fn = a_hooks or (_a_hooks() if do_a else (None, None))
+    wall = setup = 0.0
+    n_c_images = sum(c.n_images for c in spair) if do_c else 0
+    my_a = list(range(rank, n_a_images, world))
+    for st in settings:
+        t0 = time.perf_counter()
+        model = build(st)
+        _fence(dev)
+        t_setup = time.perf_counter() - t0
+        setup += t_setup
+        ent = {"setup_s": round(t_setup, 3)}
+        if do_a:
+            _fence(dev)
+            t0 = time.perf_counter()
+            feat = a_features(model, n_a_images, my_a, pixels)
+            if st.key in REFS:
+                refs[st.key] = (feat, scales_fn(feat) if feat is not None else None)
+            pending.append((st, feat))
+            if all(r in refs for r in REFS):                           # both references exist: score everything that waited for them
+                for pst, pf in pending:
+                    per.setdefault(pst.name, {})["A"] = a_score_of(pf, refs, dev, a_hooks)
+                pending = []
+            _fence(dev)
+            ent["a_s"] = round(time.perf_counter() - t0, 4)
+            wall += time.perf_counter() - t0
+        if do_c:
+            _fence(dev)
+            t0 = time.perf_counter()
+            pck = c_score_of(model, spair, pixels, dev, rank, world)
+            _fence(dev)
+            ent["c_s"] = round(time.perf_counter() - t0, 4)
+            ent["pck"] = [float(x) for x in pck]
+            wall += time.perf_counter() - t0
+        ent["images"] = (n_a_images if do_a else 0) + n_c_images
+        per.setdefault(st.name, {}).update(ent)
+        if verbose and rank == 0:
+            print(f"[sweep] {st.name}: {per[st.name]}", flush=True)
+        del model
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+    if pending:
+        raise ValueError("the A score needs the clip336 and clip224 settings in the sweep (A_score/compute.py:31-35)")
+    images = sum(v["images"] for v in per.values())
+    return {"wall_s": round(wall, 3), "setup_s": round(setup, 3), "world": world, "settings": len(per), "images": images,
+            "img_s": round(images / wall, 2) if wall else None, "img_s_per_gpu": round(images / wall / world, 2) if wall else None,
+            "a_images_per_setting": n_a_images if do_a else 0, "c_images_per_setting": n_c_images,
+            "c_pairs_per_setting": sum(len(c.thresholds) for c in spair) if do_c else 0, "tower_precision": precision,
+            "scaling": "strong (fixed total work, images sharded rank::world)", "per_setting": per}
+
+
+# ------------------------------------------------------------------------------------------------ encoder-sharded A score (configs[2])
+def a_scores_encoder_sharded(settings: Sequence[Setting], n_images: int, device="cuda", build=None, pixels=None, a_hooks=None, chunk: int = 32,
+                             hidden: int = 4096, precision: str = "bf16") -> Dict[str, float]:
+    """BASELINE.json configs[2]: "A_score ... encoder-sharded".  The two CLIP reference stacks are needed by every encoder, so they
+    are produced image-sharded (every rank runs CLIP336 / CLIP224 on images i = rank mod world) and ALL-GATHERED in chunks of `chunk`
+    images per rank: the gather of chunk k is issued asynchronously (it runs on the collective's own stream) and chunk k + 1's tower
+    forward is enqueued behind it on the compute stream, so the xGMI transfer hides under the towers.  Every other setting is owned
+    by ONE rank (setting j of the non-reference list on rank j mod world), which runs its tower + projector over ALL images and
+    scores them against the gathered references; the per-encoder results are exchanged with one all_gather_object at the end.
+    Returns {setting name: A score} on every rank - equal to the single-process / image-sharded numbers."""
+    d = _dist()
+    rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
+    dev = torch.device(device)
+    build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision))
+    pixels = pixels or (lambda ids, size: synthetic_pixels(ids, size, dev))
+    score, scales = a_hooks or _a_hooks()
+    by_key = {s.key: s for s in settings}
+    if any(r not in by_key for r in REFS):
+        raise ValueError("the A score needs the clip336 and clip224 settings (A_score/compute.py:31-35)")
+    refs = {}
+    per = (n_images + world - 1) // world
+    for r in REFS:
+        model = build(by_key[r])
+        mine = list(range(rank, n_images, world))
+        pieces, inflight = [], None
+        for s in range(0, per, chunk):
+            ids = mine[s:s + chunk]
+            n_here = min(chunk, per - s)                              # rows this chunk holds per rank (padded on short ranks)
+            f = model.project(model.tokens(pixels(ids, model.setting.size))) if ids else None
+            if f is None:
+                probe = model.project(model.tokens(pixels([0], model.setting.size)))
+                f = probe[:0]
+            if inflight is not None:
+                pieces.append(inflight())                              # the previous chunk's gather had this chunk's forward to hide under
+            n_glob = min(n_images - s * world, n_here * world)
+            _, inflight = all_gather_rows(f.contiguous(), n_glob, rank, world, async_op=True)
+        if inflight is not None:
+            pieces.append(inflight())
+        full = torch.cat(pieces, 0)                                   # chunk c holds global rows [c * chunk * world, ...), in order
+        refs[r] = (full, scales(full))
+        del model
+    results = {}
+    others = [s for s in settings]
+    for j, st in enumerate(others):
+        if j % world != rank:
+            continue
+        if st.key in REFS:
+            feat = refs[st.key][0]
+        else:
+            model = build(st)
+            feat = a_features(model, n_images, list(range(n_images)), pixels)
+            del model
+        fs = scales(feat)
+        tot = []
+        for r in REFS:
+            ref, rs = refs[r]
+            s = score(feat, ref, fs, rs).double().cpu()
+            tot.append(sum(float(s[i]) for i in range(n_images)) / n_images)
+        results[st.name] = (tot[0] + tot[1]) / 2
+    if d is not None:
+        allr = [None] * world
+        d.all_gather_object(allr, results)
+        results = {k: v for part in allr for k, v in part.items()}
+    return {s.name: results[s.name] for s in settings}
+
+
+def main(argv=None):
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(description="13-setting A + C sweep (MI355X)")
+    ap.add_argument("--a-images", type=int, default=100)
+    ap.add_argument("--c-images", type=int, default=1800)
+    ap.add_argument("--c-pairs", type=int, default=12234)
+    ap.add_argument("--settings", nargs="*", default=None, help="subset of setting names (default: all 13)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"], help="ViT tower precision (fp32 = the reference's C-path dtype)")
+    ap.add_argument("--mode", default="image", choices=["image", "encoder"], help="image-sharded sweep, or the encoder-sharded A score only")
+    a = ap.parse_args(argv)
+    from . import dist_env
+    owned = dist_env.init_from_env()
+    try:
+        sel = [s for s in SETTINGS if a.settings is None or s.name in a.settings]
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        if a.mode == "encoder":
+            out = a_scores_encoder_sharded(sel, a.a_images, dev, precision=a.precision)
+        else:
+            out = run_sweep(sel, a.a_images, synthetic_spair(a.c_images, a.c_pairs), dev, precision=a.precision, verbose=True)
+        if not _dist() or _dist().get_rank() == 0:
+            print(json.dumps(out), flush=True)
+        return out
+    finally:
+        dist_env.finalize(owned)
+
+
+if __name__ == "__main__":
+    main()

@@ -203,8 +203,12 @@ def synthetic_weights(spec: ViTSpec, seed: int = 1, n_layers: Optional[int] = No
     """
     rs = np.random.RandomState(seed)
     d, m, p = spec.d, spec.mlp, spec.patch
+    import os
+    fast = torch.Generator().manual_seed(seed) if os.environ.get("VISREP_FAST_SYNTHETIC") == "1" else None   # throughput runs only
 
     def rn(*shape, std=0.02, mean=0.0):
+        if fast is not None:
+            return torch.randn(shape, generator=fast) * std + mean
         return torch.from_numpy((rs.standard_normal(shape) * std + mean).astype(np.float32))
 
     w = {

@@ -1,0 +1,170 @@
+"""Host logic of the 13-setting A + C sweep driver (law_of_vision_representation_in_mllms_amd/sweep.py) on CPU: the sharding, the
+all-gather of the C-score feature bank, the A-score all-reduce and the encoder-sharded A score (BASELINE.json configs[2] / [4]),
+single process and on 2 gloo ranks.  Towers are deterministic CPU stand-ins, the score kernels are the oracle (monkeypatched
+hooks, like tests/test_host_cscore.py / test_host_ascore.py) - the product has no CPU fallback; this exercises the driver only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(__file__))
+from test_host_cscore import cpu_pck_counts, cpu_transfer  # noqa: E402
+
+from law_of_vision_representation_in_mllms_amd import cscore_ops, sweep as S  # noqa: E402
+from oracle import ascore as OA, cscore as OC  # noqa: E402
+
+D_OUT = 32
+SETTINGS = (S.Setting("CLIP336", "clip336", ("a",), 24, 3), S.Setting("CLIP224", "clip224", ("b",), 16, 4),
+            S.Setting("DINOv2", "dino", ("c",), 16, 3), S.Setting("CLIP224+DINOv2", "clip224+dino", ("b", "c"), 16, 2))
+
+
+class FakeModel:
+    """tokens = 4x4 mean-pooled pixels through a fixed linear map per tower id; project = another fixed linear map."""
+
+    def __init__(self, st):
+        self.setting = st
+        self.maps = []
+        for tid in st.towers:
+            g = torch.Generator().manual_seed(sum(map(ord, tid)))
+            self.maps.append(torch.randn(3 * 16, 8, generator=g))
+        g = torch.Generator().manual_seed(99 + len(st.towers))
+        self.proj = torch.randn(8 * len(st.towers), D_OUT, generator=g)
+        self.split = 8 if len(st.towers) == 2 else 0
+
+    def tokens(self, px):
+        B, _, s, _ = px.shape
+        p = px.float().unfold(2, 4, 4).unfold(3, 4, 4)                      # [B, 3, s/4, s/4, 4, 4]
+        p = p.permute(0, 2, 3, 1, 4, 5).reshape(B, (s // 4) ** 2, 48)
+        return torch.cat([p @ m for m in self.maps], -1)
+
+    def project(self, tok):
+        return tok @ self.proj
+
+
+def fake_pixels(ids, size):
+    out = torch.empty(len(ids), 3, size, size)
+    g = torch.Generator()
+    for j, i in enumerate(ids):
+        g.manual_seed(1000 + int(i))
+        out[j] = torch.rand(3, size, size, generator=g) * 2 - 1
+    return out
+
+
+def oracle_score(o, r, o_scale=None, r_scale=None):
+    return torch.tensor([OA.max_cos_mean(o[i], r[i]) for i in range(o.shape[0])])
+
+
+HOOKS = (oracle_score, lambda x: None)
+
+
+def spair_small():
+    return S.synthetic_spair(n_images=14, n_pairs=20, kmax=6, seed=3, categories=("aeroplane", "cat", "dog"))
+
+
+def run(world_rank=None):
+    return S.run_sweep(SETTINGS, n_a_images=7, spair=spair_small(), device="cpu", build=FakeModel, pixels=fake_pixels, a_hooks=HOOKS)
+
+
+@pytest.fixture
+def cpu_ops(monkeypatch):
+    monkeypatch.setattr(cscore_ops, "transfer", cpu_transfer)
+    monkeypatch.setattr(cscore_ops, "pck_counts", cpu_pck_counts)
+
+
+def direct_a(name):
+    st = {s.name: s for s in SETTINGS}
+    f = lambda s: list(FakeModel(s).project(FakeModel(s).tokens(fake_pixels(range(7), s.size))))
+    return OA.a_score(f(st[name]), f(st["CLIP336"]), f(st["CLIP224"]))[0]
+
+
+def direct_c(st):
+    model = FakeModel(st)
+    per_cat, weights = [], []
+    for ci, cat in enumerate(spair_small()):
+        maps = model.tokens(fake_pixels([ci * 100000 + i for i in range(cat.n_images)], st.size))
+        P = int(round(maps.shape[1] ** 0.5))
+        feats = []
+        for s in cat.slot:
+            m = maps[int(s)]
+            if model.split:
+                m = OC.normalize_feats_two(m[None], model.split)[0]
+            feats.append(m.t().reshape(1, -1, P, P))
+        N = len(cat.thresholds)
+        _, img_correct, _ = OC.category_pck(feats, list(range(N)), cat.kps, cat.thresholds, P)
+        per_cat.append(img_correct[:3])
+        weights.append(N)
+    return OC.weighted_pcks(per_cat, weights)
+
+
+def test_sweep_single_process_equals_the_oracle_chain(cpu_ops):
+    out = run()
+    assert out["settings"] == 4 and out["world"] == 1
+    assert out["images"] == 4 * (7 + 14) and out["c_pairs_per_setting"] == 20
+    for st in SETTINGS:
+        ent = out["per_setting"][st.name]
+        assert abs(ent["A"] - direct_a(st.name)) < 1e-9, st.name
+        np.testing.assert_allclose(ent["pck"], direct_c(st), atol=1e-7, err_msg=st.name)
+
+
+def test_sweep_needs_both_references(cpu_ops):
+    with pytest.raises(ValueError, match="clip336 and clip224"):
+        S.run_sweep(SETTINGS[2:3], n_a_images=3, spair=spair_small(), device="cpu", build=FakeModel, pixels=fake_pixels, a_hooks=HOOKS, do_c=False)
+
+
+def test_all_gather_rows_single_process_is_identity():
+    x = torch.arange(12.).view(4, 3)
+    assert torch.equal(S.all_gather_rows(x, 4, 0, 1), x)
+    h, fin = S.all_gather_rows(x, 4, 0, 1, async_op=True)
+    assert h is None and torch.equal(fin(), x)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cscore_ops.transfer, cscore_ops.pck_counts = cpu_transfer, cpu_pck_counts
+    out = S.run_sweep(SETTINGS, n_a_images=7, spair=spair_small(), device="cpu", build=FakeModel, pixels=fake_pixels, a_hooks=HOOKS)
+    enc = S.a_scores_encoder_sharded(SETTINGS, 7, device="cpu", build=FakeModel, pixels=fake_pixels, a_hooks=HOOKS, chunk=2)
+    x = torch.arange(10.)[rank::world].view(-1, 1) * torch.ones(1, 3)
+    gathered = S.all_gather_rows(x, 10, rank, world)
+    q.put((rank, out, enc, gathered.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sweep_and_encoder_sharded_a_score_equal_single_process(cpu_ops):
+    single = run()
+    enc_single = S.a_scores_encoder_sharded(SETTINGS, 7, device="cpu", build=FakeModel, pixels=fake_pixels, a_hooks=HOOKS, chunk=2)
+    for st in SETTINGS:
+        assert abs(enc_single[st.name] - single["per_setting"][st.name]["A"]) < 1e-12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, enc, gathered in got:
+        assert out["world"] == 2 and out["images"] == single["images"]
+        np.testing.assert_array_equal(gathered[:, 0], np.arange(10.))          # global row order restored, padding dropped
+        for st in SETTINGS:
+            assert abs(out["per_setting"][st.name]["A"] - single["per_setting"][st.name]["A"]) < 1e-12, st.name
+            np.testing.assert_allclose(out["per_setting"][st.name]["pck"], single["per_setting"][st.name]["pck"], atol=1e-12)
+            assert abs(enc[st.name] - single["per_setting"][st.name]["A"]) < 1e-12, st.name
+
+
+def test_settings_table_is_the_papers():
+    """policy/fit.py:20 lists the 13 settings; every tower id is in the drop-in registry; the A keys are compute.py:10's names."""
+    from law_of_vision_representation_in_mllms_amd.llava.model.llava_arch import build_function_mapping
+    assert [s.name for s in S.SETTINGS] == ["CLIP336", "CLIP224", "OpenCLIP", "DINOv2", "SDim", "SD1.5", "SDXL", "DiT", "SD3", "SD2.1", "SigLIP",
+                                            "CLIP224+DINOv2", "CLIP336+DINOv2"]
+    assert all(t in build_function_mapping for s in S.SETTINGS for t in s.towers)
+    assert {"clip336", "clip224", "dino", "dit", "imsd", "openclip", "sd1.5", "sd2.1", "sd3", "sdxl"} <= {s.key for s in S.SETTINGS}
+    sp = S.synthetic_spair()
+    assert len(sp) == 18 and sum(len(c.thresholds) for c in sp) == 12234 and sum(c.n_images for c in sp) == 1800
