@@ -14,6 +14,12 @@ Extra objects on the JSON line:
                 duration, timed with HIP events on the launch stream inside this run; peak = 2.5 PFLOP/s dense bf16.
   cpu_baseline  the CPU oracle (fp32 restatement of the reference's HF arithmetic, oracle/vit.py) on a bounded sample of
                 the same workload on this host's cores (rank 0, N=1 only).  Reported baseline, not the target.
+  sweep         the second half of BASELINE.json's metric - "A+C score wall-clock 13 encoders" (configs[4]): every setting of
+                policy/fit.py:20 through towers -> mm_projector -> A score and towers -> feature bank -> C score
+                (law_of_vision_representation_in_mllms_amd/sweep.py), images sharded over the ranks (STRONG scaling: fixed total work).
+                Default: the reference's 100 images per encoder for A and a 1/10-size SPair-shaped set for C (180 images, 1,224
+                pairs) so that the default run stays short; `--sweep full` runs the SPair-71k-size set (1,800 images, 12,234
+                pairs per setting), `--sweep off` skips it.  It never changes the headline `value`.
 """
 import argparse
 import json
@@ -87,7 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=4)
+    ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
+    ap.add_argument("--sweep", default="reduced", choices=["off", "reduced", "full"])
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2, 3])
     args = ap.parse_args()
 
@@ -230,7 +237,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import vit as OV
         n = args.cpu_images
-        torch.set_num_threads(min(os.cpu_count() or 1, 64))      # torch CPU GEMMs stop scaling (and thrash) beyond ~64 threads
+        torch.set_num_threads(os.cpu_count() or 1)               # every host core of the box (the count is reported as `cores`)
         sample = px[:n].float().cpu()
         OV.tower_features(spec, weights, sample[:1], select_layer=N_LAYERS)        # warm
         c0 = time.perf_counter()
@@ -242,6 +249,19 @@ def main():
                "sample": f"{n} of the same 336x336 images, fp32, oracle/vit.py (torch CPU), 23 layers",
                "gpu_vs_cpu_rel_l2": round(rel, 5)}
 
+    # ---- the 13-setting A + C sweep (all ranks take part; images sharded rank::world)
+    sweep = None
+    if args.sweep != "off":
+        try:
+            del eng, px, out, feats
+            torch.cuda.empty_cache()
+            from law_of_vision_representation_in_mllms_amd import sweep as SW
+            spair = SW.synthetic_spair() if args.sweep == "full" else SW.synthetic_spair(180, 1224)
+            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev)
+            sweep["size"] = args.sweep
+        except Exception as e:                                           # the headline line must survive a sweep failure
+            sweep = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         line = {
             "metric": "images/sec ViT-L/14@336 feature-extract", "value": round(value, 2), "unit": "images/s",
@@ -250,7 +270,7 @@ def main():
             "config": {"workload": "CLIP ViT-L/14-336 vision_tower feature-extract (hidden_states[-2], 23 layers run), "
                                    f"batch {B} per GPU, random-init weights, N(0,1) pixels resident in HBM",
                        "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)", "gemm_variant": args.gemm_variant},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

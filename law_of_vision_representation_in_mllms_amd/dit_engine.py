@@ -110,7 +110,8 @@ class DiTEngine(SdEngine):
         cols[:, : patches.shape[1]] = patches
         key = (gh, gw, B)
         if key not in self._pos:
-            self._pos.clear()
+            # older entries stay: HIP graphs captured for another batch size hold their pointers (clearing here made a replay
+            # after a batch-size change read freed memory - wrong features, then a memory fault under load)
             pos = _sincos(D, gh, gw, c.sample_size // ps).to(device=lat.device, dtype=torch.bfloat16)
             self._pos[key] = pos.repeat(B, 1).contiguous()
         h = gemm(cols, lin.w, lin.b, _lib.EPI_RESID, resid=self._pos[key])

@@ -120,7 +120,10 @@ class VitEngine:
         ws = self._ws.get(B)
         if ws is None:
             nbytes = self.lib.visrep_vit_workspace_bytes(C.byref(self._cfg), B)
-            self._ws.clear()             # keep one batch size resident
+            # a few batch sizes stay resident: a caller may have captured a forward at an earlier batch size into a HIP graph (the
+            # image-variation featurizer does), and a captured graph keeps using the workspace pointer it saw
+            while len(self._ws) >= 6:
+                self._ws.pop(next(iter(self._ws)))
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[B] = ws
         return ws
@@ -207,7 +210,8 @@ class VitEngineF32:
     def workspace(self, B: int) -> torch.Tensor:
         ws = self._ws.get(B)
         if ws is None:
-            self._ws.clear()
+            while len(self._ws) >= 6:
+                self._ws.pop(next(iter(self._ws)))
             ws = torch.empty(self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), B), dtype=torch.uint8, device=self.device)
             self._ws[B] = ws
         return ws

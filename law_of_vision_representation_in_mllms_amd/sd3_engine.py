@@ -148,7 +148,8 @@ class Sd3Engine(SdEngine):
             patches = cols
         key = (gh, gw, B)
         if key not in self._pos:
-            self._pos.clear()
+            # older entries stay: HIP graphs captured for another batch size hold their pointers (clearing here made a replay
+            # after a batch-size change read freed memory - wrong features, then a memory fault under load)
             full = _sincos(D, c.pos_max, c.pos_max, c.sample_size // ps).reshape(c.pos_max, c.pos_max, D)
             top, left = (c.pos_max - gh) // 2, (c.pos_max - gw) // 2
             pos = full[top: top + gh, left: left + gw].reshape(N, D).to(device=lat.device, dtype=torch.bfloat16)

@@ -215,21 +215,24 @@ def _synthetic_fast(table, seed):
     """Same distributions drawn with a torch generator (10-20x faster than numpy's RandomState for the 1-3 G parameters of the SD /
     SDXL / SD3 architectures).  Used by throughput runs (VISREP_FAST_SYNTHETIC=1, the sweep) where the values only need to be
     deterministic within one torch version; fixtures and parity tests keep the version-stable numpy stream below."""
-    g = torch.Generator().manual_seed(seed)
+    import os
+    dev = "cuda" if os.environ.get("VISREP_FAST_SYNTHETIC") == "cuda" and torch.cuda.is_available() else "cpu"   # "cuda": drawn on the GPU (the host RNG is the slow part), copied back
+    g = torch.Generator(device=dev).manual_seed(seed)
     out = {}
     for name, shape in table:
         if name.endswith("bias"):
-            out[name] = torch.randn(shape, generator=g) * 0.05
+            out[name] = torch.randn(shape, generator=g, device=dev) * 0.05
         elif "norm" in name.split(".")[-2]:
-            out[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            out[name] = 1.0 + 0.1 * torch.randn(shape, generator=g, device=dev)
         else:
-            out[name] = torch.randn(shape, generator=g) * (1.0 / np.sqrt(int(np.prod(shape[1:]))))
-    return out
+            out[name] = torch.randn(shape, generator=g, device=dev) * (1.0 / np.sqrt(int(np.prod(shape[1:]))))
+    # the engines do their host-side folds (time embeddings, weight repacking) on CPU tensors: hand the values back to the host
+    return {k: v.cpu() for k, v in out.items()} if dev == "cuda" else out
 
 
 def _synthetic(table, seed):
     import os
-    if os.environ.get("VISREP_FAST_SYNTHETIC") == "1":
+    if os.environ.get("VISREP_FAST_SYNTHETIC") in ("1", "cuda"):
         return _synthetic_fast(table, seed)
     rs = np.random.RandomState(seed)
     out = {}

@@ -118,12 +118,17 @@ def synthetic_pixels(ids: Sequence[int], size: int, device, dtype=torch.bfloat16
 class SettingModel:
     """Tower(s) + mlp2x_gelu projector of one setting, built through the drop-in registry (llava_arch.build_function_mapping)."""
 
-    def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16"):
+    def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16", fast_weights: bool = True):
+        """precision: 'bf16' = MFMA throughput engines + bf16 projector (what LLaVA runs); 'fp32' = reference-precision ViT towers and an
+        fp32 projector (diffusion towers are bf16 in the reference too).  fast_weights: draw the synthetic weights with the GPU's
+        generator (seconds instead of minutes for the 1-3 G parameter diffusion models); False keeps the version-stable numpy stream."""
         from .llava.model import llava_arch as LA
         from .llava.model.multimodal_projector.builder import build_vision_projector
         self.setting, self.device = setting, torch.device(device)
         self.towers = []
-        env = {"VISREP_SYNTHETIC_WEIGHTS": "1", "VISREP_FAST_SYNTHETIC": "1"} if synthetic else {}
+        env = {"VISREP_SYNTHETIC_WEIGHTS": "1"} if synthetic else {}
+        if synthetic and fast_weights:
+            env["VISREP_FAST_SYNTHETIC"] = "cuda" if self.device.type == "cuda" else "1"
         with _environ(env):
             for tid in setting.towers:
                 cfg = SimpleNamespace(mm_vision_tower=tid, vision_tower=tid, mm_vision_select_layer=-2, mm_vision_select_feature='patch',
@@ -133,13 +138,17 @@ class SettingModel:
         self.width = sum(t.hidden_size for t in self.towers)
         torch.manual_seed(7)                                             # same projector on every rank
         self.projector = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=self.width, hidden_size=hidden))
-        self.projector = self.projector.to(torch.bfloat16)               # what LLaVA's model.to(bfloat16) leaves: the bf16 MFMA path
+        if precision != "fp32":
+            self.projector = self.projector.to(torch.bfloat16)           # what LLaVA's model.to(bfloat16) leaves: the bf16 MFMA path
         self.split = self.towers[0].hidden_size if len(self.towers) == 2 else 0
+        if self.device.type == "cuda":                                    # untimed warm-up at the launch shape: HIP-graph capture, workspaces
+            self.project(self.tokens(synthetic_pixels(range(setting.batch), setting.size, self.device,
+                                                      torch.float32 if precision == "fp32" else torch.bfloat16)))
 
     @torch.no_grad()
     def tokens(self, px: torch.Tensor) -> torch.Tensor:
         """[B, 3, s, s] -> tower tokens [B, N, C] ('.'-fusion: channel concat of the towers' tokens, llava_arch.py:278-285)."""
-        f = [t(px) for t in self.towers]
+        f = [t(px if t.dtype == px.dtype or not hasattr(t, "up_ft_index") else px.to(t.dtype)) for t in self.towers]   # diffusion towers: bf16 in
         return f[0] if len(f) == 1 else torch.cat(f, dim=-1)
 
     @torch.no_grad()
@@ -291,6 +300,7 @@ def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spa
     rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
     dev = torch.device(device)
     import logging
+    from .C_score import pck_train as _PT  # noqa: F401  (its import configures the logger: do it before silencing it)
     clog = logging.getLogger("visrep.cscore")
     old_level = clog.level
     clog.setLevel(logging.WARNING)                                       # 18 per-category lines x 13 settings are not a bench output
@@ -302,7 +312,7 @@ def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spa
 
 def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world):
     build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision))
-    pixels = pixels or (lambda ids, size: synthetic_pixels(ids, size, dev))
+    pixels = pixels or (lambda ids, size: synthetic_pixels(ids, size, dev, torch.float32 if precision == "fp32" else torch.bfloat16))
     if spair is None and do_c:
         spair = synthetic_spair()
     per, refs, pending = {}, {}, []

@@ -204,11 +204,13 @@ def synthetic_weights(spec: ViTSpec, seed: int = 1, n_layers: Optional[int] = No
     rs = np.random.RandomState(seed)
     d, m, p = spec.d, spec.mlp, spec.patch
     import os
-    fast = torch.Generator().manual_seed(seed) if os.environ.get("VISREP_FAST_SYNTHETIC") == "1" else None   # throughput runs only
+    mode = os.environ.get("VISREP_FAST_SYNTHETIC")                     # throughput runs only: torch generator ("1") / drawn in HBM ("cuda")
+    fdev = "cuda" if mode == "cuda" and torch.cuda.is_available() else "cpu"
+    fast = torch.Generator(device=fdev).manual_seed(seed) if mode in ("1", "cuda") else None
 
     def rn(*shape, std=0.02, mean=0.0):
         if fast is not None:
-            return torch.randn(shape, generator=fast) * std + mean
+            return (torch.randn(shape, generator=fast, device=fdev) * std + mean).cpu()
         return torch.from_numpy((rs.standard_normal(shape) * std + mean).astype(np.float32))
 
     w = {

@@ -337,6 +337,37 @@ def test_dit_tower_matches_reference_golden(tag):
         eng.forward(inp["img"], ensemble_size=2, **kw)
 
 
+def test_dit_and_sd3_graphs_survive_a_batch_size_change():
+    """Regression (round 2): the position-table cache of the DiT / SD3 engines dropped the table a captured HIP graph of ANOTHER batch
+    size still pointed at, so batch 2 -> batch 1 -> batch 2 replayed the first graph on freed memory (wrong features, then a memory
+    fault in the 13-setting sweep).  The same inputs must give the same bits before and after other batch sizes ran."""
+    from test_oracle_golden import load_dit_case, load_sd3_case
+    from law_of_vision_representation_in_mllms_amd.dit_engine import DiTEngine
+    from law_of_vision_representation_in_mllms_amd.sd3_engine import Sd3Engine
+    sp, wd, wv, inp, _ = load_dit_case("last")
+    eng = DiTEngine(sp, wd, wv, DEV, up_ft_index=inp["up_ft_index"])
+    img = inp["img"]
+    B = img.shape[0]
+    big = lambda t, n: torch.cat([t] * n, 0)
+    first = eng.forward(img, t=inp["t"], post_noise=inp["post_noise"], ddim_noise=inp["ddim_noise"])
+    for n in (2, 3):
+        junk = eng.forward(big(img, n), t=inp["t"], post_noise=big(inp["post_noise"], n), ddim_noise=big(inp["ddim_noise"], n))
+        assert rel_err(junk[:B], first.float().cpu()) < 2e-2, n                     # (split-K choices depend on the batch: close, not bit-equal)
+        torch.cuda.empty_cache()
+        torch.randn(1 << 22, device=DEV)                                            # recycle whatever was freed
+    assert torch.equal(eng.forward(img, t=inp["t"], post_noise=inp["post_noise"], ddim_noise=inp["ddim_noise"]), first)
+    sp, wc, wv, inp, _ = load_sd3_case("last")
+    eng = Sd3Engine(sp, wc, wv, DEV, up_ft_index=inp["up_ft_index"])
+    run = lambda n: eng.forward(big(inp["img"], n), inp["prompt_embeds"], t=inp["t"], post_noise=big(inp["post_noise"], n),
+                                ddim_noise=big(inp["noise"], n), pooled=inp["pooled"])
+    first = run(1)
+    for n in (2, 3):
+        assert rel_err(run(n)[: first.shape[0]], first.float().cpu()) < 2e-2, n
+        torch.cuda.empty_cache()
+        torch.randn(1 << 22, device=DEV)
+    assert torch.equal(run(1), first)
+
+
 def test_dit_xl2_full_width_parity_and_tower_api(monkeypatch):
     """DiT-XL/2 widths (16 heads x 72 -> padded to 128, d = 1152, ff 4608) for the first 3 blocks on a 128-px image against the
     fp32 CPU oracle, then the DiffVisionTower drop-in (4608-channel tokens)."""
