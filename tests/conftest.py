@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    # torch's default intra-op thread count on the 256-logical-CPU GPU host (128) makes the CPU oracle several times SLOWER than
+    # 16-32 threads do (tools/cpu_probe.py): cap it for every test process
+    try:
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:
+        pass
