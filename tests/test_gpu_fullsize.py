@@ -99,4 +99,4 @@ def test_headline_batch_256_strided_sample_vs_oracle():
     for j, i in enumerate(ids):
         assert rel(out[i], want[j]) < max(1.5 * e_ref, 2e-2), (i, rel(out[i], want[j]), e_ref)
     alone = eng.forward(px[ids].to(DEV), n_layers=23)[:, 1:]
-    assert rel(alone, out[ids]) < 8e-3
+    assert rel(alone, out[ids]) < 2e-2                                          # two bf16 runs with different tilings: each ~1.2e-2 from the oracle
