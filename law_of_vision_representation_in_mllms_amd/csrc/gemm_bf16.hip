@@ -237,6 +237,7 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
         }
         return visrep_set_error(VISREP_ERR_ARG, "conv3x3: epilogue must be BIAS, RESID or F32");
     }
+    if (variant == 4 && visrep_gemm_v4_supports(a)) return visrep_gemm_v4_dispatch(a, s);
     if (variant == 3 && visrep_gemm_v3_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;

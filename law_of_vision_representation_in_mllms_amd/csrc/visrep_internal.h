@@ -44,6 +44,8 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s);
 int visrep_ln_stats_finalize(const float2* partial, int slots, float2* rt, int rows, int d, float eps, hipStream_t s);
 bool visrep_gemm_v2_supports(const GemmArgs& a);
 int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
+bool visrep_gemm_v4_supports(const GemmArgs& a);
+int visrep_gemm_v4_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v3_supports(const GemmArgs& a);
 int visrep_gemm_v3_dispatch(const GemmArgs& a, hipStream_t s);
 extern int g_visrep_gemm_dbg;
