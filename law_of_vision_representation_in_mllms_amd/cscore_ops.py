@@ -17,7 +17,7 @@ def lin_table(P: int, device) -> torch.Tensor:
 @torch.no_grad()
 def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_idx: torch.Tensor, nkp: torch.Tensor, P: int,
              window: int = 5, soft_eval: bool = True, beta: float = 0.02, anno_size: int = 840, split: int = 0,
-             layout: str = "cp") -> torch.Tensor:
+             layout: str = "cp", sort_pairs: bool = True) -> torch.Tensor:
     """Keypoint transfer for a batch of pairs.
 
     bank [n_images, C, P*P] fp32 (the reference's on-disk [1, C, P, P] maps, flattened); img1/img2/nkp int32 [n];
@@ -42,12 +42,23 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     dev = bank.device
     i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
     img1, img2, patch_idx, nkp = i32(img1), i32(img2), i32(patch_idx), i32(nkp)
+    # Launch order = pairs grouped by TARGET image.  One workgroup handles one pair and streams the whole target map (P^2 x C fp32,
+    # 1 - 2.4 MB) but only K rows of the source map; a bank of ~1,800 maps (1.9 - 4.3 GB) does not fit the 32 MB of L2, and in dataset
+    # order nearly every pair re-fetches its target map from HBM (rocprofv3 PMC, profiles/round2_scores_pmc.md: L2 hit rate 6 %,
+    # 22.5 GB of fabric traffic per launch).  An image is the target of ~7 pairs: run together they fetch it once.
+    order = torch.argsort(img2.to(torch.int64), stable=True) if sort_pairs and n > 1 else None
+    if order is not None:
+        img1, img2, patch_idx, nkp = (t.index_select(0, order).contiguous() for t in (img1, img2, patch_idx, nkp))
     xy = torch.zeros(n, kmax, 2, dtype=torch.float32, device=dev)
     stride = anno_size / P
     rc = lib.visrep_cscore_transfer(_lib.ptr(bank), _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(patch_idx), _lib.ptr(nkp),
                                     _lib.ptr(lin_table(P, dev)), _lib.ptr(xy), n, kmax, P, C_, int(split), int(window), int(soft_eval),
                                     float(beta), float(stride), float(stride // 2), 0 if layout == "cp" else 1, _lib.stream_ptr())
     _lib.check(rc, "visrep_cscore_transfer")
+    if order is not None:
+        out = torch.empty_like(xy)
+        out.index_copy_(0, order, xy)                               # back to the caller's pair order
+        return out
     return xy
 
 

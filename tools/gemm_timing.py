@@ -13,7 +13,7 @@ for (M, N, K, tag) in ((147456, 1024, 4096, "fc2-shape"), (147456, 4096, 1024, "
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    for mask in (0, 8, 16):
+    for mask in (0, 2, 1, 3):   # full | no LDS-DMA | no MFMA | reads + barriers only
         lib.visrep_debug_gemm_ablation(mask)
         for _ in range(2):
             buf.zero_()

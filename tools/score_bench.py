@@ -17,7 +17,7 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps
 
 out = {}
-n = 1000
+n = int(os.environ.get("SCORE_BENCH_N", "1000"))
 g = torch.Generator(device=dev).manual_seed(3)
 r336 = torch.randn(n, 576, 4096, device=dev, generator=g).to(torch.bfloat16)
 r224 = torch.randn(n, 256, 4096, device=dev, generator=g).to(torch.bfloat16)
@@ -44,12 +44,13 @@ for P in (16, 24):
     kps = torch.rand(n_pairs, 20, 3) * 839; kps[:, :, 2] = 1
     thr = torch.from_numpy(rs.uniform(150, 700, n_pairs))
     by = 2.0 * P * P * C * 4 * n_pairs
-    for layout, bk in (("cp", bank), ("pc", bank.transpose(1, 2).contiguous())):
+    for layout, bk, srt in (("cp", bank, True), ("pc", bank.transpose(1, 2).contiguous(), False), ("pc", None, True)):
+        bk = bank.transpose(1, 2).contiguous() if bk is None else bk
         def run():
-            xy = cscore_ops.transfer(bk, i1, i2, idx, nkp, P, layout=layout)
+            xy = cscore_ops.transfer(bk, i1, i2, idx, nkp, P, layout=layout, sort_pairs=srt)
             return cscore_ops.pck_counts(xy, kps, kps, thr, nkp)
         sec = timed(run)
-        out[f"C.P{P}.{layout}"] = {"pairs_per_s": round(n_pairs / sec, 1), "ms_all_pairs": round(sec * 1e3, 3), "alg_GB/s": round(by / sec / 1e9, 1),
+        out[f"C.P{P}.{layout}" + ("" if srt else ".dataset_order")] = {"pairs_per_s": round(n_pairs / sec, 1), "ms_all_pairs": round(sec * 1e3, 3), "alg_GB/s": round(by / sec / 1e9, 1),
                                    "frac_of_8TB/s": round(by / sec / 8e12, 4)}
     del bank, bk
 print(json.dumps(out, indent=1))
