@@ -151,9 +151,19 @@ __global__ void ascore_finalize(const float* __restrict__ partial, float* __rest
 }
 
 // ---- bf16 production path: LDS-staged MFMA Gram (same structure and LDS tile format as gemm_bf16.hip v1) --------------
-// One workgroup = 128 target rows of one image; it sweeps every 128-row tile of the reference and all of D with
-// double-buffered global_load_lds staging, keeps a running row max in the accumulator layout and writes one partial sum.
-// The [Nt, Nr] similarity never exists in memory; the target tile is re-streamed from L2 once per reference tile.
+// One workgroup = ONE 128 x 128 tile of one image's [Nt, Nr] similarity: it sweeps all of D with double-buffered global_load_lds
+// staging, scales the columns by c_ref, takes the row max over its 128 reference rows and writes it to rowmax[img][t][ref tile];
+// ascore_finalize_tiles then takes the max over the reference tiles, applies c_other and averages.  The [Nt, Nr] similarity
+// never exists in memory.
+// Work mapping (round 2, from the PMC pass in profiles/round2_pmc_midround.md): round 1 gave a workgroup one 128-row target tile
+// and looped over the reference tiles, re-streaming its target tile per reference tile and the whole reference per workgroup;
+// one image's operands (9.4 MB at 576 x 576 x 4096) do not fit an XCD's 4 MB L2, the L2 hit rate was 14-29 % and the kernel ran at
+// 7.1 TB/s of FABRIC traffic - 2.5x its algorithmic bytes: HBM-bound on re-fetches.  Now all ntt x nnt tile pairs of an image are
+// consecutive logical workgroups (xcd_remap puts consecutive ids on one XCD): they start together, walk D in step, and at any
+// moment the XCD's L2 only has to hold the current D-window of a few images, so every operand slab is fetched from HBM once and
+// hit by the other 4-5 workgroups that need it.  (Also tried: taking the row norms from the MFMA fragments inside this kernel instead
+// of the separate ascore_row_scale pass - the unpack + FMA work in the compiler-scheduled K loop cost more than the pass: 575 vs
+// 636 TFLOP/s at Nt = 576 with the pass included; the factors therefore stay a pass of their own, computed once per token stack.)
 constexpr int A_BM = 128, A_BN = 128, A_BK = 64;
 constexpr int A_TILE = A_BM * A_BK * 2, A_STAGE = 2 * A_TILE, A_LDS = 2 * A_STAGE;
 
@@ -161,23 +171,27 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntt = (p.Nt + A_BM - 1) / A_BM;
-    // XCD-aware: the row tiles of one image (they all stream the same reference rows) must share an L2, i.e. run on ONE XCD;
-    // hardware round-robins consecutive workgroups over the 8 XCDs, so consecutive LOGICAL blocks are remapped onto one XCD
+    const int ntt = (p.Nt + A_BM - 1) / A_BM, nnt = (p.Nr + A_BN - 1) / A_BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int img = bid / ntt, tt = bid - img * ntt;
+    const int per_img = ntt * nnt;
+    const int img = bid / per_img, rem = bid - img * per_img;
+    const int tt = rem / nnt, nt = rem - tt * nnt;
     const bf16_t* other = reinterpret_cast<const bf16_t*>(p.other) + (size_t)img * p.Nt * p.D;
     const bf16_t* ref = reinterpret_cast<const bf16_t*>(p.ref) + (size_t)img * p.Nr * p.D;
     const float* cr = p.c_ref + (size_t)img * p.Nr;
-    const int m0 = tt * A_BM;
+    const int m0 = tt * A_BM, n0 = nt * A_BN;
     const int srow = tid >> 3;
     const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
     const bf16_t* ga[4];
+    const bf16_t* gr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int r = m0 + j * 32 + srow;
         r = r < p.Nt ? r : p.Nt - 1;
         ga[j] = other + (size_t)r * p.D + lslot * 8;
+        int q = n0 + j * 32 + srow;
+        q = q < p.Nr ? q : p.Nr - 1;
+        gr[j] = ref + (size_t)q * p.D + lslot * 8;
     }
     const int fr = lane & 15, fg = lane >> 4;
     int foff[2];
@@ -185,69 +199,60 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
     for (int kk = 0; kk < 2; ++kk) foff[kk] = fr * 128 + (((kk * 4 + fg) ^ ((fr >> 1) & 7)) << 4);
     const int aoff = wm * 64 * 128, woff = A_TILE + wn * 64 * 128;
     float rowmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    const int nk = p.D / A_BK, nnt = (p.Nr + A_BN - 1) / A_BN;
-    for (int nt = 0; nt < nnt; ++nt) {
-        const int n0 = nt * A_BN;
-        const bf16_t* gr[4];
+    const int nk = p.D / A_BK;
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * A_STAGE + wave * 1024;
+        char* sw = sa + A_TILE;
+        const int ko = kt * A_BK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int r = n0 + j * 32 + srow;
-            r = r < p.Nr ? r : p.Nr - 1;
-            gr[j] = ref + (size_t)r * p.D + lslot * 8;
-        }
-        auto stage = [&](int buf, int kt) {
-            char* sa = smem + buf * A_STAGE + wave * 1024;
-            char* sw = sa + A_TILE;
-            const int ko = kt * A_BK;
+        for (int j = 0; j < 4; ++j) glds16(ga[j] + ko, sa + j * 4096);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(ga[j] + ko, sa + j * 4096);
+        for (int j = 0; j < 4; ++j) glds16(gr[j] + ko, sw + j * 4096);
+    };
+    f32x4 acc[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(gr[j] + ko, sw + j * 4096);
-        };
-        f32x4 acc[4][4];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // edge tiles: a wave whose 64 target rows or 64 reference columns lie entirely past the end (576 = 4.5 tiles: half of the last row /
+    // column tile) skips its fragment reads and MFMAs; it still stages and meets the barriers
+    const bool live = m0 + wm * 64 < p.Nt && n0 + wn * 64 < p.Nr;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * A_STAGE;
+        if (live)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        stage(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-            const char* sb = smem + cur * A_STAGE;
-            // edge tiles: a wave whose 64 target rows or 64 reference columns lie entirely past the end (Nt = 576 = 4.5 tiles: half
-            // of the last row / column tile) skips its fragment reads and MFMAs; it still stages and meets the barriers
-            if (m0 + wm * 64 < p.Nt && n0 + wn * 64 < p.Nr)
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 xa[4], xr[4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 xa[4], xr[4];
+            for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(sb + aoff + i * 2048 + foff[kk]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(sb + aoff + i * 2048 + foff[kk]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(sb + woff + i * 2048 + foff[kk]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[j], xa[i], acc[i][j], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-        // lane holds G[t = m0 + 64 wm + 16 i + fr][s = n0 + 64 wn + 16 j + 4 fg + e]: scale by c_ref[s], mask s >= Nr, row max
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sidx = n0 + wn * 64 + j * 16 + fg * 4;
-            float c[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c[e] = (sidx + e < p.Nr) ? cr[sidx + e] : 0.f;
+            for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(sb + woff + i * 2048 + foff[kk]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (sidx + e < p.Nr) rowmax[i] = fmaxf(rowmax[i], acc[i][j][e] * c[e]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[j], xa[i], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
     }
-    // combine over the four 4-column groups (lanes fr + 16 fg), then over the two column waves, then sum the rows
-    float* red = reinterpret_cast<float*>(smem);                 // the staging buffers are dead now
+    float* red = reinterpret_cast<float*>(smem);                 // the staging buffers are dead now (last __syncthreads above)
+    // lane holds G[t = m0 + 64 wm + 16 i + fr][s = n0 + 64 wn + 16 j + 4 fg + e]: scale by c_ref[s], mask s >= Nr, row max
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sidx = n0 + wn * 64 + j * 16 + fg * 4;
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = (sidx + e < p.Nr) ? cr[sidx + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sidx + e < p.Nr) rowmax[i] = fmaxf(rowmax[i], acc[i][j][e] * c[e]);
+    }
+    // combine over the four 4-column groups (lanes fr + 16 fg), then over the two column waves; one float per (target row, ref tile)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float v = rowmax[i];
@@ -261,16 +266,28 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
         for (int i = 0; i < 4; ++i) red[(wn * 2 + wm) * 64 + i * 16 + fr] = rowmax[i];
     }
     __syncthreads();
-    float v = 0.f;
     if (tid < 128) {
         const int t = m0 + tid;                                     // tid = 64 wm + 16 i + fr
-        if (t < p.Nt) v = fmaxf(red[(tid >> 6) * 64 + (tid & 63)], red[(2 + (tid >> 6)) * 64 + (tid & 63)]) * p.c_other[(size_t)img * p.Nt + t];
+        if (t < p.Nt) p.partial[((size_t)img * p.Nt + t) * nnt + nt] = fmaxf(red[(tid >> 6) * 64 + (tid & 63)], red[(2 + (tid >> 6)) * 64 + (tid & 63)]);
     }
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) red[512 + wave] = v;
-    __syncthreads();
-    if (tid == 0) p.partial[bid] = red[512] + red[513] + red[514] + red[515];
+}
+
+// score[img] = (1 / Nt) * sum_t c_other[t] * max over the reference tiles of rowmax[img][t][.]   (c_other > 0 commutes with the max);
+// one wave per image, lanes stride t, fixed-order wave reduction -> deterministic
+__global__ __launch_bounds__(256) void ascore_finalize_tiles(const float* __restrict__ rowmax, const float* __restrict__ c_other, float* __restrict__ score,
+                                                             int n_img, int Nt, int nnt) {
+    const int lane = threadIdx.x & 63;
+    const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (img >= n_img) return;
+    float s = 0.f;
+    for (int t = lane; t < Nt; t += 64) {
+        const float* r = rowmax + ((size_t)img * Nt + t) * nnt;
+        float m = r[0];
+        for (int k = 1; k < nnt; ++k) m = fmaxf(m, r[k]);
+        s += m * c_other[(size_t)img * Nt + t];
+    }
+    s = wave_sum(s);
+    if (lane == 0) score[img] = s / (float)Nt;
 }
 
 template <typename T>
@@ -286,18 +303,21 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
     float* c_other = ws;
     float* c_ref = c_other + (size_t)n_img * Nt;
     float* partial = c_ref + (size_t)n_img * Nr;
+    const bool tiled = sizeof(T) == 2 && D % 64 == 0;
     if (!c_other_in && row_scales<T>(other, (long)n_img * Nt, D, c_other, s)) return VISREP_ERR_LAUNCH;
     if (!c_ref_in && row_scales<T>(ref, (long)n_img * Nr, D, c_ref, s)) return VISREP_ERR_LAUNCH;
     AScoreArgs a{other, ref, c_other_in ? c_other_in : c_other, c_ref_in ? c_ref_in : c_ref, partial, n_img, Nt, Nr, D};
     int ntt = (Nt + 63) / 64;
-    if (sizeof(T) == 2 && D % 64 == 0) {                       // production path: LDS-tiled MFMA kernel, 128-row target tiles
+    if (tiled) {                                               // production path: LDS-tiled MFMA kernel, one 128 x 128 tile per workgroup
         ntt = (Nt + A_BM - 1) / A_BM;
+        const int nnt = (Nr + A_BN - 1) / A_BN;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS); attr = true; }
-        hipLaunchKernelGGL(ascore_maxcos_tiled, dim3(n_img * ntt), dim3(256), A_LDS, s, a);
-    } else {
-        hipLaunchKernelGGL(ascore_maxcos<T>, dim3(n_img * ntt), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ascore_maxcos_tiled, dim3((unsigned)((size_t)n_img * ntt * nnt)), dim3(256), A_LDS, s, a);
+        hipLaunchKernelGGL(ascore_finalize_tiles, dim3((n_img + 3) / 4), dim3(256), 0, s, partial, a.c_other, scores, n_img, Nt, nnt);
+        return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
     }
+    hipLaunchKernelGGL(ascore_maxcos<T>, dim3(n_img * ntt), dim3(256), 0, s, a);
     hipLaunchKernelGGL(ascore_finalize, dim3((n_img + 63) / 64), dim3(64), 0, s, partial, scores, n_img, ntt, Nt);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
@@ -305,7 +325,10 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
 }  // namespace
 
 extern "C" size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr) {
-    return sizeof(float) * ((size_t)n_img * Nt + (size_t)n_img * Nr + (size_t)n_img * ((Nt + 63) / 64));
+    // row scales of both operands + the larger of the two partial layouts: [n_img, ceil(Nt / 64)] block sums (direct kernels) or
+    // [n_img, Nt, ceil(Nr / 128)] per-row maxima of the tiled bf16 kernel
+    const size_t direct = (size_t)n_img * ((Nt + 63) / 64), tiled = (size_t)n_img * Nt * ((Nr + 127) / 128);
+    return sizeof(float) * ((size_t)n_img * Nt + (size_t)n_img * Nr + (direct > tiled ? direct : tiled));
 }
 
 extern "C" int visrep_ascore_row_scale(const void* x, long rows, int D, int dtype, float* scale, void* stream) {
