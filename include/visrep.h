@@ -157,6 +157,15 @@ size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B);
 int visrep_vit_forward_f32(const visrep_vit_config* cfg, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
                            void* workspace, void* stream);
 
+/* ---- ADAPT_FLIP support of the C score (C_score/pck_train.py:111-126 with MUTUAL_NN; utils/utils_correspondence.py:54-73
+ * get_distance_mutual_nn): raw Gram matrices of image pairs from a position-major fp32 bank [n_images, PP, C] (gather by index),
+ * normalize_feats' row factors r = 1 / (|x| + eps) (pck_train.py:24-29), and per pair the mean cdist of the mutual nearest neighbours
+ * of the two L2-normalised descriptor sets: out[z] fp32 (nan when a pair has none, like torch's empty mean).  gram [n_pairs, PP, PP],
+ * r1 / r2 [n_pairs, PP] (the factors of each pair's source / target map), PP <= 1024. */
+int visrep_gram_pairs_f32(const float* bank, const int* idx1, const int* idx2, int n_pairs, int PP, int C, float* gram, void* stream);
+int visrep_row_rnorm_f32(const float* x, long rows, int C, float eps, float* r, void* stream);
+int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float* out, void* stream);
+
 /* ---- A score (A_score/compute.py:12-15,54-72): scores[img] = mean_t max_s cos(other[img][t], ref[img][s]).
  * other [n_img,Nt,D], ref [n_img,Nr,D] contiguous, dtype VISREP_BF16 (D%16==0) or VISREP_F32 (D%8==0);
  * scores fp32 [n_img]; workspace of visrep_ascore_workspace_bytes(). */

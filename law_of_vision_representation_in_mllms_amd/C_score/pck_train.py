@@ -70,7 +70,7 @@ def _dist():
     return d if d.is_available() and d.is_initialized() else None
 
 
-def build_feature_bank(args, aggre_net, files, num_patches, dev, models=None):
+def build_feature_bank(args, aggre_net, files, num_patches, dev, models=None, flip=False):
     """Distinct images of a category -> ([n_img, C, P^2] fp32 device bank, per-file-slot bank index).
 
     `models`: feature-file suffixes; two of them (pck_train_two.py) are concatenated on the channel axis - the raw maps,
@@ -82,7 +82,7 @@ def build_feature_bank(args, aggre_net, files, num_patches, dev, models=None):
             uniq[f] = len(uniq)
         slot.append(uniq[f])
     def load(f):
-        per_model = [aggre_net(torch.load(_feature_path(f, False, args.ENSEMBLE, m), map_location="cpu")).reshape(-1, num_patches ** 2).float()
+        per_model = [aggre_net(torch.load(_feature_path(f, flip, args.ENSEMBLE, m), map_location="cpu")).reshape(-1, num_patches ** 2).float()
                      for m in models]
         return torch.cat(per_model, 0) if len(per_model) > 1 else per_model[0]
     # each distinct map is read ONCE (the reference reloads both maps of every pair, pck_train.py:31-39), a few files in flight
@@ -96,8 +96,13 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
 
 
 def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models):
-    if getattr(args, "ADAPT_FLIP", False):
-        raise NotImplementedError("ADAPT_FLIP is not built (the reference's get_distance only accepts 60x60 maps; SURVEY §8f N4)")
+    adapt_flip = bool(getattr(args, "ADAPT_FLIP", False))
+    if adapt_flip and not getattr(args, "MUTUAL_NN", False):
+        # pck_train.py:122-124: without MUTUAL_NN the flip decision uses get_distance, which is hard-wired to 60x60 SD+DINO maps and
+        # SAM masks (utils_correspondence.py:22-52) - it cannot run on any other feature grid in the reference either
+        raise NotImplementedError("ADAPT_FLIP needs MUTUAL_NN here: the mask-based get_distance only accepts 60x60 maps (SURVEY §8f N4)")
+    if adapt_flip and len(models) != 1:
+        raise NotImplementedError("ADAPT_FLIP is defined by pck_train.py only (pck_train_two.py has no flip branch that reads two encoders)")
     if getattr(args, "TOTAL_SAVE_RESULT", 0):
         raise NotImplementedError("TOTAL_SAVE_RESULT > 0 asks for the matplotlib match visualisations (utils_visualization.py), which are not built")
     geo = bool(getattr(args, "COMPUTE_GEOAWARE_METRICS", False))
@@ -128,9 +133,11 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     idx = np.stack([kpts_to_patch_idx(args, k1[i], P) for i in range(N)]).astype(np.int32) if N else np.zeros((0, K), np.int32)
     nkp = torch.full((N,), K, dtype=torch.int32)
     sl = slice(lo, hi)
-    xy = cscore_ops.transfer(bank_t, torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy()),
-                             torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW, soft_eval=bool(args.SOFT_EVAL),
-                             anno_size=args.ANNO_SIZE, split=split, layout=layout)
+    src, trg = torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy())
+    xy = cscore_ops.transfer(bank_t, src, trg, torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW,
+                             soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, split=split, layout=layout)
+    if adapt_flip:
+        xy = _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t, layout, slot, sl, src, trg, xy, P, dev, models)
     alphas = shown_alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)
     if thresholds is not None:
         thr = torch.tensor(thresholds, dtype=torch.float64)
@@ -189,6 +196,46 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
             logger.info(' | '.join(f'PCK-Transfer_geo-aware@{a:.2f}: {v * 100:.2f}%' for a, v in zip(_f32(shown_alphas), correct_geo[:3])))
             logger.info(f'Geo-aware occurance count: {geo_pairs}, with ratio {geo_pairs / N * 100:.2f}%; total count ratio {n_geo / n_kpts * 100:.2f}%')
     return correct, geo_score, out_results, img_correct
+
+
+def _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t, layout, slot, sl, src, trg, xy, P, dev, models):
+    """ADAPT_FLIP of compute_pck (pck_train.py:82-94,111-126) for this rank's pair block: a second keypoint transfer from the MIRRORED
+    source image's features (`<img>_<MODEL>_flip.pt`) with the mirrored, left/right-permuted key points, the mutual-nearest-neighbour
+    distance of both source variants to the target (get_distance_mutual_nn), and per pair the reference's choice between the two."""
+    from .utils.utils_geoware import AP10K_FLIP, SPAIR_FLIP, flip_keypoints, flip_permutation, optimized_kps_1_to_2, permute_indices
+    if layout != "pc":
+        raise NotImplementedError("ADAPT_FLIP needs channel counts that are multiples of 4 (position-major bank)")
+    table = AP10K_FLIP if args.EVAL_DATASET == 'ap10k' else SPAIR_FLIP[category]
+    K = kps.shape[1]
+    used = torch.arange(K) if used_points is None else used_points
+    permute_list = flip_permutation(table, used.tolist(), K)
+    if bank is not None and len(bank) > 4:
+        flip_bank = bank[4]                                                    # caller-provided mirrored maps, same slots
+    else:
+        flip_bank, _ = build_feature_bank(args, aggre_net, files, P, dev, models, flip=True)
+        flip_bank = flip_bank.transpose(1, 2).contiguous()
+    n_img = bank_t.shape[0]
+    both = torch.cat([bank_t, flip_bank.to(bank_t.device)], 0)                 # mirrored map of image i = bank entry n_img + i
+    k1, k2 = kps[0::2], kps[1::2]
+    lo, hi = sl.start, sl.stop
+    idx_f = np.zeros((hi - lo, K), np.int32)
+    for n, i in enumerate(range(lo, hi)):
+        vis = k1[i][:, 2] * k2[i][:, 2] > 0
+        flipped = flip_keypoints(k1[i], args.ANNO_SIZE, permute_indices(permute_list, vis))
+        if flipped.shape[0] != K:            # the flip table does not cover every key-point column (the reference's indexing breaks too)
+            raise ValueError(f"flip table of {category!r} covers {flipped.shape[0]} of the {K} key points")
+        idx_f[n] = kpts_to_patch_idx(args, flipped, P)
+    nkp = torch.full((hi - lo,), K, dtype=torch.int32)
+    xy_f = cscore_ops.transfer(both, src + n_img, trg, torch.from_numpy(idx_f), nkp, P, window=args.SOFT_EVAL_WINDOW,
+                               soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, layout="pc")
+    d_orig = cscore_ops.mutual_nn_distance(both, src, trg, P).cpu()
+    d_flip = cscore_ops.mutual_nn_distance(both, src + n_img, trg, P).cpu()
+    out = xy.clone()
+    xy_c, xyf_c = xy.cpu(), xy_f.cpu()
+    for n, i in enumerate(range(lo, hi)):
+        vis = k1[i][:, 2] * k2[i][:, 2] > 0
+        out[n] = optimized_kps_1_to_2(args, xy_c[n], xyf_c[n], k1[i], k2[i], d_flip[n], d_orig[n], vis, permute_list).to(out.device)
+    return out
 
 
 def _f32(alphas):

@@ -30,3 +30,14 @@ def calculate_keypoint_transformation(args, img1_desc, img2_desc, img1_patch_idx
                                  anno_size=args.ANNO_SIZE)
         outs.append(xy[0, :len(part)])
     return torch.cat(outs, 0)
+
+
+def get_distance_mutual_nn(feature1, feature2):
+    """utils_correspondence.py:54-73: feature* [1, P^2, C] descriptors -> mean cdist over the mutual nearest neighbours (a 0-dim tensor).
+    Runs visrep_gram_pairs_f32 + visrep_mutual_nn_distance; the descriptors are L2-normalised there (idempotent for the reference's
+    already-normalised inputs)."""
+    from ... import cscore_ops
+    f1, f2 = feature1.reshape(-1, feature1.shape[-1]).float(), feature2.reshape(-1, feature2.shape[-1]).float()
+    bank = torch.stack([f1, f2]).cuda()
+    P = int(round(f1.shape[0] ** 0.5))
+    return cscore_ops.mutual_nn_distance(bank, torch.tensor([0]), torch.tensor([1]), P)[0]

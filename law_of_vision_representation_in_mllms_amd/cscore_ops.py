@@ -79,3 +79,34 @@ def pck_counts(xy: torch.Tensor, kps1: torch.Tensor, kps2: torch.Tensor, thresho
                               _lib.ptr(counts), _lib.stream_ptr())
     _lib.check(rc, "visrep_pck_count")
     return counts
+
+
+@torch.no_grad()
+def mutual_nn_distance(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, P: int, chunk: int = 2048, eps: float = 1e-10) -> torch.Tensor:
+    """get_distance_mutual_nn (utils_correspondence.py:54-73) for a batch of pairs: the mean Euclidean distance of the mutual nearest
+    neighbours of the two L2-normalised descriptor sets (pck_train.py:24-29 normalisation).  bank: position-major fp32 [n_images, P*P, C]
+    RAW maps; returns fp32 [n_pairs] (nan for a pair without mutual neighbours, as torch's empty mean).  Pairs are processed in chunks:
+    the [chunk, P^2, P^2] Gram buffer (exact-fp32 MFMA, visrep_gram_pairs_f32) is the only large temporary."""
+    lib = _lib.require_gpu()
+    if bank.dtype != torch.float32 or bank.dim() != 3 or bank.shape[1] != P * P:
+        raise ValueError("bank must be fp32 [n_images, P*P, C] (position-major)")
+    bank = bank.contiguous()
+    dev = bank.device
+    n_img, PP, C_ = bank.shape
+    if PP % 4 or C_ % 4 or PP > 1024:
+        raise ValueError("mutual_nn_distance needs P*P and C multiples of 4 and P <= 32")
+    i1 = img1.to(device=dev, dtype=torch.int32).contiguous()
+    i2 = img2.to(device=dev, dtype=torch.int32).contiguous()
+    n = i1.shape[0]
+    rn = torch.empty(n_img, PP, dtype=torch.float32, device=dev)
+    _lib.check(lib.visrep_row_rnorm_f32(_lib.ptr(bank), n_img * PP, C_, float(eps), _lib.ptr(rn), _lib.stream_ptr()), "visrep_row_rnorm_f32")
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    gram = torch.empty(min(chunk, max(n, 1)), PP, PP, dtype=torch.float32, device=dev)
+    for s in range(0, n, chunk):
+        a, b = i1[s:s + chunk].contiguous(), i2[s:s + chunk].contiguous()
+        m = a.shape[0]
+        _lib.check(lib.visrep_gram_pairs_f32(_lib.ptr(bank), _lib.ptr(a), _lib.ptr(b), m, PP, C_, _lib.ptr(gram), _lib.stream_ptr()), "visrep_gram_pairs_f32")
+        r1, r2 = rn.index_select(0, a.long()).contiguous(), rn.index_select(0, b.long()).contiguous()
+        _lib.check(lib.visrep_mutual_nn_distance(_lib.ptr(gram), _lib.ptr(r1), _lib.ptr(r2), m, PP, C.c_void_p(out.data_ptr() + 4 * s), _lib.stream_ptr()),
+                   "visrep_mutual_nn_distance")
+    return out

@@ -230,7 +230,120 @@ __global__ void cscore_pck(const float* __restrict__ xy, const float* __restrict
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = nv;
 }
 
+// ---- ADAPT_FLIP support (pck_train.py:111-126): the "mutual nearest neighbour" distance of two descriptor sets,
+// utils_correspondence.py:54-73 get_distance_mutual_nn: D = cdist(F1, F2) over the L2-normalised descriptors; nn12[i] = argmin_j D[i, j],
+// nn21[j] = argmin_i D[i, j]; result = mean over the mutual pairs (nn21[nn12[i]] == i) of D[i, nn12[i]].
+// Input: the RAW Gram G = F1raw F2raw^T of the pair (visrep_gram_pairs_f32) and the normalisation factors r = 1 / (|x| + 1e-10) of both
+// sets; with a = |x| r = 1 - 1e-10 r the squared distance is a_i^2 + b_j^2 - 2 G_ij r1_i r2_j (torch.cdist's matmul form, clamped at 0).
+// One workgroup per pair, one wave per row (lanes over the columns, coalesced); the column minima are accumulated on the fly:
+// lane l owns columns l + 64 k and keeps their running (min, first argmin) over the rows its wave visits in increasing order.
+// Ties resolve to the smallest index like torch.argmin.
+__global__ __launch_bounds__(256) void mutual_nn_kernel(const float* __restrict__ gram, const float* __restrict__ r1, const float* __restrict__ r2,
+                                                        int PP, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dmin = sm;                          // [PP] min distance^2 of row i
+    int* nn12 = reinterpret_cast<int*>(sm + PP);          // [PP]
+    float* cmin = sm + 2 * PP;                 // [4][PP] per-wave column minima
+    int* cidx = reinterpret_cast<int*>(sm + 6 * PP);      // [4][PP]
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* G = gram + (size_t)pair * PP * PP;
+    const float* ra = r1 + (size_t)pair * PP;
+    const float* rb = r2 + (size_t)pair * PP;
+    constexpr int KC = 16;                     // columns per lane: PP <= 1024
+    float cb[KC], cv[KC], b2[KC];
+    int ci[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int j = lane + 64 * k;
+        cb[k] = j < PP ? rb[j] : 0.f;
+        const float b = 1.0f - 1e-10f * cb[k];
+        b2[k] = b * b;
+        cv[k] = INFINITY; ci[k] = 0x7fffffff;
+    }
+    for (int i = wave; i < PP; i += 4) {
+        const float ri = ra[i];
+        const float a = 1.0f - 1e-10f * ri, a2 = a * a;
+        float best = INFINITY;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int j = lane + 64 * k;
+            if (j < PP) {
+                const float d2 = fmaxf(a2 + b2[k] - 2.0f * G[(size_t)i * PP + j] * ri * cb[k], 0.f);
+                if (d2 < best) { best = d2; bj = j; }              // increasing j within a lane: first minimum kept
+                if (d2 < cv[k]) { cv[k] = d2; ci[k] = i; }           // increasing i within a wave: first minimum kept
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {                         // lexicographic (value, index) minimum over the lanes
+            const float ov = __shfl_xor(best, o);
+            const int oj = __shfl_xor(bj, o);
+            if (ov < best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+        }
+        if (lane == 0) { dmin[i] = best; nn12[i] = bj; }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int j = lane + 64 * k;
+        if (j < PP) { cmin[wave * PP + j] = cv[k]; cidx[wave * PP + j] = ci[k]; }
+    }
+    __syncthreads();
+    int* nn21 = cidx;                                               // wave 0's slice receives the combined result
+    for (int j = threadIdx.x; j < PP; j += 256) {
+        float v = cmin[j];
+        int idx = cidx[j];
+        for (int w = 1; w < 4; ++w) {
+            const float ov = cmin[w * PP + j];
+            const int oi = cidx[w * PP + j];
+            if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        nn21[j] = idx;
+    }
+    __syncthreads();
+    float sum = 0.f;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < PP; i += 256)
+        if (nn21[nn12[i]] == i) { sum += sqrtf(dmin[i]); ++cnt; }
+    sum = wave_sum(sum);
+    float fc = wave_sum((float)cnt);
+    __syncthreads();
+    if (lane == 0) { cmin[wave] = sum; cmin[4 + wave] = fc; }
+    __syncthreads();
+    if (threadIdx.x == 0) out[pair] = (cmin[0] + cmin[1] + cmin[2] + cmin[3]) / (cmin[4] + cmin[5] + cmin[6] + cmin[7]);   // 0 / 0 = nan like torch's empty mean
+}
+
+// r[row] = 1 / (|x_row| + eps): normalize_feats' factor (pck_train.py:24-29), one wave per row
+__global__ __launch_bounds__(256) void row_rnorm_kernel(const float* __restrict__ x, long rows, int C, float eps, float* __restrict__ r) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) r[row] = 1.0f / (sqrtf(s) + eps);
+}
+
 }  // namespace
+
+extern "C" int visrep_row_rnorm_f32(const float* x, long rows, int C, float eps, float* r, void* stream) {
+    if (!x || !r) return visrep_set_error(VISREP_ERR_ARG, "row_rnorm_f32: null pointer");
+    if (rows <= 0) return 0;
+    if (C <= 0 || (C & 3)) return visrep_set_error(VISREP_ERR_SHAPE, "row_rnorm_f32: C must be a multiple of 4");
+    hipLaunchKernelGGL(row_rnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, eps, r);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "row_rnorm_f32: launch failed");
+}
+
+extern "C" int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float* out, void* stream) {
+    if (!gram || !r1 || !r2 || !out) return visrep_set_error(VISREP_ERR_ARG, "mutual_nn_distance: null pointer");
+    if (n_pairs <= 0) return 0;
+    if (PP <= 0 || PP > 1024) return visrep_set_error(VISREP_ERR_SHAPE, "mutual_nn_distance: 1 <= P*P <= 1024");
+    hipLaunchKernelGGL(mutual_nn_kernel, dim3(n_pairs), dim3(256), (size_t)10 * PP * sizeof(float), (hipStream_t)stream, gram, r1, r2, PP, out);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mutual_nn_distance: launch failed");
+}
 
 extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
                                       const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window,

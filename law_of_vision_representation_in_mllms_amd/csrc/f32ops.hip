@@ -26,6 +26,7 @@ struct GemmF32Args {
     float alpha;         // C = epi(alpha * A W + bias)
     int nb2;             // batches: blockIdx.z = b1 * nb2 + b2, element strides below
     long sA1, sA2, sW1, sW2, sC1, sC2;
+    const int* idxA; const int* idxW;   // gather form (nb2 == 1): batch z reads A + idxA[z] * sA1 and W + idxW[z] * sW1
 };
 
 constexpr int FBM = 128, FBN = 128, FBK = 16, FLD = 132;   // FLD: LDS row stride (floats); 132 * 4 B keeps 16-B alignment, 2-way write conflicts at most
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
     const int lq = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z - b1 * p.nb2;
-    const float* A = p.A + b1 * p.sA1 + b2 * p.sA2;
-    const float* W = p.W + b1 * p.sW1 + b2 * p.sW2;
+    const float* A = p.A + (p.idxA ? (long)p.idxA[b1] : (long)b1) * p.sA1 + b2 * p.sA2;
+    const float* W = p.W + (p.idxW ? (long)p.idxW[b1] : (long)b1) * p.sW1 + b2 * p.sW2;
     float* C = p.C + b1 * p.sC1 + b2 * p.sC2;
     const float* R = p.resid ? p.resid + b1 * p.sC1 + b2 * p.sC2 : nullptr;
     const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
@@ -280,6 +281,17 @@ extern "C" int visrep_gemm_f32(const float* A, int lda, const float* W, int ldw,
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.w_kn = w_kn; a.epi = epilogue; a.act = act; a.alpha = alpha; a.nb2 = nb2;
     if (strides6) { a.sA1 = strides6[0]; a.sA2 = strides6[1]; a.sW1 = strides6[2]; a.sW2 = strides6[3]; a.sC1 = strides6[4]; a.sC2 = strides6[5]; }
     return launch_gemm_f32(a, nb1 * nb2, (hipStream_t)stream);
+}
+
+// Gram matrices of image pairs from a bank of position-major maps: G[z] = bank[idx1[z]] bank[idx2[z]]^T  ([PP, C] x [PP, C]^T -> [PP, PP])
+extern "C" int visrep_gram_pairs_f32(const float* bank, const int* idx1, const int* idx2, int n_pairs, int PP, int C, float* gram, void* stream) {
+    if (!bank || !idx1 || !idx2 || !gram) return visrep_set_error(VISREP_ERR_ARG, "gram_pairs_f32: null pointer");
+    if (n_pairs <= 0) return 0;
+    if (PP <= 0 || C <= 0 || (C & 3) || (PP & 3)) return visrep_set_error(VISREP_ERR_SHAPE, "gram_pairs_f32: PP and C must be multiples of 4");
+    GemmF32Args a{};
+    a.A = bank; a.W = bank; a.C = gram; a.M = PP; a.N = PP; a.K = C; a.lda = C; a.ldw = C; a.ldc = PP; a.epi = EPI_BIAS; a.alpha = 1.f; a.nb2 = 1;
+    a.sA1 = (long)PP * C; a.sW1 = (long)PP * C; a.sC1 = (long)PP * PP; a.idxA = idx1; a.idxW = idx2;
+    return launch_gemm_f32(a, n_pairs, (hipStream_t)stream);
 }
 
 extern "C" int visrep_layernorm_f32(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int d, float eps, void* stream) {

@@ -146,3 +146,45 @@ def weighted_pcks(per_cat_values, weights):
     # logger.py:61-72
     v = np.asarray(per_cat_values, dtype=np.float64)   # [n_cat, 3]
     return tuple(np.average(v[:, j], weights=weights) for j in range(3))
+
+
+# ---------------------------------------------------------------------------------------------------- ADAPT_FLIP (pck_train.py:111-126)
+def mutual_nn_distance(desc1: torch.Tensor, desc2: torch.Tensor) -> torch.Tensor:
+    """get_distance_mutual_nn, utils_correspondence.py:54-73: desc* [1, P^2, C] normalised descriptors -> mean distance of the
+    mutual nearest neighbours (0-dim tensor; nan if there are none)."""
+    d = torch.cdist(desc1, desc2)[0]
+    nn12, nn21 = torch.argmin(d, dim=1), torch.argmin(d, dim=0)
+    mutual = nn21[nn12] == torch.arange(d.shape[0])
+    return torch.min(d, dim=1)[0][mutual].mean()
+
+
+def permute_indices(flip_list, vis=None):
+    """utils_geoware.py:151-189: twins of a group trade places when (vis is None or) the whole group is visible."""
+    flat = []
+    for item in flip_list:
+        flat += item if isinstance(item, list) else [item]
+    idx = list(range(max(flat) + 1))
+    for item in flip_list:
+        if isinstance(item, list) and (vis is None or all(bool(vis[i]) for i in item)):
+            for n, i in enumerate(item):
+                idx[i] = item[(n + 1) % len(item)]
+    return idx
+
+
+def flip_keypoints(kps: torch.Tensor, img_size, permute_list=None) -> torch.Tensor:
+    # utils_geoware.py:199-204
+    out = kps.detach().clone()
+    out[:, 0] = img_size - out[:, 0]
+    return out if permute_list is None else out[permute_list]
+
+
+def adapt_flip_prediction(pred, pred_flip, kps1, kps2, flip_dist, orig_dist, permute_list, anno_size=840):
+    """optimized_kps_1_to_2, utils_geoware.py:269-279."""
+    vis = kps1[:, 2] * kps2[:, 2] > 0
+    masked = kps1 * vis.unsqueeze(-1).float()
+    flipped = flip_keypoints(masked, anno_size, permute_indices(permute_list, None))
+    vis_flip = flipped[:, 2] * kps2[:, 2] * kps1[:, 2] > 0
+    out = pred.clone()
+    if flip_dist < orig_dist:
+        out[vis_flip] = pred_flip[vis_flip]
+    return out

@@ -545,6 +545,82 @@ def gen_spair():
 
 
 # ----------------------------------------------------------------------------- mini AP-10k / PF-Pascal trees
+def gen_adaptflip():
+    """ADAPT_FLIP + MUTUAL_NN (pck_train.py:82-94,111-126; utils_correspondence.py:54-73 get_distance_mutual_nn; utils_geoware.py
+    permute_indices / flip_keypoints / optimized_kps_1_to_2): the reference's own eval() on the committed mini SPair tree with a
+    mirrored feature file per image, plus get_distance_mutual_nn on random descriptor sets.  Its `.cuda()` calls are made no-ops
+    (there is no GPU in the build container); nothing else is changed."""
+    import shutil
+    from PIL import Image
+    sys.path.insert(0, f"{REF}/C_score")
+    _stub_modules()
+    import pck_train as PT
+    import utils.utils_correspondence as UC
+    import utils.utils_geoware as UG
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    # ---- the distance alone: P = 6 (cdist's direct path, P^2 <= 25 is false: 36 > 25 -> matmul path) and P = 16
+    rs = np.random.RandomState(71)
+    for tag, (P, C) in {"d6": (6, 32), "d16": (16, 64)}.items():
+        base = rs.standard_normal((P * P, C)).astype(np.float32)
+        f1 = base + 0.6 * rs.standard_normal((P * P, C)).astype(np.float32)
+        f2 = np.roll(base, 3, axis=0) + 0.6 * rs.standard_normal((P * P, C)).astype(np.float32)
+        n1 = torch.from_numpy(f1)[None] / (torch.linalg.norm(torch.from_numpy(f1)[None], dim=-1)[:, :, None] + 1e-10)
+        n2 = torch.from_numpy(f2)[None] / (torch.linalg.norm(torch.from_numpy(f2)[None], dim=-1)[:, :, None] + 1e-10)
+        out[f"{tag}.f1"], out[f"{tag}.f2"] = f1, f2
+        out[f"{tag}.dist"] = np.float64(UC.get_distance_mutual_nn(n1, n2).item())
+    # ---- flip helpers on a hand-made case
+    flip_list = [0, [1, 2], 3, [4, 5, 6]]
+    out["perm.all"] = np.array(UG.permute_indices(flip_list, None))
+    out["perm.vis"] = np.array(UG.permute_indices(flip_list, [True, True, False, True, True, True, True]))
+    k = torch.tensor([[10., 20., 1.], [30., 40., 1.], [50., 60., 0.], [70., 80., 1.], [90., 100., 1.], [110., 120., 1.], [130., 140., 1.]])
+    out["flipkps"] = UG.flip_keypoints(k, 840, UG.permute_indices(flip_list, None)).numpy()
+    # ---- eval() with ADAPT_FLIP on the mini tree
+    z = np.load(f"{HERE}/spair_host.npz")
+    P, C = z["meta"].tolist()
+    cats = {"aeroplane": 4, "cat": 3}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(f"{tmp}/data")
+        shutil.copytree(f"{HERE}/mini_spair", f"{tmp}/data/SPair-71k")
+        frs = np.random.RandomState(73)
+        for cat, n_img in cats.items():
+            os.makedirs(f"{tmp}/data/SPair-71k/features/{cat}")
+            centre = np.mean([z[f"feat.{cat}.{i}"] for i in range(n_img)], axis=0)
+            for i in range(n_img):
+                m = z[f"feat.{cat}.{i}"]
+                torch.save(torch.from_numpy(m), f"{tmp}/data/SPair-71k/features/{cat}/img{i}_dino.pt")
+                # stand-ins for the mirrored image's features: for odd images close to the category's common map (so the mirrored
+                # source is the nearer one and the flip branch is taken), for even images the mirrored map plus heavy noise
+                mf = (centre + 0.05 * frs.standard_normal(m.shape).astype(np.float32)) if i % 2 else \
+                     (m[:, :, :, ::-1].copy() + 0.9 * frs.standard_normal(m.shape).astype(np.float32))
+                torch.save(torch.from_numpy(mf), f"{tmp}/data/SPair-71k/features/{cat}/img{i}_dino_flip.pt")
+                out[f"flipfeat.{cat}.{i}"] = mf
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            PT.load_img_and_kps = lambda idx, files, kps, img_size=224, edge=False: (Image.new("RGB", (4, 4)), kps[idx])
+            PT.device = "cpu"
+            _gpd = PT.get_patch_descriptors
+            PT.get_patch_descriptors = lambda *a, **k: _gpd(*a, **{**k, "device": "cpu"})
+            PT.logger = sys.modules["loguru"].logger
+            args = argparse.Namespace(NUM_PATCHES=P, COMPUTE_GEOAWARE_METRICS=False, ADAPT_FLIP=True, EVAL_DATASET="spair",
+                                      TRAIN_DATASET="spair", ANNO_SIZE=840, ENSEMBLE=1, MODEL="dino", SOFT_EVAL=True,
+                                      SOFT_EVAL_WINDOW=5, KPT_RESULT=False, TOTAL_SAVE_RESULT=0, MUTUAL_NN=True, TEST_SAMPLE=0,
+                                      BBOX_THRE=True)
+            dists = []
+            _d = UC.get_distance_mutual_nn
+            PT.get_distance_mutual_nn = lambda a, b: (lambda v: (dists.append(float(v)), v)[1])(_d(a, b))
+            p10, p05, p01, results = PT.eval(args, PT.DummyAggregationNetwork(), tmp, split="test")
+            PT.get_distance_mutual_nn = _d
+        finally:
+            os.chdir(cwd)
+    out["eval.pck"] = np.array([p10, p05, p01], np.float64)
+    out["eval.pred"] = np.stack([r["src_kpts_pred"] for r in results]).astype(np.float32)
+    out["eval.dists"] = np.array(dists, np.float64).reshape(-1, 2)             # per pair (original, flip)
+    np.savez_compressed(f"{HERE}/adaptflip.npz", **out)
+    print("adaptflip.npz eval pck:", out["eval.pck"], "flip chosen for", int((out["eval.dists"][:, 1] < out["eval.dists"][:, 0]).sum()), "of", len(dists) // 2, "pairs")
+
+
 def gen_nextsets():
     """Synthetic AP-10k- and PF-Pascal-shaped trees and what the reference's loaders / eval() produce on them
     (utils_dataset.py:151-204, 278-371, 125-147; pck_train.py eval with EVAL_DATASET = ap10k / pascal).  The AP-10k json
@@ -1094,7 +1170,8 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip"]
     with torch.no_grad():
         for w in which:
-            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize}[w]()
+            {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize,
+             "adaptflip": gen_adaptflip}[w]()

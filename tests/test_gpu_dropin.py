@@ -298,3 +298,40 @@ def test_device_lanczos_and_geoaware_loader_are_bit_exact():
         for edge in (False, True):
             got = DP.geoaware_resize(a, T, edge)
             assert got.shape == (T, T, 3) and np.array_equal(got.cpu().numpy(), z[f"{tag}.edge{int(edge)}"]), (tag, edge)
+
+
+# ------------------------------------------------------------------------------------------------ ADAPT_FLIP on the device (§8f N4)
+def test_mutual_nn_distance_matches_the_reference():
+    """visrep_gram_pairs_f32 + visrep_mutual_nn_distance vs the reference's get_distance_mutual_nn (tests/golden/adaptflip.npz), the
+    drop-in function, and a batch of pairs against the oracle."""
+    from law_of_vision_representation_in_mllms_amd import cscore_ops
+    from law_of_vision_representation_in_mllms_amd.C_score.utils import utils_correspondence as UC
+    from oracle import cscore as OC
+    zf = np.load(f"{G}/adaptflip.npz")
+    for tag, P in (("d6", 6), ("d16", 16)):
+        f1, f2 = torch.from_numpy(zf[f"{tag}.f1"]), torch.from_numpy(zf[f"{tag}.f2"])
+        bank = torch.stack([f1, f2]).to(DEV)
+        got = cscore_ops.mutual_nn_distance(bank, torch.tensor([0, 1]), torch.tensor([1, 0]), P).cpu()
+        assert abs(got[0].item() - float(zf[f"{tag}.dist"])) < 1e-4, tag
+        want10 = OC.mutual_nn_distance(OC.normalize_feats(f2[None]), OC.normalize_feats(f1[None])).item()
+        assert abs(got[1].item() - want10) < 1e-4
+        d = UC.get_distance_mutual_nn(OC.normalize_feats(f1[None]), OC.normalize_feats(f2[None]))
+        assert abs(d.item() - float(zf[f"{tag}.dist"])) < 1e-4
+    g = torch.Generator().manual_seed(9)
+    bank = torch.randn(7, 24 * 24, 64, generator=g) + 2.0 * torch.randn(1, 24 * 24, 64, generator=g)      # P = 24: 9 columns per lane
+    i1, i2 = torch.tensor([0, 3, 6, 2, 5]), torch.tensor([1, 3, 0, 4, 6])
+    got = cscore_ops.mutual_nn_distance(bank.to(DEV), i1, i2, 24, chunk=2).cpu()                           # chunked launches
+    for n, (a, b) in enumerate(zip(i1.tolist(), i2.tolist())):
+        want = OC.mutual_nn_distance(OC.normalize_feats(bank[a][None]), OC.normalize_feats(bank[b][None])).item()
+        assert abs(got[n].item() - want) < 1e-4, (n, got[n].item(), want)
+    assert got[1].item() < 1e-3                                                                            # a map against itself
+
+
+def test_adapt_flip_eval_on_device_matches_reference_eval(tmp_path):
+    from test_host_cscore import make_flip_tree
+    root, z, zf = make_flip_tree(str(tmp_path))
+    a = eval_args(root, 16)
+    a.ADAPT_FLIP, a.MUTUAL_NN = True, True
+    p10, p05, p01, results = PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+    np.testing.assert_allclose([p10, p05, p01], zf["eval.pck"], atol=1e-7)
+    np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), zf["eval.pred"], atol=5e-3)

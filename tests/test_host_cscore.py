@@ -31,7 +31,7 @@ def cpu_descriptors(m, P, split=0, layout="cp"):
     return OC.normalize_feats_two(m.view(1, C, P * P).permute(0, 2, 1), split)
 
 
-def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840, split=0, layout="cp"):
+def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840, split=0, layout="cp", sort_pairs=True):
     n, kmax = patch_idx.shape
     out = torch.zeros(n, kmax, 2)
     for i in range(n):
@@ -53,10 +53,19 @@ def cpu_pck_counts(xy, kps1, kps2, thresholds, nkp, alphas=(0.1, 0.05, 0.01)):
     return cnt
 
 
+def cpu_mutual_nn(bank, img1, img2, P, chunk=2048, eps=1e-10):
+    """oracle-backed stand-in of cscore_ops.mutual_nn_distance: position-major raw maps [n, P^2, C]"""
+    out = []
+    for a, b in zip(img1.tolist(), img2.tolist()):
+        out.append(OC.mutual_nn_distance(OC.normalize_feats(bank[a][None].float()), OC.normalize_feats(bank[b][None].float())))
+    return torch.stack(out)
+
+
 @pytest.fixture
 def cpu_ops(monkeypatch):
     monkeypatch.setattr(cscore_ops, "transfer", cpu_transfer)
     monkeypatch.setattr(cscore_ops, "pck_counts", cpu_pck_counts)
+    monkeypatch.setattr(cscore_ops, "mutual_nn_distance", cpu_mutual_nn)
 
 
 def make_tree(tmp):
@@ -225,3 +234,48 @@ def test_result_postprocessing_matches_reference(tmp_path, cpu_ops):
     np.testing.assert_allclose(std, z["post.std"], atol=1e-7)
     assert n == z["post.n"].tolist()
     assert ES.get_img_result(conv, cls="nope")[1] == 0
+
+
+# ------------------------------------------------------------------------------------------------ ADAPT_FLIP (§8f N4)
+def make_flip_tree(tmp):
+    root, z = make_tree(tmp)
+    zf = np.load(f"{G}/adaptflip.npz")
+    for key in zf.files:
+        if key.startswith("flipfeat."):
+            _, cat, i = key.split(".")
+            torch.save(torch.from_numpy(zf[key]), f"{root}/features/{cat}/img{i}_dino_flip.pt")
+    return root, z, zf
+
+
+def test_flip_helpers_and_distance_oracle_match_the_reference():
+    from law_of_vision_representation_in_mllms_amd.C_score.utils import utils_geoware as UG
+    zf = np.load(f"{G}/adaptflip.npz")
+    flip_list = [0, [1, 2], 3, [4, 5, 6]]
+    vis = [True, True, False, True, True, True, True]
+    k = torch.tensor([[10., 20., 1.], [30., 40., 1.], [50., 60., 0.], [70., 80., 1.], [90., 100., 1.], [110., 120., 1.], [130., 140., 1.]])
+    for mod in (UG, OC):
+        assert mod.permute_indices(flip_list, None) == zf["perm.all"].tolist()
+        assert mod.permute_indices(flip_list, vis) == zf["perm.vis"].tolist()
+        np.testing.assert_array_equal(mod.flip_keypoints(k, 840, mod.permute_indices(flip_list, None)).numpy(), zf["flipkps"])
+    for tag in ("d6", "d16"):
+        n1 = OC.normalize_feats(torch.from_numpy(zf[f"{tag}.f1"])[None])
+        n2 = OC.normalize_feats(torch.from_numpy(zf[f"{tag}.f2"])[None])
+        assert abs(OC.mutual_nn_distance(n1, n2).item() - float(zf[f"{tag}.dist"])) < 1e-6
+    # the permute list compute_pck derives for a category: table restricted to the used key points, renumbered (pck_train.py:82-94)
+    assert UG.flip_permutation(UG.SPAIR_FLIP["cat"], [0, 1, 4, 5, 8], 5) == [[0, 1], [2, 3], [4]]
+    assert UG.flip_permutation(UG.SPAIR_FLIP["bottle"], list(range(10)), 10) == UG.SPAIR_FLIP["bottle"]
+
+
+def test_adapt_flip_eval_matches_reference_eval(tmp_path, cpu_ops):
+    """pck_train.eval with ADAPT_FLIP + MUTUAL_NN on the mini tree (mirrored feature file per image) == the reference's own run:
+    6 of the 10 pairs take the mirrored prediction there."""
+    root, z, zf = make_flip_tree(str(tmp_path))
+    a = eval_args(root, 16)
+    a.ADAPT_FLIP, a.MUTUAL_NN = True, True
+    p10, p05, p01, results = PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+    np.testing.assert_allclose([p10, p05, p01], zf["eval.pck"], atol=1e-7)
+    np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), zf["eval.pred"], atol=2e-3)
+    assert not np.allclose(zf["eval.pred"], z["eval.pred"], atol=1.0)          # the flip branch really changes predictions
+    a.MUTUAL_NN = False
+    with pytest.raises(NotImplementedError, match="60x60"):
+        PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
