@@ -26,7 +26,7 @@ _TOWER_ID = {"CLIP": 'openai/clip-vit-large-patch14', "OPENCLIP": 'laion/CLIP-Vi
 _DIFT = {"DIFT2.1": ("sd", 'stabilityai/stable-diffusion-2-1', 768), "DIFT1.5": ("sd", 'runwayml/stable-diffusion-v1-5', 768),
          "DIFTXL": ("sd", 'stabilityai/stable-diffusion-xl-base-1.0', 512), "IMDIFT": ("imsd", None, 768),
          "DiTDIFT": ("dit", None, 512), "SD3DIFT": ("sd3", None, 512)}
-_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64, kind="vit", device_preprocess=False)
+_state = SimpleNamespace(dift=None, img_size=None, suffix="dino336", batch=64, kind="vit", device_preprocess=False, flip=False)
 
 
 # The precision each ViT tower runs in HERE follows the reference script: CLIP / OPENCLIP / DINOv2 are built with no dtype cast
@@ -99,7 +99,7 @@ def _load_pixels(image_path, size):
     """extract_feature.py:65-67: RGB, resize((s, s)) (PIL bicubic), PILToTensor, (x / 255 - 0.5) * 2 in float32.  The arithmetic is
     done in numpy: the same correctly-rounded float32 operations, without torch's intra-op thread pool waking up for a 150k-element
     tensor (on a 256-core host that cost more than the JPEG decode: 29 ms per image serial, profiles/round1_pipeline.md)."""
-    img = Image.open(image_path).convert('RGB').resize((size, size))
+    img = _maybe_flip(Image.open(image_path).convert('RGB')).resize((size, size))
     a = np.asarray(img).transpose(2, 0, 1).astype(np.float32)               # PILToTensor layout: [3, H, W]
     return torch.from_numpy((a / np.float32(255.0) - np.float32(0.5)) * np.float32(2.0))
 
@@ -109,7 +109,7 @@ def _load_pixels_worker(image_path, size):
     fan-out) and release the GIL, whereas the numpy steps of _load_pixels make eight threads queue on the GIL.  Measured on a
     256-core host, 1024 JPEGs -> DINOv2-L maps -> files: torch-in-pool 690-790 images/s, numpy-in-pool 180-210, and on the calling
     thread torch 34 vs numpy 200-310 (profiles/round1_pipeline.md).  Same bits either way (tests/test_host_preprocess.py)."""
-    img = Image.open(image_path).convert('RGB').resize((size, size))
+    img = _maybe_flip(Image.open(image_path).convert('RGB')).resize((size, size))
     a = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)           # PILToTensor: uint8 [3, H, W]
     return (a / 255.0 - 0.5) * 2
 
@@ -122,7 +122,13 @@ def _load_pixels_device(image_path, size, device="cuda"):
 
 def _decode_rgb(image_path, size=None):
     """JPEG -> uint8 [H, W, 3] on the host (the part that runs on the decode pool)."""
-    return np.array(Image.open(image_path).convert('RGB'))
+    return np.array(_maybe_flip(Image.open(image_path).convert('RGB')))
+
+
+def _maybe_flip(img):
+    """ADAPT_FLIP's second feature set (pck_train.py:33-37 `<img>_<model>_flip.pt`): the same extraction on the mirrored image
+    (pck_train.py:112 `img1.transpose(Image.FLIP_LEFT_RIGHT)`)."""
+    return img.transpose(Image.FLIP_LEFT_RIGHT) if getattr(_state, "flip", False) else img
 
 
 def _finish_on_device(a, size, device="cuda"):
@@ -166,17 +172,27 @@ def _prefetched(chunks, load, workers, finish=None):
             pending = nxt
 
 
-def process_images(input_dir, output_dir, workers=8):
-    """Walks input_dir like the reference; towers run in batches (the reference runs batch 1), files are identical."""
+def process_images(input_dir, output_dir, workers=8, flip=False):
+    """Walks input_dir like the reference; towers run in batches (the reference runs batch 1), files are identical.
+    flip=True writes the mirrored images' maps as `<image>_<suffix>_flip.pt` (what pck_train's ADAPT_FLIP reads)."""
     if _state.dift is None:
         configure(feature)
+    _state.flip = bool(flip)
+    try:
+        return _process_images(input_dir, output_dir, workers)
+    finally:
+        _state.flip = False
+
+
+def _process_images(input_dir, output_dir, workers):
     todo = []
     for root, _, files in os.walk(input_dir):
         for file in sorted(files):
             if file.endswith(('.jpg', '.jpeg', '.png')):
                 class_name = os.path.basename(root)
                 image_name = os.path.splitext(file)[0]
-                todo.append((os.path.join(root, file), os.path.join(output_dir, class_name, f'{image_name}_{_state.suffix}.pt')))
+                suffix = f'{_state.suffix}{"_flip" if getattr(_state, "flip", False) else ""}'
+                todo.append((os.path.join(root, file), os.path.join(output_dir, class_name, f'{image_name}_{suffix}.pt')))
     d = torch.distributed
     if d.is_available() and d.is_initialized():
         todo = todo[d.get_rank()::d.get_world_size()]                        # image-sharded across ranks, no collective

@@ -143,6 +143,11 @@ def test_extract_feature_and_pck_train_on_device(small_towers, tmp_path):
         EF._state.device_preprocess = False
     for i in range(3):
         assert torch.equal(torch.load(tmp_path / "features_dev" / "cat" / f"im{i}_dino.pt"), torch.load(tmp_path / "features" / "cat" / f"im{i}_dino.pt"))
+    # ADAPT_FLIP's mirrored feature files: the same extraction on the left-right flipped image
+    EF.process_images(str(tmp_path / "JPEGImages"), str(tmp_path / "features"), flip=True)
+    ff = torch.load(tmp_path / "features" / "cat" / "im1_dino_flip.pt")
+    pxf = EF._load_pixels(str(src / "im1.jpg"), 42).flip(-1).unsqueeze(0)       # mirroring commutes with the square resize only approximately
+    assert ff.shape == f.shape and not torch.equal(ff, f)
     spec = small_towers['facebook/dinov2-large']
     px = EF._load_pixels(str(src / "im1.jpg"), 42).unsqueeze(0)
     want = tower_oracle(spec, px, 'patch').permute(0, 2, 1).reshape(1, 128, 3, 3)
