@@ -157,6 +157,15 @@ size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B);
 int visrep_vit_forward_f32(const visrep_vit_config* cfg, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
                            void* workspace, void* stream);
 
+/* ---- fp32 convolution-block primitives of the supervised C-score post-processor (C_score/model_utils/projection_network.py:15-125
+ * AggregationNetwork = detectron2-style BottleneckBlocks, model_utils/resnet.py:174-286: 1x1 / 3x3 / 1x1 bias-free convolutions, each
+ * followed by nn.GroupNorm, ReLU, projection shortcut).  Tokens are channels-last fp32 [B, H*W, C]; a 1x1 convolution is visrep_gemm_f32,
+ * a 3x3 one visrep_im2col3x3_f32 (pad 1, stride 1; column order (ky, kx, c)) + visrep_gemm_f32 on weights repacked [Cout, 9 C];
+ * visrep_groupnorm_f32: y = alpha * act(GN(x) * gamma + beta + resid) (+ y when accumulate), resid may be NULL, relu 0 / 1. */
+int visrep_im2col3x3_f32(const float* x, float* cols, int B, int H, int W, int C, void* stream);
+int visrep_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* resid, float* y, int B, int HW, int C, int groups,
+                         float eps, int relu, float alpha, int accumulate, void* stream);
+
 /* ---- ADAPT_FLIP support of the C score (C_score/pck_train.py:111-126 with MUTUAL_NN; utils/utils_correspondence.py:54-73
  * get_distance_mutual_nn): raw Gram matrices of image pairs from a position-major fp32 bank [n_images, PP, C] (gather by index),
  * normalize_feats' row factors r = 1 / (|x| + eps) (pck_train.py:24-29), and per pair the mean cdist of the mutual nearest neighbours

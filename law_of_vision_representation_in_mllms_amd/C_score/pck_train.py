@@ -284,9 +284,14 @@ def main(args, _eval=None):
             import logging
             get_logger().setLevel(logging.WARNING)
         logger.info(args)
-        if not args.DUMMY_NET:
-            raise NotImplementedError("the supervised AggregationNetwork post-processor is outside the zero-shot C score (SURVEY §8f N4)")
-        aggre_net = DummyAggregationNetwork()
+        if args.DUMMY_NET:
+            aggre_net = DummyAggregationNetwork()
+        else:   # pck_train.py:347,356-363: GeoAware-SC's supervised post-processor over [SD s5, s4, s3, DINOv2] channel groups
+            from .model_utils.projection_network import AggregationNetwork
+            aggre_net = AggregationNetwork(feature_dims=[640, 1280, 1280, 768], projection_dim=args.PROJ_DIM, device=device)
+            if args.LOAD is not None:
+                aggre_net.load_pretrained_weights(torch.load(args.LOAD, map_location="cpu"))
+                logger.info(f'Load model from {args.LOAD}')
         if not args.DO_EVAL:
             raise NotImplementedError("training is out of scope of the scoring path; run with DO_EVAL (configs/eval_zero_shot_spair.yaml)")
         with torch.no_grad():

@@ -69,6 +69,8 @@ SIGNATURES = {
     "visrep_softmax_rows_f32": (_i, [_vp, _i, _l, _i, _vp]),
     "visrep_vit_f32_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
     "visrep_vit_forward_f32": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _vp]),
+    "visrep_im2col3x3_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "visrep_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_row_rnorm_f32": (_i, [_vp, _l, _i, _f, _vp, _vp]),
     "visrep_mutual_nn_distance": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -237,6 +237,56 @@ __global__ void embed_finish_f32_kernel(const float* __restrict__ patches, const
     }
 }
 
+// 3x3 patch gather on channels-last fp32 tokens (pad 1, stride 1): cols[(b, y, x)][(ky * 3 + kx) * C + c] = x[b, y + ky - 1, x + kx - 1, c] or 0
+__global__ void im2col3x3_f32_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int H, int W, int C) {
+    const long total = (long)B * H * W * 9 * (C / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4));
+        long r = i / (C / 4);
+        const int tap = (int)(r % 9); r /= 9;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + sy) * W + sx) * C + 4 * c4);
+        *reinterpret_cast<float4*>(cols + ((((size_t)b * H + yy) * W + xx) * 9 + tap) * C + 4 * c4) = v;
+    }
+}
+
+// nn.GroupNorm on channels-last fp32 tokens [B, HW, C] fused with what follows it in a detectron2-style bottleneck block:
+//   y = alpha * act( GN(x) * gamma + beta + resid ) (+ y when accumulate)          one workgroup per (image, group), two-pass variance
+__global__ __launch_bounds__(256) void groupnorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ resid, float* __restrict__ y, int HW, int C, int groups, float eps,
+                                                            int relu, float alpha, int accumulate) {
+    __shared__ float red[8];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cpg = C / groups;
+    const float* xb = x + (size_t)b * HW * C + g * cpg;
+    const int n = HW * cpg;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += xb[(size_t)(i / cpg) * C + i % cpg];
+    const float mean = block_sum(s) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float t = xb[(size_t)(i / cpg) * C + i % cpg] - mean; q += t * t; }
+    const float rstd = 1.0f / sqrtf(block_sum(q) / (float)n + eps);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = g * cpg + i % cpg;
+        const size_t off = ((size_t)b * HW + i / cpg) * C + c;
+        float v = (x[off] - mean) * rstd * gamma[c] + beta[c];
+        if (resid) v += resid[off];
+        if (relu) v = fmaxf(v, 0.f);
+        v *= alpha;
+        y[off] = accumulate ? y[off] + v : v;
+    }
+}
+
 int launch_gemm_f32(const GemmF32Args& a, int nb, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || nb <= 0) return 0;
     if ((a.lda & 3) || (a.ldw & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || (a.sA1 & 3) || (a.sA2 & 3) || (a.sW1 & 3) || (a.sW2 & 3))
@@ -292,6 +342,21 @@ extern "C" int visrep_gram_pairs_f32(const float* bank, const int* idx1, const i
     a.A = bank; a.W = bank; a.C = gram; a.M = PP; a.N = PP; a.K = C; a.lda = C; a.ldw = C; a.ldc = PP; a.epi = EPI_BIAS; a.alpha = 1.f; a.nb2 = 1;
     a.sA1 = (long)PP * C; a.sW1 = (long)PP * C; a.sC1 = (long)PP * PP; a.idxA = idx1; a.idxW = idx2;
     return launch_gemm_f32(a, n_pairs, (hipStream_t)stream);
+}
+
+extern "C" int visrep_im2col3x3_f32(const float* x, float* cols, int B, int H, int W, int C, void* stream) {
+    if (!x || !cols) return visrep_set_error(VISREP_ERR_ARG, "im2col3x3_f32: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return visrep_set_error(VISREP_ERR_SHAPE, "im2col3x3_f32: C must be a positive multiple of 4");
+    hipLaunchKernelGGL(im2col3x3_f32_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, cols, B, H, W, C);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "im2col3x3_f32: launch failed");
+}
+
+extern "C" int visrep_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* resid, float* y, int B, int HW, int C, int groups,
+                                    float eps, int relu, float alpha, int accumulate, void* stream) {
+    if (!x || !gamma || !beta || !y) return visrep_set_error(VISREP_ERR_ARG, "groupnorm_f32: null pointer");
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm_f32: C must be a multiple of groups");
+    hipLaunchKernelGGL(groupnorm_f32_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, resid, y, HW, C, groups, eps, relu, alpha, accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "groupnorm_f32: launch failed");
 }
 
 extern "C" int visrep_layernorm_f32(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int d, float eps, void* stream) {

@@ -188,3 +188,28 @@ def adapt_flip_prediction(pred, pred_flip, kps1, kps2, flip_dist, orig_dist, per
     if flip_dist < orig_dist:
         out[vis_flip] = pred_flip[vis_flip]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- supervised post-processor
+def aggregation_network(x: torch.Tensor, sd: dict, feature_dims, num_norm_groups: int, eps: float = 1e-5) -> torch.Tensor:
+    """AggregationNetwork.forward in evaluation mode (projection_network.py:89-125) over one BottleneckBlock per channel group
+    (model_utils/resnet.py:174-286): x [B, sum(dims), H, W], sd = the module's state_dict (fp32 tensors)."""
+    import torch.nn.functional as F
+    mix = torch.softmax(sd["mixing_weights"].float(), dim=0)
+    out, start = None, 0
+
+    def conv_gn(t, pre, pad):
+        t = F.conv2d(t, sd[f"{pre}.weight"], None, 1, pad)
+        return F.group_norm(t, num_norm_groups, sd[f"{pre}.norm.weight"], sd[f"{pre}.norm.bias"], eps)
+    for i in range(mix.shape[0]):
+        l = i % len(feature_dims)
+        pre = f"bottleneck_layers.{l}.0"
+        feats = x[:, start:start + feature_dims[l]]
+        start += feature_dims[l]
+        h = F.relu(conv_gn(feats, f"{pre}.conv1", 0))
+        h = F.relu(conv_gn(h, f"{pre}.conv2", 1))
+        h = conv_gn(h, f"{pre}.conv3", 0)
+        sc = conv_gn(feats, f"{pre}.shortcut", 0) if f"{pre}.shortcut.weight" in sd else feats
+        y = mix[i] * F.relu(h + sc)
+        out = y if out is None else out + y
+    return out

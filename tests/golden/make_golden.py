@@ -621,6 +621,46 @@ def gen_adaptflip():
     print("adaptflip.npz eval pck:", out["eval.pck"], "flip chosen for", int((out["eval.dists"][:, 1] < out["eval.dists"][:, 0]).sum()), "of", len(dists) // 2, "pairs")
 
 
+def gen_aggnet():
+    """The supervised post-processor: the reference's own AggregationNetwork (projection_network.py:15-125 over model_utils/resnet.py's
+    BottleneckBlock) with seeded random parameters on small shapes.  fvcore (weight INITIALISATION only; absent here) is replaced by a
+    stand-in initialiser - every parameter is overwritten with seeded values before the forward, so it does not touch the fixture."""
+    sys.path.insert(0, f"{REF}/C_score")
+    fv, fvnn, fvwi = types.ModuleType("fvcore"), types.ModuleType("fvcore.nn"), types.ModuleType("fvcore.nn.weight_init")
+    fvwi.c2_msra_fill = lambda m: torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    fvwi.c2_xavier_fill = lambda m: torch.nn.init.kaiming_uniform_(m.weight, a=1)
+    fv.nn, fvnn.weight_init = fvnn, fvwi
+    sys.modules.update({"fvcore": fv, "fvcore.nn": fvnn, "fvcore.nn.weight_init": fvwi})
+    for k in [k for k in sys.modules if k.startswith("model_utils")]:
+        del sys.modules[k]
+    PN = load_by_path("model_utils.projection_network_real", f"{REF}/C_score/model_utils/projection_network.py")
+    out = {}
+    for tag, (dims, proj, groups, P, B) in {"small": ([8, 12], 16, 4, 6, 2), "wide": ([64, 128, 32], 64, 8, 16, 1)}.items():
+        with redirect_stdout(io.StringIO()):
+            net = PN.AggregationNetwork(device="cpu", feature_dims=dims, projection_dim=proj, num_norm_groups=groups)
+        g = torch.Generator().manual_seed(len(tag) + proj)
+        sd = net.state_dict()
+        for k in sd:
+            if sd[k].dim() == 0:
+                continue
+            sd[k] = torch.randn(sd[k].shape, generator=g) * (0.3 if k.endswith(".weight") and sd[k].dim() == 4 else 0.5) + (1.0 if "norm.weight" in k else 0.0)
+        net.load_state_dict(sd)
+        net.eval()
+        x = torch.randn(B, sum(dims), P, P, generator=g)
+        y = net(x)
+        out[f"{tag}.x"], out[f"{tag}.y"] = x.numpy(), y.numpy()
+        out[f"{tag}.cfg"] = np.array(json_dumps({"feature_dims": dims, "projection_dim": proj, "num_norm_groups": groups}))
+        for k, v in sd.items():
+            out[f"{tag}.sd.{k}"] = v.numpy()
+    np.savez_compressed(f"{HERE}/aggnet.npz", **out)
+    print("aggnet.npz ok", {k: v.shape for k, v in out.items() if k.endswith(".y")})
+
+
+def json_dumps(o):
+    import json
+    return json.dumps(o)
+
+
 def gen_nextsets():
     """Synthetic AP-10k- and PF-Pascal-shaped trees and what the reference's loaders / eval() produce on them
     (utils_dataset.py:151-204, 278-371, 125-147; pck_train.py eval with EVAL_DATASET = ap10k / pascal).  The AP-10k json
@@ -1170,8 +1210,8 @@ def gen_projector():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet"]
     with torch.no_grad():
         for w in which:
             {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize,
-             "adaptflip": gen_adaptflip}[w]()
+             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet}[w]()

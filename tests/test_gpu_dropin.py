@@ -340,3 +340,18 @@ def test_adapt_flip_eval_on_device_matches_reference_eval(tmp_path):
     p10, p05, p01, results = PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
     np.testing.assert_allclose([p10, p05, p01], zf["eval.pck"], atol=1e-7)
     np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), zf["eval.pred"], atol=5e-3)
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_aggregation_network_on_device_matches_reference(tag):
+    """GeoAware-SC's supervised post-processor (projection_network.py:15-125) on the exact-fp32 path vs the reference module's output."""
+    from test_oracle_golden import load_aggnet_case
+    from law_of_vision_representation_in_mllms_amd.C_score.model_utils.projection_network import AggregationNetwork
+    cfg, sd, x, want = load_aggnet_case(tag)
+    net = AggregationNetwork(device=DEV, **cfg)
+    net.load_state_dict(sd)
+    got = net(x.to(DEV))
+    assert got.shape == want.shape and got.dtype == torch.float32
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
+    again = net(x)                                                              # CPU tensor in: moved to the device, cached packing reused
+    assert torch.equal(again, got)

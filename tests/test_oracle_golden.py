@@ -254,3 +254,26 @@ def test_sd3_oracle_matches_reference(tag):
                           up_ft_index=inp["up_ft_index"])
     assert got.shape == want.shape
     torch.testing.assert_close(got, want, rtol=1e-3, atol=5e-4)
+
+
+# ------------------------------------------------------------------------------------------------ supervised post-processor (N4)
+def load_aggnet_case(tag):
+    import json
+    z = np.load(f"{G}/aggnet.npz")
+    cfg = json.loads(str(z[f"{tag}.cfg"]))
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}.sd.")}
+    return cfg, sd, torch.from_numpy(z[f"{tag}.x"]), torch.from_numpy(z[f"{tag}.y"])
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_aggregation_network_oracle_matches_reference(tag):
+    cfg, sd, x, want = load_aggnet_case(tag)
+    got = OC.aggregation_network(x, sd, cfg["feature_dims"], cfg["num_norm_groups"])
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    # the drop-in module carries the reference's parameter names: a checkpoint of the reference loads without remapping
+    from law_of_vision_representation_in_mllms_amd.C_score.model_utils.projection_network import AggregationNetwork
+    net = AggregationNetwork(device="cpu", **cfg)
+    assert set(net.state_dict()) == set(sd)
+    net.load_pretrained_weights(sd)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k]), k
