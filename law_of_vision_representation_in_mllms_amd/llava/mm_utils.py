@@ -1,32 +1,33 @@
-"""Host-side image pre-processing — same functions as llava/mm_utils.py:64-95."""
+"""Host-side image pre-processing with the call signatures of llava/mm_utils.py:64-95 (`expand2square`, `process_images`).
+
+Behaviour kept from the reference: 'pad' mode squares every image on a mean-colour canvas (centred along the short side) and
+pre-processes all of them, stacking when the shapes agree; every other mode pre-processes ONLY `images[0]` - with a list of
+processors ('.'-fused towers) one `[1, 3, H, W]` batch per processor, otherwise the bare `[3, H, W]` tensor.
+"""
 import torch
 from PIL import Image
 
 
 def expand2square(pil_img, background_color):
-    width, height = pil_img.size
-    if width == height:
+    w, h = pil_img.size
+    if w == h:
         return pil_img
-    side = max(width, height)
-    result = Image.new(pil_img.mode, (side, side), background_color)
-    if width > height:
-        result.paste(pil_img, (0, (width - height) // 2))
-    else:
-        result.paste(pil_img, ((height - width) // 2, 0))
-    return result
+    side = max(w, h)
+    canvas = Image.new(pil_img.mode, (side, side), background_color)
+    canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))        # centred on the short axis, flush on the long one
+    return canvas
+
+
+def _pixels(processor, image):
+    return processor.preprocess(image, return_tensors='pt')['pixel_values']
 
 
 def process_images(images, image_processor, model_cfg):
-    image_aspect_ratio = getattr(model_cfg, "image_aspect_ratio", None)
-    new_images = []
-    if image_aspect_ratio == 'pad':
-        for image in images:
-            image = expand2square(image, tuple(int(x * 255) for x in image_processor.image_mean))
-            new_images.append(image_processor.preprocess(image, return_tensors='pt')['pixel_values'][0])
-    else:
+    if getattr(model_cfg, "image_aspect_ratio", None) != 'pad':
         if type(image_processor) is list:
-            return [p.preprocess(images[0], return_tensors='pt')['pixel_values'] for p in image_processor]
-        return image_processor.preprocess(images[0], return_tensors='pt')['pixel_values'][0]
-    if all(x.shape == new_images[0].shape for x in new_images):
-        new_images = torch.stack(new_images, dim=0)
-    return new_images
+            return [_pixels(p, images[0]) for p in image_processor]
+        return _pixels(image_processor, images[0])[0]
+    fill = tuple(int(c * 255) for c in image_processor.image_mean)
+    out = [_pixels(image_processor, expand2square(im, fill))[0] for im in images]
+    same = all(t.shape == out[0].shape for t in out)
+    return torch.stack(out, dim=0) if same else out
