@@ -20,8 +20,16 @@
 #include "common.h"
 #include "visrep_internal.h"
 
+#ifdef VISREP_EPI_NO_STORE   // timing-only (tools/): how much of a GEMM is its output store stream - results are not written
+VR_DEV void store_b64(void* ptr, u32x2 v) { asm volatile("" ::"v"(ptr), "v"(v)); }
+#else
 VR_DEV void store_b64(void* ptr, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ptr), "v"(v) : "memory"); }
+#endif
+#ifdef VISREP_EPI_NO_STORE
+VR_DEV void store_b128(void* ptr, f32x4 v) { asm volatile("" ::"v"(ptr), "v"(v)); }
+#else
 VR_DEV void store_b128(void* ptr, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
+#endif
 VR_DEV void drain_visible_loads() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0), expcnt / lgkmcnt untouched
 
 // sum of v over the lanes that differ from this one in lane bits 4 (RBLK == 16 only) and 5: the lanes that hold the other column
@@ -104,38 +112,64 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
         for (int ii = 0; ii < RB; ++ii) {
             const int i = i0 + ii;
             float st1 = 0.f, st2 = 0.f;
+            // Output stores.  16x16 accumulators: the four lanes fg = 0..3 of a row hold 4 consecutive columns each of every 16-column block
+            // j, i.e. 8-byte stores, 32 contiguous bytes per row and instruction.  The K = 1024 GEMMs spend 15-22 % of their time in this
+            // store stream (profiles/round2_store_stream.md: the same kernels without their stores), which is issue-bound, not
+            // bandwidth-bound.  WIDE: one v_permlane16_swap per word between the lanes fg and fg ^ 1 regroups a PAIR of column blocks
+            // (j, j + 1): even lanes end up with 8 consecutive columns of block j, odd lanes with 8 of block j + 1 -> one 16-byte store
+            // per pair instead of two 8-byte ones (64 contiguous bytes per row and instruction), same bytes, same addresses.
+            constexpr bool WIDE = QN == 1 && (NC % 2) == 0 && EPI != EPI_F32;
+            const bool wide = WIDE && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;     // uniform
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int j = c / QN, q = c % QN, n = col(c);
-                float v0, v1, v2, v3;
-                if (HAS_LN) {       // rstd * (acc - mean * s) + bias'
-                    v0 = __builtin_fmaf(acc[i][j][4 * q + 0], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].x, bv[c].x));
-                    v1 = __builtin_fmaf(acc[i][j][4 * q + 1], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].y, bv[c].y));
-                    v2 = __builtin_fmaf(acc[i][j][4 * q + 2], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].z, bv[c].z));
-                    v3 = __builtin_fmaf(acc[i][j][4 * q + 3], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].w, bv[c].w));
-                } else {
-                    v0 = acc[i][j][4 * q + 0] + bv[c].x; v1 = acc[i][j][4 * q + 1] + bv[c].y;
-                    v2 = acc[i][j][4 * q + 2] + bv[c].z; v3 = acc[i][j][4 * q + 3] + bv[c].w;
-                }
-                if (EPI == EPI_ACT) {
-                    v0 = apply_act(v0, ACT); v1 = apply_act(v1, ACT); v2 = apply_act(v2, ACT); v3 = apply_act(v3, ACT);
-                }
-                if (EPI == EPI_RESID) {
-                    if (HAS_LS) { v0 *= lv[c].x; v1 *= lv[c].y; v2 *= lv[c].z; v3 *= lv[c].w; }
-                    v0 += bf_lo(rv[ii][c][0]); v1 += bf_hi(rv[ii][c][0]); v2 += bf_lo(rv[ii][c][1]); v3 += bf_hi(rv[ii][c][1]);
-                }
-                if (EPI == EPI_PATCH) { v0 += pv[ii][c].x; v1 += pv[ii][c].y; v2 += pv[ii][c].z; v3 += pv[ii][c].w; }
-                if (ok[ii]) {
-                    if (EPI == EPI_F32) {
-                        store_b128(reinterpret_cast<float*>(p.C) + orow[ii] * p.ldc + n, f32x4{v0, v1, v2, v3});
+            for (int c0 = 0; c0 < NC; c0 += (WIDE ? 2 : 1)) {
+                u32x2 o2[WIDE ? 2 : 1];
+#pragma unroll
+                for (int cc = 0; cc < (WIDE ? 2 : 1); ++cc) {
+                    const int c = c0 + cc;
+                    const int j = c / QN, q = c % QN, n = col(c);
+                    float v0, v1, v2, v3;
+                    if (HAS_LN) {       // rstd * (acc - mean * s) + bias'
+                        v0 = __builtin_fmaf(acc[i][j][4 * q + 0], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].x, bv[c].x));
+                        v1 = __builtin_fmaf(acc[i][j][4 * q + 1], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].y, bv[c].y));
+                        v2 = __builtin_fmaf(acc[i][j][4 * q + 2], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].z, bv[c].z));
+                        v3 = __builtin_fmaf(acc[i][j][4 * q + 3], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].w, bv[c].w));
                     } else {
-                        u32x2 o = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
-                        store_b64(p.C + orow[ii] * p.ldc + n, o);
-                        if (HAS_ST) {
-                            const float r0 = bf_lo(o[0]), r1 = bf_hi(o[0]), r2 = bf_lo(o[1]), r3 = bf_hi(o[1]);
+                        v0 = acc[i][j][4 * q + 0] + bv[c].x; v1 = acc[i][j][4 * q + 1] + bv[c].y;
+                        v2 = acc[i][j][4 * q + 2] + bv[c].z; v3 = acc[i][j][4 * q + 3] + bv[c].w;
+                    }
+                    if (EPI == EPI_ACT) {
+                        v0 = apply_act(v0, ACT); v1 = apply_act(v1, ACT); v2 = apply_act(v2, ACT); v3 = apply_act(v3, ACT);
+                    }
+                    if (EPI == EPI_RESID) {
+                        if (HAS_LS) { v0 *= lv[c].x; v1 *= lv[c].y; v2 *= lv[c].z; v3 *= lv[c].w; }
+                        v0 += bf_lo(rv[ii][c][0]); v1 += bf_hi(rv[ii][c][0]); v2 += bf_lo(rv[ii][c][1]); v3 += bf_hi(rv[ii][c][1]);
+                    }
+                    if (EPI == EPI_PATCH) { v0 += pv[ii][c].x; v1 += pv[ii][c].y; v2 += pv[ii][c].z; v3 += pv[ii][c].w; }
+                    if (EPI == EPI_F32) {
+                        if (ok[ii]) store_b128(reinterpret_cast<float*>(p.C) + orow[ii] * p.ldc + n, f32x4{v0, v1, v2, v3});
+                    } else {
+                        o2[cc] = u32x2{pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                        if (HAS_ST && ok[ii]) {
+                            const float r0 = bf_lo(o2[cc][0]), r1 = bf_hi(o2[cc][0]), r2 = bf_lo(o2[cc][1]), r3 = bf_hi(o2[cc][1]);
                             st1 += (r0 + r1) + (r2 + r3);
                             st2 = __builtin_fmaf(r0, r0, __builtin_fmaf(r1, r1, __builtin_fmaf(r2, r2, __builtin_fmaf(r3, r3, st2))));
                         }
+                    }
+                }
+                if (EPI != EPI_F32) {
+                    if (WIDE && wide) {
+                        // swap(vdst = block j word, src = block j + 1 word): odd 16-lane rows of vdst <-> even rows of src.  Even lanes:
+                        // (own j, partner's j); odd lanes: (partner's j + 1, own j + 1) - ascending columns in both cases.
+                        const auto w0 = __builtin_amdgcn_permlane16_swap(o2[0][0], o2[WIDE ? 1 : 0][0], false, false);
+                        const auto w1 = __builtin_amdgcn_permlane16_swap(o2[0][1], o2[WIDE ? 1 : 0][1], false, false);
+                        if (ok[ii]) {
+                            const int nn = (hg & 1) ? col(c0 + (WIDE ? 1 : 0)) - 4 : col(c0);
+                            const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
+                            store_b128(p.C + orow[ii] * p.ldc + nn, __builtin_bit_cast(f32x4, q4));
+                        }
+                    } else if (ok[ii]) {
+#pragma unroll
+                        for (int cc = 0; cc < (WIDE ? 2 : 1); ++cc) store_b64(p.C + orow[ii] * p.ldc + col(c0 + cc), o2[cc]);
                     }
                 }
             }
@@ -223,17 +257,26 @@ VR_DEV void gemm_epilogue_vt_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], i
                 }
             drain_visible_loads();
         }
+        // WIDE (16x16 accumulators): the lanes fg and fg ^ 2 of a row hold token groups that are NEIGHBOURS in the perm16 order
+        // (memory order of the four 4-token groups of a 16-token block is 0, 2, 1, 3), so one v_permlane32_swap per word between the
+        // row blocks (i, i + 1) gives the lower half-wave 8 consecutive stored tokens of block i and the upper half-wave 8 of block
+        // i + 1: one 16-byte store per pair of blocks instead of two 8-byte ones (the store stream is issue-bound, see the row-major
+        // epilogue).  A chunk's first group is the lower-numbered one (groups 0 / 1, the second is group 2 / 3 = + 8 tokens).
+        constexpr bool WIDE = QN == 1 && (IH % 2) == 0;
+        const bool wide = WIDE && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;      // uniform
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             bf16_t* colp = p.C + (size_t)(nb + j * RBLK + fr) * p.ldc;
 #pragma unroll
-            for (int ii = 0; ii < IH; ++ii)
+            for (int ii0 = 0; ii0 < IH; ii0 += (WIDE ? 2 : 1))
 #pragma unroll
                 for (int q = 0; q < QN; ++q) {
-                    const int i = i0 + ii;
-                    const int m = mb + i * RBLK + q * 8 + hg * 4;                       // multiple of 4
-                    if (m < p.M) {                                                       // columns >= M are never read unmasked
-                        const int mp = (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2);   // swap 4-token groups 1 <-> 2
+                    u32x2 o2[WIDE ? 2 : 1];
+                    int mm[WIDE ? 2 : 1];
+#pragma unroll
+                    for (int t = 0; t < (WIDE ? 2 : 1); ++t) {
+                        const int ii = ii0 + t, i = i0 + ii;
+                        mm[t] = mb + i * RBLK + q * 8 + hg * 4;                                   // multiple of 4
                         float v0, v1, v2, v3;
                         if (HAS_LN) {
                             const float4 a4 = ra[ii * QN + q], b4 = rb[ii * QN + q];
@@ -245,8 +288,24 @@ VR_DEV void gemm_epilogue_vt_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], i
                             v0 = acc[i][j][4 * q + 0] + bj[j]; v1 = acc[i][j][4 * q + 1] + bj[j];
                             v2 = acc[i][j][4 * q + 2] + bj[j]; v3 = acc[i][j][4 * q + 3] + bj[j];
                         }
-                        u32x2 v = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
-                        store_b64(colp + mp, v);
+                        o2[t] = u32x2{pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                    }
+                    auto perm16 = [](int m) { return (m & ~15) | ((((m >> 2) & 1) << 1 | ((m >> 3) & 1)) << 2); };   // swap 4-token groups 1 <-> 2
+                    if (WIDE && wide) {
+                        // swap(vdst = block i word, src = block i + 1 word): lanes 32-63 of vdst <-> lanes 0-31 of src
+                        const auto w0 = __builtin_amdgcn_permlane32_swap(o2[0][0], o2[WIDE ? 1 : 0][0], false, false);
+                        const auto w1 = __builtin_amdgcn_permlane32_swap(o2[0][1], o2[WIDE ? 1 : 0][1], false, false);
+                        const int m = (hg & 2) ? mm[WIDE ? 1 : 0] - 8 : mm[0];                    // first token group of this lane's 8-token chunk
+                        if (m + 8 < p.M) {                                                       // both token groups of the chunk exist
+                            const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
+                            store_b128(colp + perm16(m), __builtin_bit_cast(f32x4, q4));
+                        } else if (m < p.M) {                                                    // last block of the token axis: token groups >= M
+                            store_b64(colp + perm16(m), u32x2{(unsigned)w0[0], (unsigned)w1[0]});   // are never written (as before)
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < (WIDE ? 2 : 1); ++t)
+                            if (mm[t] < p.M) store_b64(colp + perm16(mm[t]), o2[t]);
                     }
                 }
         }
