@@ -53,6 +53,12 @@
 #define TSTAMP(i) do { } while (0)
 #endif
 
+// 1: two of a wave's four LDS-DMA loads per K-tile go out in L0, two in L1; 0: all four in L1 (round 1).  The texture-addresser queue takes
+// ~180 cycles per piece when 16 pieces arrive in one interval (tools/gemm_timing.py: L1 = 967 cycles with its four pieces, 236 without).
+#ifndef VISREP_V2_DMA_SPLIT
+#define VISREP_V2_DMA_SPLIT 1
+#endif
+
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 32;
@@ -212,6 +218,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
             //                  under the LDS read latency; everything is retired before the barrier
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(1);   // the load segment gets the issue priority (measured +20 % vs prio on the MFMA segment)
             if (!(DBG & 4)) lds_issue8(wf, xf, sb + woff, sb + xoff);
+#if VISREP_V2_DMA_SPLIT
+            if (!(DBG & 2)) { if (G == 0) issue_w(); else issue_x(); }   // first LDS-DMA pair of this K-tile's four: see L1
+#endif
             lds_wait8(wf, xf);
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(0);
             TSTAMP(0);
@@ -235,7 +244,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
             // ---------------- L1: X fragments of rows 64..127 + this wave's other two LDS-DMA loads
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(1);
             if (!(DBG & 4)) lds_issue4(xf, sb + xoff + 4096);
+#if VISREP_V2_DMA_SPLIT
+            if (!(DBG & 2)) { if (G == 0) issue_x(); else issue_w(); }   // second pair (same piece ORDER as before, so the vmcnt ledger holds)
+#else
             if (!(DBG & 2)) { if (G == 0) { issue_w(); issue_x(); } else { issue_x(); issue_w(); } }   // all four LDS-DMA loads ride in the short segment
+#endif
             if (G == 1) wait_g1();
             lds_wait4(xf);
             if (!(DBG & 24)) __builtin_amdgcn_s_setprio(0);
