@@ -192,17 +192,29 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
     // ---- normalise and store: lane holds O[q][d = dt*32 + 8*rg + 4*hi + (0..3)]
     l_run += __shfl_xor(l_run, 32);
     const float inv = 1.f / l_run;
-    if (qloc < p.Tq) {
-        bf16_t* orow = p.out + ((size_t)b * p.Tq + qloc) * p.ldo + h * D;
+    // Two 8-column groups (rg, rg + 1) are regrouped with one v_permlane32_swap per word: lanes l and l + 32 hold the two halves of
+    // every 8-column group, so after the swap the lower half-wave owns the 8 columns of group rg and the upper one those of rg + 1 ->
+    // 16-byte stores, half as many (the store tail is issue-bound; all lanes take part in the swaps, only valid rows store).
+    bf16_t* orow = p.out + ((size_t)b * p.Tq + (qloc < p.Tq ? qloc : p.Tq - 1)) * p.ldo + h * D;
+    const bool wide = (p.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;          // uniform
 #pragma unroll
-        for (int dt = 0; dt < 2 * ND; ++dt)
+    for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                u32x2 v = {pack_bf16(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv),
-                           pack_bf16(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv)};
-                *reinterpret_cast<u32x2*>(orow + dt * 32 + rg * 8 + hi * 4) = v;
+        for (int rg = 0; rg < 4; rg += 2) {
+            u32x2 a = {pack_bf16(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv), pack_bf16(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv)};
+            u32x2 c = {pack_bf16(o[dt][4 * rg + 4] * inv, o[dt][4 * rg + 5] * inv), pack_bf16(o[dt][4 * rg + 6] * inv, o[dt][4 * rg + 7] * inv)};
+            if (wide) {
+                const auto w0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                if (qloc < p.Tq) {
+                    const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
+                    *reinterpret_cast<u32x4*>(orow + dt * 32 + (rg + hi) * 8) = q4;
+                }
+            } else if (qloc < p.Tq) {
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + rg * 8 + hi * 4) = a;
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + (rg + 1) * 8 + hi * 4) = c;
             }
-    }
+        }
 }
 
 }  // namespace
