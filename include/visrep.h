@@ -40,7 +40,9 @@ size_t visrep_last_error(char* buf, size_t n);
 
 /* Tuning knob (process-global, for A/B measurements): selects the GEMM kernel family used by every entry point below.
  * 1 = 128x128 tiles / one barrier per K-tile; 2 = 256x256 persistent ping-pong kernel (16x16x32 MFMA, 4 barriers per K-tile);
- * 3 = same with 32x32x16 MFMA and 2 barriers per K-tile.  2 and 3 fall back to 1 when N % 256 != 0.
+ * 3 = same with 32x32x16 MFMA and 2 barriers per K-tile; 4 = experimental 4-wave 256x256 kernel, one 128x128 quadrant per wave with
+ * AGPR accumulators and one barrier per K-tile (measured slower than 2: profiles/round2_gemm_v4.md).  2-4 fall back to 1 when
+ * N % 256 != 0.
  * Returns the previous value.  Results are identical up to fp32 summation order. */
 int visrep_set_gemm_variant(int variant);
 /* Timing-only ablation of GEMM variant 2 (bit 0: skip MFMAs, bit 1: skip the LDS-DMA loads, bit 2: skip the fragment reads):
