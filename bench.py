@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
     ap.add_argument("--sweep", default="reduced", choices=["off", "reduced", "full"])
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2, 3])
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2, 3, 4])
     args = ap.parse_args()
 
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # host-side weight packing: torch's default (128 here) thrashes, see cpu_baseline
@@ -222,7 +222,7 @@ def main():
                 head = {"rows": m1, "ms": round(hs * 1e3, 4), "tflops": round(2.0 * m1 * m * d / hs / 1e12, 1)}
         except Exception as e:                                          # never let the extra line take the bench down
             head = {"error": str(e)[:200]}
-        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p", 4: "gemm_bf16_v4"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
                 "traffic": FC1_HBM_BYTES_PER_LAUNCH.get((args.gemm_variant, B)), "traffic_unit": "HBM bytes per launch (PMC, profiles/round1_traffic.md)",
                 "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),
@@ -235,7 +235,7 @@ def main():
 
     # ---- CPU baseline: the oracle on a bounded sample, host cores of this box (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_images > 0:
         from oracle import vit as OV
         n = args.cpu_images
         sample = px[:n].float().cpu()
