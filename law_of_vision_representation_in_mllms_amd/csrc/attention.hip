@@ -71,23 +71,34 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
     const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
     const int m_begin = tok0 & ~63;
     const int ntile = (((tok1 + 63) & ~63) - m_begin) >> 6;
-    const bf16_t* kbase = p.k + h * D + lslot * 8;
-    const bf16_t* vbase = p.vt + (size_t)(h * D + srow) * p.ldvt + lslot * 8;
-    auto stage = [&](int buf, int it) {
+    // Running source pointers of this thread's chunks (tile `it` is staged right after tile it - 1, so they only ever advance by one
+    // tile: 64 key rows of K, 64 key columns of V^T); only a tile that reaches past the last key row of the buffer re-derives clamped rows.
+    const bf16_t* kcur = p.k + h * D + lslot * 8 + (size_t)(m_begin + srow) * p.ldk;
+    const bf16_t* vcur = p.vt + (size_t)(h * D + srow) * p.ldvt + lslot * 8 + m_begin;
+    const size_t kstep = (size_t)KT * p.ldk, khalf = (size_t)32 * p.ldk, vhalf = (size_t)32 * p.ldvt;
+    int mt_stage = m_begin;
+    auto stage = [&](int buf) {
         char* sk = smem + buf * STAGE_B + wave * 1024;
         char* sv = sk + KV_B;
-        const int mt = m_begin + it * KT;
+        if (mt_stage + KT <= p.Mk) {                        // uniform
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int mk = mt + j * 32 + srow;
-            mk = mk < p.Mk ? mk : p.Mk - 1;                 // rows past the last token are masked below
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) glds16(kbase + (size_t)mk * p.ldk + nd * 64, sk + nd * TILE_B + j * 4096);
+                for (int nd = 0; nd < ND; ++nd) glds16(kcur + j * khalf + nd * 64, sk + nd * TILE_B + j * 4096);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int mk = mt_stage + j * 32 + srow;    // rows past the last token are masked below: re-read the last row
+                const bf16_t* kr = mk < p.Mk ? kcur + j * khalf : kcur - (size_t)(mt_stage + srow - (p.Mk - 1)) * p.ldk;
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) glds16(kr + nd * 64, sk + nd * TILE_B + j * 4096);
+            }
         }
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(vbase + (size_t)(nd * 64 + j * 32) * p.ldvt + mt, sv + nd * TILE_B + j * 4096);
+            for (int j = 0; j < 2; ++j) glds16(vcur + nd * 2 * vhalf + j * vhalf, sv + nd * TILE_B + j * 4096);
+        kcur += kstep; vcur += KT; mt_stage += KT;
     };
 
     // fragment read offsets inside a tile: row = 32*blk + lq, logical slot s -> physical s ^ ((lq>>1)&7)
@@ -99,20 +110,20 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
     for (int dt = 0; dt < 2 * ND; ++dt) o[dt] = f32x16{};
     float m_run = -INFINITY, l_run = 0.f;
 
-    stage(0, 0);
+    stage(0);
     __syncthreads();
     if (qt * 128 + wave * 32 >= p.Tq) {
         // this wave's 32 query rows are all past the sequence (the last query tile of T = 577 has 65 rows: wave 3 is empty):
         // it only keeps staging its quarter of the K / V^T tiles and meeting the barriers, and leaves its SIMD to other blocks
         for (int it = 0; it < ntile; ++it) {
-            if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage((it & 1) ^ 1, it + 1);
+            if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage((it & 1) ^ 1);
             if (!(VISREP_ATTN_ABLATE & 16)) __syncthreads();
         }
         return;
     }
     for (int it = 0; it < ntile; ++it) {
         const int cur = it & 1;
-        if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage(cur ^ 1, it + 1);
+        if (!(VISREP_ATTN_ABLATE & 16) && it + 1 < ntile) stage(cur ^ 1);
         const char* sk = smem + ((VISREP_ATTN_ABLATE & 16) ? 0 : cur) * STAGE_B;
         const char* sv = sk + KV_B;
 
@@ -141,10 +152,18 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
                     if (key < tok0 || key >= tok1 || (p.causal && key - tok0 > qloc)) s[kt2][r] = -INFINITY;
                 }
         }
-        float mloc = fmaxf(s[0][0], s[1][0]);
+        float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]), mloc1 = fmaxf(fmaxf(s[1][0], s[1][1]), s[1][2]);   // two independent
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[0][r]), s[1][r]);     // v_max3_f32
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        for (int r = 3; r < 15; r += 2) {                                                                         // v_max3_f32 chains
+            mloc = fmaxf(fmaxf(mloc, s[0][r]), s[0][r + 1]);
+            mloc1 = fmaxf(fmaxf(mloc1, s[1][r]), s[1][r + 1]);
+        }
+        mloc = fmaxf(fmaxf(mloc, s[0][15]), fmaxf(mloc1, s[1][15]));
+        {   // the other half of this query's keys lives in lane ^ 32: one lane-swap VALU op (no LDS round trip)
+            const unsigned u = __builtin_bit_cast(unsigned, mloc);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+        }
         const float m_new = fmaxf(m_run, mloc);             // finite: every image's first tile holds >= 1 valid key
         const float msc = m_new * p.sc;
         float psum = 0.f;
