@@ -318,6 +318,38 @@ def test_sd15_full_width_parity_and_tower_api(monkeypatch):
     assert tower(img[0]).shape == (1, 16, 1280)
 
 
+def test_sdxl_full_width_parity(monkeypatch):
+    """The real SDXL-base UNet (320/640/1280, attention-free first block, 2 / 10 transformer layers per attention, Linear proj_in /
+    proj_out, 64-wide heads, 2048-wide two-encoder prompt) on a small image against the fp32 CPU oracle.  2.4 B parameters: the
+    deterministic weights are drawn on the device (VISREP_FAST_SYNTHETIC) and the same tensors feed the engine and the oracle."""
+    from types import SimpleNamespace
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import builder as B
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("VISREP_FAST_SYNTHETIC", "cuda")
+    args = SimpleNamespace(vision_tower='stabilityai/stable-diffusion-xl-base-1.0', up_ft_index=0, t=261, prompt="a photo of a cat",
+                           ensemble_size=1, img_size=128)
+    tower = B.build_diffusion_vision_tower(args)
+    assert tower.is_loaded and tower.hidden_size == 1280
+    feat = tower.vision_tower
+    sp = feat.spec
+    assert sp.unet.tlayers == (1, 2, 10) and sp.unet.linear_projection
+    rs = np.random.RandomState(6)
+    img = torch.from_numpy(rs.uniform(-1, 1, (1, 3, 128, 128)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((1, 4, 16, 16)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((1, 4, 16, 16)).astype(np.float32))
+    pe = feat.encode_prompt(args.prompt)
+    assert pe.shape == (1, 77, 2048)                                     # hidden_states[-2] of both text encoders, concatenated
+    got = feat.forward(img, args.prompt, t=261, up_ft_index=0, ensemble_size=1, post_noise=post, ddim_noise=ddim)     # [c, h, w]
+    assert got.shape == (1280, 8, 8)
+    wu = {k: v.float().cpu() for k, v in feat._wu.items() if not k.startswith(("up_blocks.1", "up_blocks.2"))}
+    wv = {k: v.float().cpu() for k, v in feat._wv.items()}
+    want = OD.sd_features(sp, wu, wv, img, pe.float().cpu(), post, ddim, t=261)                                       # [1, 64, 1280]
+    ref_bf16 = OD.sd_features(sp, wu, wv, img, pe.float().cpu(), post, ddim, t=261, dtype=torch.bfloat16)
+    got_tok = got.permute(1, 2, 0).reshape(1, 64, 1280)
+    e_hip, e_ref = rel_err(got_tok, want), rel_err(ref_bf16, want)
+    assert e_hip < max(2.0 * e_ref, 3e-2), (e_hip, e_ref)
+
+
 # ------------------------------------------------------------------------------------------------ DiT tower
 @pytest.mark.parametrize("tag", ["last", "first_other_res"])
 def test_dit_tower_matches_reference_golden(tag):
