@@ -266,9 +266,35 @@ def main():
                "sample": f"{n} of the same 336x336 images, fp32, oracle/vit.py (torch CPU), 23 layers; thread count = fastest of 16/32/64 on one image",
                "gpu_vs_cpu_rel_l2": round(rel, 5)}
 
-    # ---- the 13-setting A + C sweep (all ranks take part; images sharded rank::world)
+    def emit(sweep):
+        if rank == 0:
+            line = {
+                "metric": "images/sec ViT-L/14@336 feature-extract", "value": round(value, 2), "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "CLIP ViT-L/14-336 vision_tower feature-extract (hidden_states[-2], 23 layers run), "
+                                       f"batch {B} per GPU, random-init weights, N(0,1) pixels resident in HBM",
+                           "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)", "gemm_variant": args.gemm_variant},
+                "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
+            }
+            print(json.dumps(line), flush=True)
+
+    # ---- the 13-setting A + C sweep (all ranks take part; images sharded rank::world).  It is an extra on the headline line and has the
+    # path's only collectives: a rank that fails alone would leave the others waiting in an all-gather, so a watchdog bounds it - on
+    # expiry rank 0 prints the line it already has (sweep = the timeout) and every rank leaves without the final barrier.
     sweep = None
     if args.sweep != "off":
+        import threading
+        limit = float(os.environ.get("VISREP_SWEEP_LIMIT_S", "600" if args.sweep == "reduced" else "3600"))
+
+        def bail():
+            emit({"error": f"sweep did not finish within {limit:.0f} s", "size": args.sweep})
+            sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(limit, bail)
+        dog.daemon = True
+        dog.start()
         try:
             del eng, px, out, feats
             torch.cuda.empty_cache()
@@ -278,18 +304,14 @@ def main():
             sweep["size"] = args.sweep
         except Exception as e:                                           # the headline line must survive a sweep failure
             sweep = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if dist is not None:                                         # the other ranks may be inside a collective: do not join them
+                dog.cancel()
+                emit(sweep)
+                sys.stdout.flush()
+                os._exit(0)
+        dog.cancel()
 
-    if rank == 0:
-        line = {
-            "metric": "images/sec ViT-L/14@336 feature-extract", "value": round(value, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "CLIP ViT-L/14-336 vision_tower feature-extract (hidden_states[-2], 23 layers run), "
-                                   f"batch {B} per GPU, random-init weights, N(0,1) pixels resident in HBM",
-                       "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)", "gemm_variant": args.gemm_variant},
-            "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
-        }
-        print(json.dumps(line), flush=True)
+    emit(sweep)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
