@@ -48,18 +48,19 @@ class Setting:
     batch: int                # images per tower launch
 
 
-# order of policy/fit.py:20; the two CLIP stacks come first there too, which is what the A score needs (its references)
+# order of policy/fit.py:20; the two CLIP stacks come first there too, which is what the A score needs (its references).  Diffusion towers run
+# 16 images per launch: SD1.5 at 768 px does 160 / 173 / 180 images/s at batch 4 / 8 / 16 (tools/sd_bench.py, 8.3 GiB peak at 16)
 SETTINGS = (
     Setting("CLIP336", "clip336", (CLIP336,), 336, 128),
     Setting("CLIP224", "clip224", (CLIP224,), 224, 256),
     Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 256),
     Setting("DINOv2", "dino", (DINOV2,), 224, 256),
-    Setting("SDim", "imsd", (IMSD,), 768, 4),
-    Setting("SD1.5", "sd1.5", (SD15,), 768, 4),
-    Setting("SDXL", "sdxl", (SDXL,), 512, 4),
-    Setting("DiT", "dit", (DIT,), 512, 8),
-    Setting("SD3", "sd3", (SD3,), 512, 4),
-    Setting("SD2.1", "sd2.1", (SD21,), 768, 4),
+    Setting("SDim", "imsd", (IMSD,), 768, 16),
+    Setting("SD1.5", "sd1.5", (SD15,), 768, 16),
+    Setting("SDXL", "sdxl", (SDXL,), 512, 16),
+    Setting("DiT", "dit", (DIT,), 512, 16),
+    Setting("SD3", "sd3", (SD3,), 512, 16),
+    Setting("SD2.1", "sd2.1", (SD21,), 768, 16),
     Setting("SigLIP", "siglip", (SIGLIP,), 224, 256),
     Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 256),
     Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 128),
