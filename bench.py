@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
     ap.add_argument("--sweep", default="reduced", choices=["off", "reduced", "full"])
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "2")), choices=[1, 2, 3, 4])
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 3, 4, 5])
     args = ap.parse_args()
 
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # host-side weight packing: torch's default (128 here) thrashes, see cpu_baseline
@@ -214,7 +214,7 @@ def main():
             ntn, ntm = m // 256, (M + 255) // 256
             rounds = (ntm * ntn) // ncu
             m1 = rounds * ncu // ntn * 256
-            if eng.fuse_ln and args.gemm_variant == 2 and rounds >= 1 and (rounds * ncu) % ntn == 0 and 0 < m1 <= M:
+            if eng.fuse_ln and args.gemm_variant in (2, 5) and rounds >= 1 and (rounds * ncu) % ntn == 0 and 0 < m1 <= M:
                 def fc1_head():
                     _lib.check(lib.visrep_gemm_bf16_ln(_lib.ptr(x), d, _lib.ptr(w1), d, _lib.ptr(b1), _lib.ptr(rt), _lib.ptr(s1), _lib.ptr(o1), m, m1, m, d,
                                                        _lib.EPI_ACT, _lib.ACT["quick_gelu"], sp()), "gemm_ln")
@@ -222,7 +222,7 @@ def main():
                 head = {"rows": m1, "ms": round(hs * 1e3, 4), "tflops": round(2.0 * m1 * m * d / hs / 1e12, 1)}
         except Exception as e:                                          # never let the extra line take the bench down
             head = {"error": str(e)[:200]}
-        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p", 4: "gemm_bf16_v4"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p", 4: "gemm_bf16_v4", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
                 "traffic": FC1_HBM_BYTES_PER_LAUNCH.get((args.gemm_variant, B)), "traffic_unit": "HBM bytes per launch (PMC, profiles/round2_final_kernel_stats.md)",
                 "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),

@@ -40,9 +40,9 @@ size_t visrep_last_error(char* buf, size_t n);
 
 /* Tuning knob (process-global, for A/B measurements): selects the GEMM kernel family used by every entry point below.
  * 1 = 128x128 tiles / one barrier per K-tile; 2 = 256x256 persistent ping-pong kernel (16x16x32 MFMA, 4 barriers per K-tile);
- * 3 = same with 32x32x16 MFMA and 2 barriers per K-tile; 4 = experimental 4-wave 256x256 kernel, one 128x128 quadrant per wave with
- * AGPR accumulators and one barrier per K-tile (measured slower than 2: profiles/round2_gemm_v4.md).  2-4 fall back to 1 when
- * N % 256 != 0.
+ * 3 = 128-byte LDS rows (BK = 64), 32x32x16 MFMA, 2 barriers per 32-deep k-step; 4 = experimental 4-wave 256x256 kernel, one 128x128
+ * quadrant per wave with AGPR accumulators (profiles/round2_gemm_v4.md); 5 (default) = 3's data path with 2's 16x16x32 MFMAs and epilogues
+ * (profiles/round2_gemm_v5.md).  2-5 need N % 256 == 0 (3, 5: K % 64 == 0, else 2 runs); everything else runs 1.
  * Returns the previous value.  Results are identical up to fp32 summation order. */
 int visrep_set_gemm_variant(int variant);
 /* Timing-only ablation of GEMM variant 2 (bit 0: skip MFMAs, bit 1: skip the LDS-DMA loads, bit 2: skip the fragment reads):

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
 
 }  // namespace
 
-int g_visrep_gemm_variant = 2;
+int g_visrep_gemm_variant = 5;
 // split-K scratch, one registration PER DEVICE (a process that drives several GPUs registers one buffer on each; a GEMM only ever
 // uses the buffer of the device it is launched on).  One stream per device at a time may run split-K GEMMs: the planes are not keyed
 // by stream (documented in include/visrep.h).
@@ -238,6 +238,11 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
         return visrep_set_error(VISREP_ERR_ARG, "conv3x3: epilogue must be BIAS, RESID or F32");
     }
     if (variant == 4 && visrep_gemm_v4_supports(a)) return visrep_gemm_v4_dispatch(a, s);
+    if (variant == 5 && visrep_gemm_v5_supports(a)) {
+        GemmArgs b = a;
+        b.dbg = g_visrep_gemm_dbg;
+        return visrep_gemm_v5_dispatch(b, s);
+    }
     if (variant == 3 && visrep_gemm_v3_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
@@ -314,7 +319,7 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
 namespace {
 // the statistics-emitting epilogue exists in the 256x256 v2 kernel only
 bool v2_emits_stats(const GemmArgs& a, int variant) {
-    return a.stat_rt && a.stat_partial && a.epi == EPI_RESID && !a.conv && variant == 2 && visrep_gemm_v2_supports(a) && a.N % 128 == 0;
+    return a.stat_rt && a.stat_partial && a.epi == EPI_RESID && !a.conv && (variant == 2 || variant == 5) && visrep_gemm_v2_supports(a) && a.N % 128 == 0;   // v5 falls back to v2 when K % 64 != 0: both emit
 }
 // rows [0, a.M) of a finished residual GEMM -> a.stat_rt: from the epilogue's partial sums, else by reading the rows back
 int finish_stats(const GemmArgs& a, bool from_partials, hipStream_t s) {

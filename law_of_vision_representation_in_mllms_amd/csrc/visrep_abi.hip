@@ -15,7 +15,7 @@ int visrep_set_error(int code, const char* msg) {
 extern "C" int visrep_version(void) { return VISREP_VERSION; }
 
 extern "C" int visrep_set_gemm_variant(int variant) {
-    if (variant < 1 || variant > 4) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1 .. 4");
+    if (variant < 1 || variant > 5) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1 .. 5");
     const int old = g_visrep_gemm_variant;
     g_visrep_gemm_variant = variant;
     return old;

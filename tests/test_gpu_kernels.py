@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(params=[1, 2, 3, 4], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v3_256", "gemm_v4_256q"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v3_256", "gemm_v4_256q", "gemm_v5_256k64"])
 def gemm_variant(request):
     """Run a test under both GEMM kernel families (v2 falls back to v1 when N % 256 != 0)."""
     lib = _lib.load()
