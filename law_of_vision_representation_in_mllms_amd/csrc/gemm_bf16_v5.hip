@@ -52,6 +52,14 @@
 #define DBG 0
 #endif
 
+// A/B knobs (tools/): LDS-DMA quad before or after the fragment reads of a load segment; s_setprio(1) on the load segments
+#ifndef V5_DMA_FIRST
+#define V5_DMA_FIRST 0
+#endif
+#ifndef V5_PRIO
+#define V5_PRIO 1
+#endif
+
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 64;
@@ -88,12 +96,23 @@ VR_DEV void barrier() {
 }
 
 struct TileWalk {           // the block's list of output tiles: chunk of its XCD, strided by the blocks of that XCD
-    int start, stride, count, ntn;
+    int start, stride, count, ntn, ntm;
+    // Tile order as in v2: the ~32 blocks of an XCD work on ~32 consecutive tile indices and share that XCD's 4-MB L2; for more than 8
+    // column panels (fc1: 16) the indices walk 4 x 8 blocks of tiles, so a window touches 4 + 8 operand panels instead of 2 + 16.
     VR_DEV void decode(int i, int& m0, int& n0) const {
         const int ii = i < count ? i : count - 1;        // past-the-end loads re-read the last tile (never consumed)
         const int t = start + ii * stride;
-        m0 = (t / ntn) * TM;
-        n0 = (t % ntn) * TN;
+        if (ntn > 8 && (ntn & 7) == 0) {
+            const int R = 4, c = 8;
+            const int sr = t / (R * ntn), u = t - sr * R * ntn;
+            const int rl = min(R, ntm - sr * R);          // the last super-row may be shorter
+            const int cg = u / (rl * c), v = u - cg * rl * c;
+            m0 = (sr * R + v / c) * TM;
+            n0 = (cg * c + v % c) * TN;
+        } else {
+            m0 = (t / ntn) * TM;
+            n0 = (t % ntn) * TN;
+        }
     }
 };
 
@@ -117,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         tw.stride = per;
         tw.count = j < csize ? (csize - j + per - 1) / per : 0;
         tw.ntn = ntn;
+        tw.ntm = ntm;
     }
     if (tw.count == 0) return;                                 // uniform per block: no barrier has been executed yet
     const int nk = p.K / TK;
@@ -187,12 +207,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
             for (int h = 0; h < 2; ++h) {
                 // ---------------- L(h): 12 fragment reads of k-half h + four LDS-DMA loads (L0: W of tile s+1, L1: X of tile s+2)
                 const unsigned xa = (sx + xbase) ^ (h << 6), wa = (sw + wbase) ^ (h << 6);
-                __builtin_amdgcn_s_setprio(1);                 // the load segment gets the issue priority
+                if (V5_PRIO) __builtin_amdgcn_s_setprio(1);    // the load segment gets the issue priority
+                if (V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) issue_w(); else issue_x(); }
                 if (!(DBG & 4)) lds_issue12(xf, wf, xa, wa);
-                if (!(DBG & 2)) { if (h == 0) issue_w(); else issue_x(); }
+                if (!V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) issue_w(); else issue_x(); }
                 if (h == 1 && G == 1) wait_vm4();
                 lds_wait12(xf, wf);
-                __builtin_amdgcn_s_setprio(0);
+                if (V5_PRIO) __builtin_amdgcn_s_setprio(0);
                 barrier();
                 // ---------------- M(h): 32 MFMAs 16x16x32, nothing else
                 if (!(DBG & 1))
