@@ -40,9 +40,9 @@ BATCH = 256
 N_LAYERS = 23                     # select_layer = -2: the 24th layer is never needed
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # HBM bytes per fc1 launch at batch 256 with the default (v2) GEMM, from rocprofv3 PMC passes of this kernel at this shape
-# (profiles/round2_final_kernel_stats.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
+# (profiles/round2_final_kernel_stats.md, v2: round2_v2default_kernel_stats.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md "HBM"; round 1 calibrated both on layernorm_rows' known byte count).  Algorithmic bytes are 1.52e9.
-FC1_HBM_BYTES_PER_LAUNCH = {(2, 256): 3.055e9}
+FC1_HBM_BYTES_PER_LAUNCH = {(5, 256): 2.969e9, (2, 256): 3.055e9}
 
 
 def flops_per_image(spec, n_layers):
