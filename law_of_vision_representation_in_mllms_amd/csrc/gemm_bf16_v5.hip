@@ -59,6 +59,15 @@
 #ifndef V5_PRIO
 #define V5_PRIO 1
 #endif
+// 1: group 0 (waves 0-3) stages ALL of W (64 rows = 8 pieces per wave and K-tile) and the upper half of X; group 1 stages only the lower half of
+//    X - the half nobody but group 1 reads.  Group 1's counted wait then moves from the end of its load segment L1 (where it stalled a
+//    segment the other group's MFMAs were waiting behind) to the end of its M1, under its own MFMAs, like group 0's.
+// 0: every wave stages 32 rows of both operands (v3's scheme).
+// Measured (same process, rows = 147,456): N >= 2048 gains (fc1 1.122 -> 1.103 ms, Q|K 0.544 -> 0.531), N = 1024 loses (fc2 0.938 -> 0.970, out 0.328 -> 0.337,
+// V^T 0.269 -> 0.280): the kernel is compiled both ways and the launcher picks by N.  -DV5_OWN=0 / =1 forces one scheme (A/B builds).
+#ifndef V5_OWN
+#define V5_OWN OWN_
+#endif
 
 namespace {
 
@@ -116,7 +125,7 @@ struct TileWalk {           // the block's list of output tiles: chunk of its XC
     }
 };
 
-template <int EPI>
+template <int EPI, bool OWN_>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,6 +166,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     };
     auto set_w = [&](Cur& c) {
         int m0, n0; tw.decode(c.ti, m0, n0);
+        if (V5_OWN) {   // wave w < 4 covers W rows [64w, 64w+64): piece j = row 8j + lane>>3; the swizzle term only depends on j & 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                c.p[j] = p.W + (size_t)(n0 + wn * 64 + j * 8 + (lane >> 3)) * p.ldw + (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 3);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             c.p[j] = p.W + (size_t)(n0 + wave * 32 + j * 8 + (lane >> 3)) * p.ldw + (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 3);
@@ -171,9 +186,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         if (cx.k == p.K) { cx.k = 0; ++cx.ti; set_x(cx); }
     };
     auto issue_w = [&]() {
-        char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wave * 4096;
+        if (V5_OWN) {                                         // group 0 only: eight pieces, rows 64 wn + 8 j + lane>>3
+            char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wn * 8192;
+            const size_t step = (size_t)16 * p.ldw;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(cw.p[j] + cw.k, dst + j * 1024);
+            for (int j = 0; j < 8; ++j) glds16(cw.p[j & 1] + (j >> 1) * step + cw.k, dst + j * 1024);
+        } else {
+            char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wave * 4096;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(cw.p[j] + cw.k, dst + j * 1024);
+        }
         ++cw.idx; cw.k += TK;
         if (cw.k == p.K) { cw.k = 0; ++cw.ti; set_w(cw); }
     };
@@ -186,7 +208,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     const int wbase = wn * 64 * 128 + fbase;                   // + slot base + nj*2048 (immediate)
 
     // ---- prologue: X0, W0 landed and visible, X1 in flight
-    issue_x(); issue_w(); issue_x();
+    issue_x();
+    if (!V5_OWN || grp == 0) issue_w();
+    issue_x();
     wait_vm4();
     barrier();
 
@@ -208,10 +232,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 // ---------------- L(h): 12 fragment reads of k-half h + four LDS-DMA loads (L0: W of tile s+1, L1: X of tile s+2)
                 const unsigned xa = (sx + xbase) ^ (h << 6), wa = (sw + wbase) ^ (h << 6);
                 if (V5_PRIO) __builtin_amdgcn_s_setprio(1);    // the load segment gets the issue priority
-                if (V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) issue_w(); else issue_x(); }
+                if (V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) { if (!V5_OWN || G == 0) issue_w(); } else issue_x(); }
                 if (!(DBG & 4)) lds_issue12(xf, wf, xa, wa);
-                if (!V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) issue_w(); else issue_x(); }
-                if (h == 1 && G == 1) wait_vm4();
+                if (!V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) { if (!V5_OWN || G == 0) issue_w(); } else issue_x(); }
+                if (!V5_OWN && h == 1 && G == 1) wait_vm4();
                 lds_wait12(xf, wf);
                 if (V5_PRIO) __builtin_amdgcn_s_setprio(0);
                 barrier();
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                     }
                 if (h == 0) barrier();
             }
-            if (G == 0) wait_vm4();
+            if (G == 0 || V5_OWN) wait_vm4();
             if (++kt == nk) {
                 // ------------------------------------------------ epilogue of output tile ti
                 kt = 0;
@@ -248,12 +272,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     wait_vm0();                                                // drain the (unused) run-ahead loads before exit
 }
 
-template <int EPI>
-int launch5(const GemmArgs& a, hipStream_t s) {
+template <int EPI, bool OWN_>
+int launch5o(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     static int ncu = 256;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256q<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -262,8 +286,13 @@ int launch5(const GemmArgs& a, hipStream_t s) {
     }
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL(gemm_bf16_256q<EPI>, dim3(grid), dim3(512), LDS2, s, a);
+    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_>), dim3(grid), dim3(512), LDS2, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+}
+
+template <int EPI>
+int launch5(const GemmArgs& a, hipStream_t s) {
+    return a.N >= 2048 ? launch5o<EPI, true>(a, s) : launch5o<EPI, false>(a, s);     // operand ownership pays for wide outputs only (see V5_OWN)
 }
 
 }  // namespace
