@@ -1,44 +1,41 @@
-// bf16 MFMA GEMM v5 for gfx950: v3's data path (128-byte LDS rows, BK = 64, five-slot ring, two barriers per 32-deep k-step instead of
-// four) with v2's arithmetic (v_mfma_f32_16x16x32_bf16, 8 x 4 accumulators per wave, v2's epilogues incl. row statistics and patch embed).
-// Everything below the next line is v3's design text; the differences are: fragments are 16-row blocks (8 X + 4 W reads per k-half,
-// the same twelve ds_read_b128), an M segment is 32 MFMAs of 16 cycles, accumulators and epilogues are the 16x16 layout of v2.
-//
-// bf16 MFMA GEMM v3 for gfx950: persistent ping-pong kernel with 128-byte LDS rows (BK = 64) and 32x32x16 MFMAs.
+// bf16 MFMA GEMM v5 for gfx950 (the default): persistent 256x256 ping-pong kernel, 128-byte LDS rows (BK = 64), 16x16x32 MFMAs.
 //
 //   C[M,N] = epilogue( A[M,K] * W[N,K]^T )          same contract / epilogues as gemm_bf16.hip (v1) and v2
 //
-// What the v2 measurements said (rocprofv3 PMC + the timing ablation of tools/gemm_ablate.py, fc2 shape 147712x1024x4096):
-//   full kernel 1.34 ms | MFMA + barriers only 0.85 ms | LDS-DMA stream + barriers only 0.93 ms | barriers only 0.33 ms
-//   - the LDS-DMA stream alone is as slow as the math: v2's BK = 32 K-tiles make every global_load_lds fetch 64-byte
-//     half lines (TCC requests = bytes / 64), and the L2 serves requests, not bytes: ~10 TB/s at this request size;
-//   - every barrier interval carries ~150 cycles of fixed cost, v2 has one per 16 MFMAs (272 matrix-pipe cycles).
-// v3 keeps what worked (256x256 tile, two groups of four waves skewed by one barrier so that one wave per SIMD is always in
-// an MFMA segment, persistent blocks walking XCD-contiguous tile chunks, counted/explicit waits, hand-written fragment
-// reads, hoisted epilogues) and changes the data path:
-//   * K-tiles of 64 -> LDS rows of 128 B: every LDS-DMA instruction moves eight FULL 128-byte lines (1.5x the DMA rate,
-//     measured below); slot ^= (row>>1)&7 keeps the 32-row fragment ds_read_b128 conflict free (same format as v1 / attention);
-//   * an operand tile (256 rows x 64 k) is 32 KB; the whole 160 KB LDS is a ring of FIVE operand slots walked by the
-//     item sequence X0 W0 X1 W1 X2 ...: while tile s is consumed, W(s+1) and X(s+2) stream in.  Each wave issues four
-//     LDS-DMA loads per load segment (W quad in L0, X quad in L1), so the DMA bursts are balanced against the MFMA
-//     segments and the urgent half (W of the next tile) is issued first; waits are counted, the queue never drains;
-//   * per K-tile and group: L0 | M0 | L1 | M1 with 12 fragment reads per L and 16 v_mfma_f32_32x32x16_bf16 per M
-//     (512 matrix-pipe cycles per barrier interval instead of 272).
+// Lineage.  v2 (256x256 tile, two groups of four waves skewed by one barrier so that one wave per SIMD is always in an MFMA
+// segment, persistent XCD-contiguous tile walk, counted vmcnt waits, hand-written fragment reads) pays twice: its BK = 32 K-tiles
+// make every LDS-DMA instruction fetch 64-byte half lines (the L2 serves requests, not bytes), and it has a barrier pair per 16
+// MFMAs (~110 cycles of fixed cost per barrier interval).  v3 fixed both (BK = 64, five-slot ring, a barrier pair per 512
+// matrix-pipe cycles) but computed with 32x32x16 MFMAs and lost the gain again.  v5 = v3's data path with v2's arithmetic:
+//   * K-tiles of 64 -> LDS rows of 128 B: every LDS-DMA instruction moves eight FULL 128-byte lines; slot ^= (row>>1)&7 keeps the
+//     fragment ds_read_b128 conflict free (same tile format as v1 / attention);
+//   * an operand tile (256 rows x 64 k) is 32 KB; the whole 160 KB LDS is a ring of FIVE operand slots walked by the item
+//     sequence X0 W0 X1 W1 X2 ...: while tile s is consumed, W(s+1) and X(s+2) stream in; waits are counted, the queue never drains;
+//   * per K-tile and group: L0 | M0 | L1 | M1, one k-half (32 k) per L / M pair: an L segment is twelve ds_read_b128 (eight 16-row X
+//     fragments of the group's 128 rows + four W fragments of the wave's 64 columns; 16-row steps leave (row>>1)&7 alone and the
+//     k-half only flips slot bit 2, so every read is base ^ (h << 6) + immediate) plus the segment's LDS-DMA pieces; an M segment is
+//     32 v_mfma_f32_16x16x32_bf16 (512 matrix-pipe cycles) on 8 x 4 accumulators and nothing else;
+//   * epilogues are v2's (gemm_epilogue.h, 16x16 layout): 16-byte stores, LayerNorm fold, row statistics, patch embed.
 //
-// Measured DMA ceilings (tools/probes/dma_probe.hip, L2-resident panels): 64-byte row segments 21 TB/s = 34.5 B/clk/CU,
-// 128-byte rows 31.6 TB/s = 51.5 B/clk/CU; a 256x256 tile needs 32 B/clk/CU at 100 % MFMA utilisation.
+// Who stages what (template flag OWN_, picked by N in the launcher; measurements in profiles/round2_gemm_v5.md):
+//   OWN_ = false (v3's scheme): wave w stages rows [32w, 32w+32) of both operand tiles, four pieces each; both groups issue their
+//     W quad of tile s+1 in L0(s) and their X quad of tile s+2 in L1(s).  Group 0 waits vmcnt(4) at the end of M1(s); group 1, whose
+//     loads group 0 needs one barrier later, has to wait at the end of its L1(s) - inside a segment the other group's MFMAs wait behind.
+//   OWN_ = true: group 0 stages ALL of W (wave wn: rows [64wn, 64wn+64), eight pieces in L0(s)) and its own upper half of X (four
+//     pieces in L1(s)); group 1 stages only the lower half of X, which nobody but group 1 reads.  Both groups then wait vmcnt(4) at
+//     the end of M1(s), under their own MFMAs.  Pays for wide outputs (fc1 +1.7 %, Q|K +2.4 %), costs 3 % at N = 1024 (8 pieces in one
+//     load segment).
 //
-// Barrier / hazard ledger (s = stream index of a K-tile; item X(s) -> slot (2s) % 5, W(s) -> slot (2s+1) % 5;
-// "instance" = global s_barrier count):
+// Barrier / hazard ledger (s = stream index of a K-tile; item X(s) -> slot (2s) % 5, W(s) -> slot (2s+1) % 5; "instance" = global
+// s_barrier count; prologue: X0, W0, X1):
 //   group 0:  L0(s) | b 4s+1 | M0(s) | b 4s+2 | L1(s) | b 4s+3 | M1(s) | b 4s+4
 //   group 1:  (extra barrier = instance 1)  L0(s) | b 4s+2 | M0(s) | b 4s+3 | L1(s) | b 4s+4 | M1(s) | b 4s+5
-//   issue:    both groups issue their W quad of tile s+1 in L0(s) and their X quad of tile s+2 in L1(s)
-//             (prologue: X0, W0, X1).
-//   WAR:      W(s+1) reuses the slot of X(s-1), X(s+2) the slot of W(s-1); tile s-1 was last read in L1(s-1): group 0's
-//             reads retired before instance 4s-1, group 1's before instance 4s; the earliest overwrite is issued after
-//             instance 4s (group 0's L0(s)).
-//   RAW:      tile s+1 is first read after instance 4s+4.  Group 0 waits vmcnt(4) at the end of M1(s), group 1 at the
-//             end of L1(s): only the X quad of tile s+2 (issued last) may still be in flight, so X(s+1) and W(s+1) have
-//             landed on every wave before anyone passes instance 4s+4.
+//   WAR:  W(s+1) reuses the slot of X(s-1), X(s+2) the slot of W(s-1); tile s-1 was last read in L1(s-1): group 0's reads retired
+//         before instance 4s-1, group 1's before instance 4s; the earliest overwrite is issued after instance 4s (group 0's L0(s)).
+//   RAW:  tile s+1 is first read after instance 4s+4 (group 0) / 4s+5 (group 1).  The counted wait leaves only the X quad of tile
+//         s+2 (issued last) in flight.  OWN_ = false: every wave has confirmed W(s+1) and X(s+1) before instance 4s+4.  OWN_ = true:
+//         group 0 has confirmed W(s+1) and X-upper(s+1) before instance 4s+4; X-lower(s+1) is confirmed by group 1 before instance
+//         4s+5, which is all its only readers (group 1, from L0(s+1) on) need.
 #include <type_traits>
 
 #include "common.h"
