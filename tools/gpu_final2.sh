@@ -1,8 +1,8 @@
 # round-2 end evidence in one gpurun call (every step time-bounded): full GPU suite, smoke(), default bench line, the same bench under
 # torch.distributed.run (world 1: the launch line the driver uses for N > 1), rocprofv3 kernel-trace stats of the bench command, and the
-# PMC passes over the GEMM probe (separate invocations, never combined with tracing).  Outputs under gpurun_out/final3/.
+# PMC passes over the GEMM probe (separate invocations, never combined with tracing).  Outputs under gpurun_out/final4/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/final3
+O=$R/gpurun_out/final4
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout=400 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
