@@ -267,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
                 }
             }
             if (DBG & 16) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);                 // keep the counted wait behind the segment's MFMAs (hipcc hoists it otherwise)
             if (G == 0) wait_g0();
             TSTAMP(6);
             if (++kt == nk) {

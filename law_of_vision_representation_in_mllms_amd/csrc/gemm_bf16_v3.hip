@@ -203,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256p(const GemmArgs p) {
                         }
                 if (h == 0) barrier();
             }
+            __builtin_amdgcn_sched_barrier(0);                 // keep the counted wait behind the segment's MFMAs (hipcc hoists it otherwise)
             if (G == 0) wait_vm4();
             if (++kt == nk) {
                 // ------------------------------------------------ epilogue of output tile ti

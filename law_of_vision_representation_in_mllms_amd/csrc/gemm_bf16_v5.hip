@@ -247,6 +247,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                     }
                 if (h == 0) barrier();
             }
+            // the wait must stay BEHIND the segment's MFMAs (hipcc otherwise hoists it to after the first one: the wave then sits in the wait
+            // with one MFMA in the pipe instead of 32) - a scheduling fence pins it
+            __builtin_amdgcn_sched_barrier(0);
             if (G == 0 || V5_OWN) wait_vm4();
             if (++kt == nk) {
                 // ------------------------------------------------ epilogue of output tile ti
