@@ -37,6 +37,7 @@ SIGNATURES = {
     "visrep_version": (_i, []),
     "visrep_last_error": (_sz, [C.c_char_p, _sz]),
     "visrep_set_gemm_variant": (_i, [_i]),
+    "visrep_set_attn_variant": (_i, [_i]),
     "visrep_debug_gemm_ablation": (_i, [_i]),
     "visrep_debug_gemm_timing_buffer": (_i, [_vp]),
     "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

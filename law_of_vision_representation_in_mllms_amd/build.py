@@ -22,11 +22,14 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "gemm_bf16_v5.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "gemm_bf16_v5.hip", "attention.hip", "attention_ab.hip", "rowops.hip", "convnet.hip", "ascore.hip",
            "cscore.hip", "f32ops.hip", "visrep_abi.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
+# Per-file flags.  attention_ab.hip: -O3's SLP vectoriser packs the softmax's adjacent f32 multiplies / adds into v_pk_*_f32, which
+# cost more than the two plain VALU ops they replace when they sit beside MFMAs (MI355X guide, per-instruction constants).
+FILE_FLAGS = {"attention_ab.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -46,7 +49,7 @@ def _digest(files, extra=()) -> str:
     for f in files:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read() + b"\0")
-    h.update(" ".join(list(CFLAGS) + list(extra)).encode())
+    h.update(" ".join(list(CFLAGS) + list(extra) + [f"{k}:{' '.join(v)}" for k, v in sorted(FILE_FLAGS.items()) if k in files]).encode())
     return h.hexdigest()
 
 
@@ -72,6 +75,7 @@ def _stale(out: str = LIB, defines=()) -> bool:
 def _compile(src: str, objdir: str, defines, verbose: bool) -> str:
     """src -> objdir/src.<hash>.o unless that exact (source, headers, flags) combination was compiled before."""
     path = os.path.join(CSRC, src)
+    defines = list(defines) + FILE_FLAGS.get(src, [])
     key = _digest([src] + HEADERS, defines)[:16]
     obj = os.path.join(objdir, f"{src}.{key}.o")
     if os.path.exists(obj):

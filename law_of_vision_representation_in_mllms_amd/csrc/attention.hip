@@ -238,6 +238,15 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 
 }  // namespace
 
+int g_visrep_attn_variant = 2;   // 1 = attn_fwd<ND> for every head width; 2 = attn_fwd_ab (attention_ab.hip) for head width 64
+
+extern "C" int visrep_set_attn_variant(int variant) {
+    if (variant != 1 && variant != 2) return visrep_set_error(VISREP_ERR_SHAPE, "attention variant must be 1 or 2");
+    const int old = g_visrep_attn_variant;
+    g_visrep_attn_variant = variant;
+    return old;
+}
+
 extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
                                     int B, int Tq, int Tk, int H, int head_dim, int kv_shared, int causal, float scale, void* stream) {
     if (head_dim != 64 && head_dim != 128 && head_dim != 192)
@@ -246,6 +255,8 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     if ((ldq % 8) || (ldk % 8) || (ldvt % 64) || (ldo % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "attention: bad leading dimension");
     const long Mk = kv_shared ? Tk : (long)B * Tk;
     if (ldvt < ((Mk + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "attention: ldvt must cover round_up(key rows, 64)");
+    if (head_dim == 64 && g_visrep_attn_variant == 2)
+        return visrep_attention_ab_launch(q, ldq, k, ldk, vt, ldvt, out, ldo, B, Tq, Tk, H, kv_shared, causal, scale, (hipStream_t)stream);
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.Mk = (int)Mk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.kv_shared = kv_shared; a.causal = causal;

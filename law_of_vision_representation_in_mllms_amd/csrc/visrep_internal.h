@@ -53,6 +53,9 @@ int visrep_gemm_v3_dispatch(const GemmArgs& a, hipStream_t s);
 extern int g_visrep_gemm_dbg;
 extern unsigned long long* g_visrep_gemm_dbg_buf;
 extern int g_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 3 / 5 = 256x256 persistent ping-pong kernels (when N % 256 == 0), 4 = 4-wave stream; default 5
+int visrep_attention_ab_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
+                               int B, int Tq, int Tk, int H, int kv_shared, int causal, float scale, hipStream_t st);
+extern int g_visrep_attn_variant;
 int visrep_set_error(int code, const char* msg);
 constexpr int VISREP_MAX_DEVICES = 16;
 extern void* g_visrep_scratch[VISREP_MAX_DEVICES];       // caller-owned device scratch (visrep_set_scratch), per device: split-K partial sums

@@ -27,6 +27,15 @@ def gemm_variant(request):
     lib.visrep_set_gemm_variant(old)
 
 
+@pytest.fixture(params=[1, 2], ids=["attn_v1", "attn_ab"])
+def attn_variant(request):
+    """Head-width-64 attention under both kernels: the four-wave attn_fwd<1> and the two-blocks-per-wave attn_fwd_ab (default)."""
+    lib = _lib.load()
+    old = lib.visrep_set_attn_variant(request.param)
+    yield request.param
+    lib.visrep_set_attn_variant(old)
+
+
 def bf(x):
     return x.to(torch.bfloat16)
 
@@ -206,8 +215,8 @@ def ref_attention(q, k, v, B, T, H):
     return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * T, H * 64)
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 64, 2), (3, 577, 2), (5, 17, 2), (2, 257, 4), (7, 196, 2)])
-def test_attention_matches_torch(B, T, H, gemm_variant):
+@pytest.mark.parametrize("B,T,H", [(1, 64, 2), (3, 577, 2), (5, 17, 2), (2, 257, 4), (7, 196, 2), (2, 33, 2), (3, 300, 1), (2, 1, 2), (9, 129, 2)])
+def test_attention_matches_torch(B, T, H, gemm_variant, attn_variant):
     g = torch.Generator().manual_seed(B * 1000 + T)
     d = H * 64
     M = B * T
@@ -223,7 +232,7 @@ def test_attention_matches_torch(B, T, H, gemm_variant):
     assert rel_err(out, want) < 1e-2
 
 
-def test_attention_peaked_softmax():
+def test_attention_peaked_softmax(attn_variant):
     # one key dominates each query by a huge margin: exercises the running-max rescale path at every tile
     B, T, H, d = 2, 300, 2, 128
     g = torch.Generator().manual_seed(9)
@@ -239,6 +248,47 @@ def test_attention_peaked_softmax():
     out = engine.mhsa(qk, vt, B, T, H, 0.125)
     want = ref_attention(qk[:, :d], qk[:, d:], v, B, T, H)
     assert max_err(out, want) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,shared,causal", [(2, 77, 77, 2, False, True), (3, 256, 77, 2, True, False), (2, 100, 11, 4, True, False),
+                                                     (2, 130, 130, 2, False, True), (2, 96, 200, 2, False, False), (1, 320, 64, 1, False, False),
+                                                     (4, 65, 513, 2, False, False)])
+def test_attention_head64_cross_and_causal(B, Tq, Tk, H, shared, causal, attn_variant):
+    """visrep_attention_fwd at head width 64: key length of its own, keys shared by the batch (prompt), causal mask (CLIP text)."""
+    from law_of_vision_representation_in_mllms_amd import sd_engine as SE
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    d = H * 64
+    q = bf(torch.randn(B * Tq, d, generator=g)).to(DEV)
+    k = bf(torch.randn((1 if shared else B) * Tk, d, generator=g)).to(DEV)
+    v = bf(torch.randn((1 if shared else B) * Tk, d, generator=g)).to(DEV)
+    vt = engine.linear_vt(v, bf(torch.eye(d)).to(DEV), None)
+    out = SE.attention(q, k, vt, d, B, Tq, Tk, H, 64, 0.125, shared, causal)
+    qf = q.float().cpu().view(B, Tq, H, 64).transpose(1, 2)
+    kf, vf = [(t.float().cpu().view(1, Tk, H, 64).expand(B, -1, -1, -1) if shared else t.float().cpu().view(B, Tk, H, 64)).transpose(1, 2) for t in (k, v)]
+    sc = (qf @ kf.transpose(-1, -2)) * 0.125
+    if causal:
+        sc = sc.masked_fill(torch.ones(Tq, Tk, dtype=torch.bool).triu(1), float("-inf"))
+    want = (torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B * Tq, d)
+    assert max_err(out, want) < 1.5e-2
+    assert rel_err(out, want) < 1e-2
+
+
+def test_attention_variants_agree_at_the_headline_shape_sample():
+    """ViT-L/14-336 geometry (16 heads x 577 tokens), 4 images: the two head-width-64 kernels agree to the bf16 rounding of P."""
+    B, T, H, d = 4, 577, 16, 1024
+    g = torch.Generator().manual_seed(3)
+    qk = bf(torch.randn(B * T, 2 * d, generator=g)).to(DEV)
+    v = bf(torch.randn(B * T, d, generator=g)).to(DEV)
+    vt = engine.linear_vt(v, bf(torch.eye(d)).to(DEV), None)
+    lib = _lib.load()
+    outs = []
+    for variant in (1, 2):
+        old = lib.visrep_set_attn_variant(variant)
+        outs.append(engine.mhsa(qk, vt, B, T, H, 0.125))
+        lib.visrep_set_attn_variant(old)
+    assert rel_err(outs[1], outs[0]) < 6e-3
+    want = ref_attention(qk[:, :d], qk[:, d:], v, B, T, H)
+    assert rel_err(outs[1], want) < 1e-2 and max_err(outs[1], want) < 1.5e-2
 
 
 # ------------------------------------------------------------------------------------------------ towers

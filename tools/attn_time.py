@@ -1,6 +1,8 @@
+"""Attention forward at the headline shape (256 images x 16 heads x 577 tokens, head width 64), both kernels of the loaded library
+(visrep_set_attn_variant 1 / 2).  Other builds: VISREP_LIB=<path to a build.build_variant_lib() library> python tools/attn_time.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from law_of_vision_representation_in_mllms_amd import engine
+from law_of_vision_representation_in_mllms_amd import _lib, engine
 B, T, H, d = 256, 577, 16, 1024
 M = B * T
 torch.manual_seed(0)
@@ -8,12 +10,20 @@ qk = torch.randn(M, 2 * d, device="cuda").to(torch.bfloat16)
 x = torch.randn(M, d, device="cuda").to(torch.bfloat16)
 w = (torch.randn(d, d, device="cuda") * 0.03).to(torch.bfloat16)
 vt = engine.linear_vt(x, w, None)
-for _ in range(10): engine.mhsa(qk, vt, B, T, H, 0.125)
-torch.cuda.synchronize()
-for rep in range(3):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): engine.mhsa(qk, vt, B, T, H, 0.125)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
-    print(f"mhsa {ms:.4f} ms  {4.0 * B * T * T * d / ms / 1e9:.1f} TFLOP/s")
+lib = _lib.load()
+tag = os.path.basename(os.environ.get("VISREP_LIB", "default"))
+ref = None
+for variant in [int(v) for v in os.environ.get("ATTN_VARIANTS", "1,2").split(",")]:
+    lib.visrep_set_attn_variant(variant)
+    for _ in range(10): out = engine.mhsa(qk, vt, B, T, H, 0.125)
+    torch.cuda.synchronize()
+    if ref is None: ref = out.float()
+    err = ((out.float() - ref).norm() / ref.norm()).item()
+    best = 1e9
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): engine.mhsa(qk, vt, B, T, H, 0.125)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20)
+    print(f"{tag} attn variant {variant}: {best:.4f} ms  {4.0 * B * T * T * d / best / 1e9:.1f} TFLOP/s  rel diff to first variant {err:.2e}", flush=True)
