@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
     ap.add_argument("--sweep", default="reduced", choices=["off", "reduced", "full"])
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 3, 4, 5])
+    ap.add_argument("--attn-variant", type=int, default=int(os.environ.get("VISREP_ATTN_VARIANT", "0")), choices=[0, 1, 2])   # 0 = library default
     args = ap.parse_args()
 
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # host-side weight packing: torch's default (128 here) thrashes, see cpu_baseline
@@ -116,6 +117,8 @@ def main():
     from law_of_vision_representation_in_mllms_amd import vit_weights as VW
 
     _lib.load().visrep_set_gemm_variant(args.gemm_variant)
+    if args.attn_variant:
+        _lib.load().visrep_set_attn_variant(args.attn_variant)
     spec = VW.SPECS[MODEL]
     weights = VW.synthetic_weights(spec, seed=1, n_layers=N_LAYERS)      # same tower replica on every rank
     eng = engine.VitEngine(spec, weights, dev)

@@ -45,9 +45,10 @@ size_t visrep_last_error(char* buf, size_t n);
  * (profiles/round2_gemm_v5.md).  2-5 need N % 256 == 0 (3, 5: K % 64 == 0, else 2 runs); everything else runs 1.
  * Returns the previous value.  Results are identical up to fp32 summation order. */
 int visrep_set_gemm_variant(int variant);
-/* Same kind of knob for the attention forward at head width 64 (the ViT towers' MHSA): 2 (default) = attn_fwd_ab, two 32-row query
- * blocks per wave whose matrix work and softmax are interleaved MFMA by MFMA (csrc/attention_ab.hip); 1 = the four-wave kernel that
- * also serves head widths 128 / 192.  Returns the previous value.  Results agree to bf16 rounding of P. */
+/* Same kind of knob for the attention forward at head width 64 (the ViT towers' MHSA): 1 (default) = the four-wave kernel that also
+ * serves head widths 128 / 192; 2 = attn_fwd_ab, two 32-row query blocks per wave whose matrix work and softmax are interleaved MFMA
+ * by MFMA (csrc/attention_ab.hip; measured equal-to-slower, profiles/round3_attention.md).  Returns the previous value.  Results
+ * agree to the bf16 rounding of P. */
 int visrep_set_attn_variant(int variant);
 /* Timing-only ablation of GEMM variant 2 (bit 0: skip MFMAs, bit 1: skip the LDS-DMA loads, bit 2: skip the fragment reads):
  * results are WRONG for mask != 0; used by tools/gemm_ablate.py to attribute cycles.  Returns the previous mask. */

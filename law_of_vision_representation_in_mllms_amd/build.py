@@ -95,14 +95,20 @@ def _compile(src: str, objdir: str, defines, verbose: bool) -> str:
     return obj
 
 
-def _build(out: str, defines=(), tag: str = "", verbose: bool = False) -> str:
+def _build(out: str, defines=(), tag: str = "", verbose: bool = False, only=None) -> str:
+    """only: the translation units the extra defines apply to (diagnostic builds); every other unit is the default build's object."""
     objdir = os.path.join(OBJ, tag) if tag else OBJ
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
     with open(os.path.join(objdir, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)                  # one builder at a time (per object directory), across processes
         try:
+            def one(src):
+                if only is not None and src not in only:
+                    return _compile(src, OBJ, (), verbose)
+                return _compile(src, objdir, defines, verbose)
             with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
-                objs = list(pool.map(lambda s: _compile(s, objdir, defines, verbose), SOURCES))
+                objs = list(pool.map(one, SOURCES))
             if not _stale(out, defines):
                 return out                                # another process linked it while this one waited for the lock
             tmp = f"{out}.{os.getpid()}.tmp"
@@ -132,9 +138,9 @@ def build_attn_ablation_lib(mask: int) -> str:
     return _build(os.path.join(PKG, f"libvisrep_hip_attn{mask}.so"), [f"-DVISREP_ATTN_ABLATE={mask}"], f"attn{mask}")
 
 
-def build_variant_lib(name: str, defines) -> str:
+def build_variant_lib(name: str, defines, only=None) -> str:
     """Diagnostic build with extra -D flags (tools/ only): libvisrep_hip_<name>.so, loaded through VISREP_LIB."""
-    return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), list(defines), name)
+    return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), list(defines), name, only=only)
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:

@@ -24,6 +24,8 @@
 //     key tiles are aligned to GLOBAL 64-token blocks, so no per-image padding exists anywhere: the first and last
 //     tile of an image are masked against [b*T, (b+1)*T).
 //   * blockIdx is XCD-remapped so the q-tiles of one (b,h) share an XCD L2 (K/V fetched from HBM once).
+#include <cstdlib>
+
 #include "common.h"
 #include "visrep_internal.h"
 
@@ -164,7 +166,11 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
             const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             mloc = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
         }
+#ifdef VISREP_ATTN_V1_THR                                   // diagnostic build: keep the old maximum while no row's maximum grew by more than THR (exp2 units)
+        const float m_new = __any((mloc - m_run) * p.sc > (float)VISREP_ATTN_V1_THR) ? fmaxf(m_run, mloc) : m_run;
+#else
         const float m_new = fmaxf(m_run, mloc);             // finite: every image's first tile holds >= 1 valid key
+#endif
         const float msc = m_new * p.sc;
         float psum = 0.f;
         uint32_t pb[2][8];
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 
 }  // namespace
 
-int g_visrep_attn_variant = 2;   // 1 = attn_fwd<ND> for every head width; 2 = attn_fwd_ab (attention_ab.hip) for head width 64
+int g_visrep_attn_variant = 1;   // 1 = attn_fwd<ND> for every head width (default); 2 = attn_fwd_ab (attention_ab.hip) for head width 64
 
 extern "C" int visrep_set_attn_variant(int variant) {
     if (variant != 1 && variant != 2) return visrep_set_error(VISREP_ERR_SHAPE, "attention variant must be 1 or 2");
@@ -263,7 +269,12 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     a.sc = scale * 1.4426950408889634f;
     const int nqt = (Tq + 127) / 128, nd = head_dim / 64;
     const dim3 grid(nqt * H * B), block(256);
-    const size_t lds = (size_t)nd * 4 * TILE_B;             // double-buffered K + V^T tiles
+    size_t lds = (size_t)nd * 4 * TILE_B;                   // double-buffered K + V^T tiles
+    if (const char* e = getenv("VISREP_ATTN_EXTRA_LDS")) {  // diagnostic: unused LDS to lower the number of resident workgroups per CU
+        lds += (size_t)atoi(e);
+        static bool attr1 = false;
+        if (!attr1) { (void)hipFuncSetAttribute((const void*)attn_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (nd == 1) hipLaunchKernelGGL(attn_fwd<1>, grid, block, lds, st, a);
     else if (nd == 2) hipLaunchKernelGGL(attn_fwd<2>, grid, block, lds, st, a);

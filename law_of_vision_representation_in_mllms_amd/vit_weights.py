@@ -174,6 +174,9 @@ def pack_hf_state_dict(sd: Dict[str, torch.Tensor], spec: ViTSpec) -> dict:
                      o="attention.output.dense", ln1="norm1", ln2="norm2", fc1="mlp.fc1", fc2="mlp.fc2")
     else:
         raise ValueError(spec.family)
+    # The checkpoint's own grid stays in the packed weights: a later change of resolution (weights_at_resolution) must resize from
+    # IT, once, like HF's interpolate_pos_encoding does (37 x 37 -> target), not from the already-resized table (37 -> 16 -> 24).
+    w["pos_native"] = w["pos"]
     w["pos"] = interpolate_pos(w["pos"], spec.has_cls, spec.grid)
     layers = []
     for i in range(spec.layers):
@@ -262,5 +265,9 @@ def weights_at_resolution(spec: ViTSpec, w: dict, image_size: int):
     """Return (spec', w') for another input resolution: only the position embedding changes (bicubic resize)."""
     spec2 = spec.at_resolution(image_size)
     w2 = dict(w)
-    w2["pos"] = interpolate_pos(w["pos"], spec.has_cls, spec2.grid)
+    src = w.get("pos_native")
+    if src is None:
+        src = w["pos"]
+    w2["pos_native"] = src                                   # every later resize starts from the same table
+    w2["pos"] = interpolate_pos(src, spec.has_cls, spec2.grid)
     return spec2, w2

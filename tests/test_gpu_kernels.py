@@ -29,7 +29,7 @@ def gemm_variant(request):
 
 @pytest.fixture(params=[1, 2], ids=["attn_v1", "attn_ab"])
 def attn_variant(request):
-    """Head-width-64 attention under both kernels: the four-wave attn_fwd<1> and the two-blocks-per-wave attn_fwd_ab (default)."""
+    """Head-width-64 attention under both kernels: the four-wave attn_fwd<1> (default) and the two-blocks-per-wave attn_fwd_ab."""
     lib = _lib.load()
     old = lib.visrep_set_attn_variant(request.param)
     yield request.param

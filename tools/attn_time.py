@@ -6,8 +6,10 @@ from law_of_vision_representation_in_mllms_amd import _lib, engine
 B, T, H, d = 256, 577, 16, 1024
 M = B * T
 torch.manual_seed(0)
-qk = torch.randn(M, 2 * d, device="cuda").to(torch.bfloat16)
-x = torch.randn(M, d, device="cuda").to(torch.bfloat16)
+data = os.environ.get("ATTN_DATA", "randn")             # randn | zeros | peaked (q, k x 6: P mostly 0) | flat (q, k x 0.05: P ~ uniform) | vzero
+qscale = {"peaked": 6.0, "flat": 0.05, "zeros": 0.0}.get(data, 1.0)
+qk = (torch.randn(M, 2 * d, device="cuda") * qscale).to(torch.bfloat16)
+x = (torch.randn(M, d, device="cuda") * (0.0 if data in ("zeros", "vzero") else 1.0)).to(torch.bfloat16)
 w = (torch.randn(d, d, device="cuda") * 0.03).to(torch.bfloat16)
 vt = engine.linear_vt(x, w, None)
 lib = _lib.load()
@@ -26,4 +28,4 @@ for variant in [int(v) for v in os.environ.get("ATTN_VARIANTS", "1,2").split(","
         for _ in range(20): engine.mhsa(qk, vt, B, T, H, 0.125)
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 20)
-    print(f"{tag} attn variant {variant}: {best:.4f} ms  {4.0 * B * T * T * d / best / 1e9:.1f} TFLOP/s  rel diff to first variant {err:.2e}", flush=True)
+    print(f"{tag} [{data}] attn variant {variant}: {best:.4f} ms  {4.0 * B * T * T * d / best / 1e9:.1f} TFLOP/s  rel diff to first variant {err:.2e}", flush=True)

@@ -1,13 +1,12 @@
 #!/bin/bash
-# Round 3, first GPU call: parity of the two-blocks-per-wave attention kernel + its timing against attn_fwd<1> and the THR / NOPIN builds.
+# Round 3: parity of the two-blocks-per-wave attention kernel + its timing against attn_fwd<1> and the diagnostic builds.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out/r3a
-export TMPDIR=/tmp
+export TMPDIR=/tmp VISREP_DEBUG=1
 P=law_of_vision_representation_in_mllms_amd
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "attention" > gpurun_out/r3a/pytest_attn.log 2>&1; echo "pytest attention rc=$?" | tee -a gpurun_out/r3a/summary.txt
-tail -5 gpurun_out/r3a/pytest_attn.log
-timeout 300 python tools/attn_time.py 2>&1 | tee -a gpurun_out/r3a/summary.txt
-for v in ab_thr8 ab_nopin; do
-  VISREP_LIB=$PWD/$P/libvisrep_hip_$v.so ATTN_VARIANTS=2 timeout 300 python tools/attn_time.py 2>&1 | tail -1 | tee -a gpurun_out/r3a/summary.txt
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "attention" > gpurun_out/r3a/pytest_attn.log 2>&1; echo "pytest attention rc=$?" | tee gpurun_out/r3a/summary.txt
+tail -3 gpurun_out/r3a/pytest_attn.log
+timeout 300 python tools/attn_time.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r3a/summary.txt
+for v in "$@"; do
+  VISREP_LIB=$PWD/$P/libvisrep_hip_$v.so ATTN_VARIANTS=2 timeout 300 python tools/attn_time.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r3a/summary.txt
 done
-timeout 600 python bench.py --sweep off --no-cpu-baseline --steps 10 --warmup 3 2>&1 | tail -1 | tee gpurun_out/r3a/bench_ab.json
