@@ -17,9 +17,13 @@ Extra objects on the JSON line:
   sweep         the second half of BASELINE.json's metric - "A+C score wall-clock 13 encoders" (configs[4]): every setting of
                 policy/fit.py:20 through towers -> mm_projector -> A score and towers -> feature bank -> C score
                 (law_of_vision_representation_in_mllms_amd/sweep.py), images sharded over the ranks (STRONG scaling: fixed total work).
-                Default: the reference's 100 images per encoder for A and a 1/10-size SPair-shaped set for C (180 images, 1,224
-                pairs) so that the default run stays short; `--sweep full` runs the SPair-71k-size set (1,800 images, 12,234
-                pairs per setting), `--sweep off` skips it.  It never changes the headline `value`.
+                Default (`--sweep full`): the reference's 100 images per encoder for A and the SPair-71k-size set for C (1,800
+                images, 12,234 pairs per setting); `--sweep reduced` = a 1/10-size C set, `--sweep off` skips it.  It never changes
+                the headline `value`.
+  scores        the two score kernels at their single-GPU sizes (BASELINE.json configs[2] / [3]), timed in this run with HIP events:
+                A score (bf16 MFMA Gram + row max + mean) at Nt = 576 / 256 / 196 target tokens against the 576- and 256-token
+                references, C score (exact-fp32 MFMA keypoint transfer + PCK count) for 12,234 pairs at P = 16 / 24, each with its
+                fraction of the roof that bounds it.
 """
 import argparse
 import json
@@ -81,6 +85,64 @@ def timed_steps(step, steps, warmup, dist=None, device=None):
     return dt, result
 
 
+PEAK_F32_MFMA_TFLOPS = 157.3      # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
+
+
+def score_extras(dev, n_a=256, n_img=1800, n_pairs=12234):
+    """The A-score and C-score kernels at the SURVEY §8(d) sizes, HIP events on the launch stream (the library launches on torch's
+    current stream).  A: [n, Nt, 4096] bf16 targets against clip336 [n, 576, 4096] and clip224 [n, 256, 4096] (row scales precomputed,
+    as the sweep does): 2 Nt (576 + 256) 4096 flop per image.  C: DINOv2-L-shaped position-major bank [1800, P^2, 1024] fp32, K ~ U{3..20}
+    key points per pair: 2 * 32 padded rows * P^2 * C flop per pair on the exact-fp32 matrix pipe."""
+    from law_of_vision_representation_in_mllms_amd import ascore_ops, cscore_ops
+
+    def ev_time(fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(3)
+    r336 = torch.randn(n_a, 576, 4096, device=dev, generator=g).to(torch.bfloat16)
+    r224 = torch.randn(n_a, 256, 4096, device=dev, generator=g).to(torch.bfloat16)
+    s336, s224 = ascore_ops.row_scales(r336), ascore_ops.row_scales(r224)
+    for Nt in (576, 256, 196):
+        o = torch.randn(n_a, Nt, 4096, device=dev, generator=g).to(torch.bfloat16)
+        so = ascore_ops.row_scales(o)
+        sec = ev_time(lambda: (ascore_ops.max_cos_mean(o, r336, so, s336), ascore_ops.max_cos_mean(o, r224, so, s224)))
+        tf = 2.0 * Nt * 832 * 4096 * n_a / sec / 1e12
+        out[f"ascore_Nt{Nt}"] = {"ms": round(sec * 1e3, 3), "images": n_a, "images_per_s": round(n_a / sec, 1), "tflops": round(tf, 1),
+                                 "bound": "mfma (bf16)", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+        del o, so
+    del r336, r224, s336, s224
+    rs = np.random.RandomState(5)
+    for P in (16, 24):
+        C_ = 1024
+        bank = torch.randn(n_img, P * P, C_, device=dev, generator=g)
+        i1 = torch.from_numpy(rs.randint(0, n_img, n_pairs).astype(np.int32))
+        i2 = torch.from_numpy(rs.randint(0, n_img, n_pairs).astype(np.int32))
+        nkp = torch.from_numpy(rs.randint(3, 21, n_pairs).astype(np.int32))
+        idx = torch.from_numpy(rs.randint(0, P * P, (n_pairs, 20)).astype(np.int32))
+        kps = torch.rand(n_pairs, 20, 3) * 839
+        kps[:, :, 2] = 1
+        thr = torch.from_numpy(rs.uniform(150, 700, n_pairs))
+        i1, i2, nkp, idx, kps, thr = (t.to(dev) for t in (i1, i2, nkp, idx, kps, thr))
+        sec = ev_time(lambda: cscore_ops.pck_counts(cscore_ops.transfer(bank, i1, i2, idx, nkp, P, layout="pc"), kps, kps, thr, nkp))
+        tf = 2.0 * 32 * P * P * C_ * n_pairs / sec / 1e12
+        out[f"cscore_P{P}"] = {"ms": round(sec * 1e3, 3), "pairs": n_pairs, "pairs_per_s": round(n_pairs / sec, 1), "tflops_fp32": round(tf, 1),
+                               "bound": "mfma (exact fp32)", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                               "unique_bank_GB_per_s": round(n_img * P * P * C_ * 4 / sec / 1e9, 1)}
+        del bank
+    torch.cuda.empty_cache()
+    return out
+
+
 def aggregate_value(world, per_rank_units, steps, seconds):
     """Whole-job throughput: units of ALL ranks (weak scaling: every rank steps over its own batch) / max-over-ranks time."""
     return world * per_rank_units * steps / seconds
@@ -94,7 +156,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
-    ap.add_argument("--sweep", default="reduced", choices=["off", "reduced", "full"])
+    ap.add_argument("--sweep", default="full", choices=["off", "reduced", "full"])
+    ap.add_argument("--no-scores", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 3, 4, 5])
     ap.add_argument("--attn-variant", type=int, default=int(os.environ.get("VISREP_ATTN_VARIANT", "0")), choices=[0, 1, 2])   # 0 = library default
     args = ap.parse_args()
@@ -236,6 +299,13 @@ def main():
                 "kernels": kern}
         del x, hmlp, o1, o2, oqk, qk_act, vt
 
+    scores = None
+    if rank == 0 and not args.no_scores:
+        try:
+            scores = score_extras(dev)
+        except Exception as e:                                              # never let the extra object take the bench down
+            scores = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- CPU baseline: the oracle on a bounded sample, host cores of this box (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_images > 0:
@@ -278,7 +348,7 @@ def main():
                 "config": {"workload": "CLIP ViT-L/14-336 vision_tower feature-extract (hidden_states[-2], 23 layers run), "
                                        f"batch {B} per GPU, random-init weights, N(0,1) pixels resident in HBM",
                            "global_batch": world * B, "tokens": spec.tokens, "parallelism": f"dp{world} (image-sharded, no collective)", "gemm_variant": args.gemm_variant},
-                "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
+                "roofline": roof, "cpu_baseline": cpu, "scores": scores, "sweep": sweep,
             }
             print(json.dumps(line), flush=True)
 

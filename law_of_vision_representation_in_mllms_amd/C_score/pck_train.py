@@ -95,7 +95,8 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
     return _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models=(args.MODEL,))
 
 
-def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models):
+def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models, local=False):
+    """local: this rank evaluates ALL pairs of the category by itself (sweep.py: categories are owned by ranks) - no pair sharding, no collective."""
     adapt_flip = bool(getattr(args, "ADAPT_FLIP", False))
     if adapt_flip and not getattr(args, "MUTUAL_NN", False):
         # pck_train.py:122-124: without MUTUAL_NN the flip decision uses get_distance, which is hard-wired to 60x60 SD+DINO maps and
@@ -126,7 +127,7 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     K = kps.shape[1]
     if K > 32:
         raise ValueError("at most 32 keypoints per pair are supported")
-    d = _dist()
+    d = None if local else _dist()
     rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
     lo, hi = (N * rank) // world, (N * (rank + 1)) // world                   # contiguous pair block of this rank
     k1, k2 = kps[0::2], kps[1::2]

@@ -9,10 +9,12 @@ Here one launcher-aware driver does both legs per setting with every feature res
 kept: 100 x 576 x 4096 bf16 = 0.47 GB each), one process per GPU:
 
   image-sharded mode (default; the reference's own precedent, llava/feature/extract.py:198-214): images i = rank (mod world) for
-    towers, projector and A score; the per-category C-score feature bank is built from the rank's share of the category's images and
-    ALL-GATHERED (the one real exchange step of the path: every rank's pairs may touch any image), then pairs are sharded as in
-    C_score.pck_train.  Collectives: one all-gather per (setting, category), one all-reduce of three fp64 sums per setting (A) and the
-    integer hit counters per category (C).
+    towers, projector and A score.  C leg: ONE tower pass over all of a setting's SPair images (every category at once, interleaved over
+    the ranks, launches of equal size - `plan_launches` - so that a rank's share runs at the full launch batch whatever the world size);
+    every launch's maps are all-gathered asynchronously while the next launch computes (the one real exchange step of the path), each
+    rank keeps the rows of the categories it OWNS (pairs never cross categories; owners balanced by pair count) and evaluates those
+    categories alone; one all_gather_object of the per-category results ends the setting.  A leg: one all-reduce of three fp64 sums per
+    setting.
   encoder-sharded A score (BASELINE.json configs[2]; `a_scores_encoder_sharded`): the CLIP336 / CLIP224 reference stacks are produced
     image-sharded and all-gathered in image chunks on the collective's own stream while the next chunk's towers run; each rank then
     runs ITS OWN encoders (setting i on rank i mod world) over all images and scores them against the gathered references.
@@ -142,9 +144,15 @@ class SettingModel:
         if precision != "fp32":
             self.projector = self.projector.to(torch.bfloat16)           # what LLaVA's model.to(bfloat16) leaves: the bf16 MFMA path
         self.split = self.towers[0].hidden_size if len(self.towers) == 2 else 0
-        if self.device.type == "cuda":                                    # untimed warm-up at the launch shape: HIP-graph capture, workspaces
-            self.project(self.tokens(synthetic_pixels(range(setting.batch), setting.size, self.device,
-                                                      torch.float32 if precision == "fp32" else torch.bfloat16)))
+        self._px_dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+
+    def warm(self, shapes: Sequence[int]) -> None:
+        """Untimed warm-up at every launch shape the sweep will use on this rank (HIP-graph capture of the diffusion towers, engine
+        workspaces): no capture or allocation is left for the timed region."""
+        if self.device.type != "cuda":
+            return
+        for n in sorted(set(int(x) for x in shapes if x > 0)):
+            self.project(self.tokens(synthetic_pixels(range(n), self.setting.size, self.device, self._px_dtype)))
 
     @torch.no_grad()
     def tokens(self, px: torch.Tensor) -> torch.Tensor:
@@ -252,39 +260,126 @@ def _c_args(P: int, window: int = 5):
                            MODEL="fused")
 
 
+def plan_launches(n: int, batch: int) -> List[int]:
+    """n images in ceil(n / batch) launches of (almost) equal size: at most two distinct shapes, differing by one, so that a rank's
+    share never ends in a near-empty launch (225 images at batch 16 -> 15 x 15, not 14 x 16 + 1) and every shape can be warmed
+    (HIP-graph captured) in setup."""
+    if n <= 0:
+        return []
+    k = (n + batch - 1) // batch
+    return [n // k + (1 if j < n % k else 0) for j in range(k)]
+
+
+def category_owners(spair: Sequence[SpairCategory], world: int) -> List[int]:
+    """Owner rank of every category: longest-processing-time greedy on the pair counts (ties by index), identical on every rank.
+    Pairs never cross categories (C_score/pck_train.py:315-340 evaluates category by category), so an owner needs no other bank."""
+    load = [0] * world
+    owner = [0] * len(spair)
+    for ci in sorted(range(len(spair)), key=lambda c: (-len(spair[c].thresholds), c)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[ci] = r
+        load[r] += len(spair[ci].thresholds)
+    return owner
+
+
+def launch_shapes(setting: Setting, n_a_images: int, spair, rank: int, world: int, do_a: bool = True, do_c: bool = True) -> List[int]:
+    """Every tower launch size `run_sweep` issues for this setting on this rank (A leg: the rank's images in launches of `batch`)."""
+    shapes = []
+    if do_a:
+        n = len(range(rank, n_a_images, world))
+        shapes += [min(setting.batch, n - s) for s in range(0, n, setting.batch)]
+    if do_c and spair:
+        shapes += c_launch_plan(spair, setting.batch, world)
+    return shapes
+
+
+def c_launch_plan(spair: Sequence[SpairCategory], batch: int, world: int) -> List[int]:
+    """Launch sizes of ONE rank's share of a setting's C images (the same on every rank: short ranks repeat their last image)."""
+    n_items = sum(c.n_images for c in spair)
+    return plan_launches((n_items + world - 1) // world, batch)
+
+
 def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int):
-    """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set with the per-category bank built in HBM: this rank's share
-    of the category's distinct images -> tokens [n, P^2, C] fp32 -> all-gather -> _compute_pck (pairs sharded, counters all-reduced)."""
+    """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set, every feature resident in HBM.
+    1. ONE image-sharded tower pass over all categories' distinct images (global item g = (category, image) on rank g mod world) in
+       `c_launch_plan` launches; 2. each launch's maps are all-gathered (async: the gather of launch j runs under launch j + 1) and the
+       rows of the categories this rank owns land in its banks; 3. the owner evaluates its categories with _compute_pck(local=True);
+    4. one all_gather_object of (pck, img_correct) per category; statistics are accumulated in category order on every rank, so the
+       result does not depend on the world size."""
     from .C_score import pck_train as PT
     from .C_score.utils.logger import log_weighted_pcks, update_stats
     aggre = PT.DummyAggregationNetwork()
-    pcks, pcks_05, pcks_01, weights, kpt_weights = ([] for _ in range(5))
-    args = None
-    B = model.setting.batch
+    d = _dist() if world > 1 else None
+    items = [(ci, i) for ci, cat in enumerate(spair) for i in range(cat.n_images)]
+    n_items = len(items)
+    owner = category_owners(spair, world)
+    per = (n_items + world - 1) // world
+    mine = items[rank::world]
+    mine = mine + [mine[-1] if mine else items[-1]] * (per - len(mine))      # equal shapes on every rank: a short rank repeats an image
+    plan = c_launch_plan(spair, model.setting.batch, world)
+    # where a gathered row goes: global item -> (row of this rank's bank storage) or -1
+    base, tot = {}, 0
     for ci, cat in enumerate(spair):
-        ids = list(range(rank, cat.n_images, world))
-        local = []
-        for s in range(0, len(ids), B):
-            gids = [ci * 100000 + i for i in ids[s:s + B]]
-            local.append(model.tokens(pixels(gids, model.setting.size)).float())
-        if local:
-            loc = torch.cat(local, 0)
+        if owner[ci] == rank:
+            base[ci] = tot
+            tot += cat.n_images
+    dest_of = torch.full((per * world,), -1, dtype=torch.long)
+    for g, (ci, i) in enumerate(items):
+        if ci in base:
+            dest_of[g] = base[ci] + i
+    store, inflight, off = None, None, 0
+
+    def land(rows, o, sz):
+        """rows [world, sz, N, C] of local rows [o, o + sz) of every rank -> this rank's bank storage"""
+        nonlocal store
+        g = ((torch.arange(o, o + sz)[None, :] * world) + torch.arange(rows.shape[0])[:, None]).reshape(-1)    # global item of every row
+        dst = dest_of[g]
+        keep = (dst >= 0).nonzero().squeeze(1)
+        if store is None:
+            store = torch.empty((max(tot, 1),) + tuple(rows.shape[2:]), dtype=torch.float32, device=rows.device)
+        if keep.numel():
+            flat = rows.reshape((-1,) + tuple(rows.shape[2:]))
+            store.index_copy_(0, dst[keep].to(rows.device), flat.index_select(0, keep.to(rows.device)).float())
+
+    for sz in plan:
+        chunk = mine[off:off + sz]
+        tok = model.tokens(pixels([ci * 100000 + i for ci, i in chunk], model.setting.size)).contiguous()
+        if inflight is not None:
+            inflight()
+        if d is None:
+            land(tok[None], off, sz)
+            inflight = None
         else:
-            probe = model.tokens(pixels([ci * 100000], model.setting.size)).float()
-            loc = probe[:0]
-        bank = all_gather_rows(loc.contiguous(), cat.n_images, rank, world)
-        P = int(round(bank.shape[1] ** 0.5))
-        if P * P != bank.shape[1]:
-            raise ValueError(f"{model.setting.name}: {bank.shape[1]} tokens is not a square map")
-        if args is None:
-            args = _c_args(P)
-        layout = "pc"
+            parts = [torch.empty_like(tok) for _ in range(world)]
+            h = d.all_gather(parts, tok, async_op=True)
+            inflight = (lambda h=h, parts=parts, o=off, sz=sz: (h.wait(), land(torch.stack(parts, 0), o, sz)))
+        off += sz
+    if inflight is not None:
+        inflight()
+    if store is None:
+        raise ValueError("empty SPair set")
+    P = int(round(store.shape[1] ** 0.5))
+    if P * P != store.shape[1]:
+        raise ValueError(f"{model.setting.name}: {store.shape[1]} tokens is not a square map")
+    args = _c_args(P)
+    results = {}
+    for ci, cat in enumerate(spair):
+        if owner[ci] != rank:
+            continue
+        bank, layout = store[base[ci]:base[ci] + cat.n_images], "pc"
         if bank.shape[2] % 4 or model.split % 4:
             bank, layout = bank.transpose(1, 2).contiguous(), "cp"
         pck, _, _, img_correct = PT._compute_pck(args, ".", aggre, cat.files, cat.kps, cat.name, None, cat.thresholds,
-                                                 (bank, cat.slot, model.split, layout), models=("fused",))
-        update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, pck, img_correct)
-        del bank
+                                                 (bank, cat.slot, model.split, layout), models=("fused",), local=True)
+        results[ci] = (pck, img_correct)
+    del store
+    if d is not None:
+        allr = [None] * world
+        d.all_gather_object(allr, results)
+        results = {k: v for part in allr for k, v in part.items()}
+    pcks, pcks_05, pcks_01, weights, kpt_weights = ([] for _ in range(5))
+    for ci in range(len(spair)):
+        update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, *results[ci])
     import logging
     quiet = logging.getLogger("visrep.sweep")
     return log_weighted_pcks(args, quiet, pcks, pcks_05, pcks_01, weights)
@@ -324,6 +419,8 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
     for st in settings:
         t0 = time.perf_counter()
         model = build(st)
+        if hasattr(model, "warm"):
+            model.warm(launch_shapes(st, n_a_images, spair, rank, world, do_a, do_c))
         _fence(dev)
         t_setup = time.perf_counter() - t0
         setup += t_setup
@@ -364,7 +461,7 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
             "img_s": round(images / wall, 2) if wall else None, "img_s_per_gpu": round(images / wall / world, 2) if wall else None,
             "a_images_per_setting": n_a_images if do_a else 0, "c_images_per_setting": n_c_images,
             "c_pairs_per_setting": sum(len(c.thresholds) for c in spair) if do_c else 0, "tower_precision": precision,
-            "scaling": "strong (fixed total work, images sharded rank::world)", "per_setting": per}
+            "scaling": "strong (fixed total work, images sharded rank::world, C categories owned by ranks)", "per_setting": per}
 
 
 # ------------------------------------------------------------------------------------------------ encoder-sharded A score (configs[2])

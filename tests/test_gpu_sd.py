@@ -536,3 +536,80 @@ def test_sd3_medium_width_blocks_and_featurizer_prompt(monkeypatch):
         last = OT.clip_text_hidden(w, ids, ts.heads, ts.act)
         want_pool = last[0, int(ids[0].argmax())] @ proj[i].t()
         assert rel_err(pooled2[0, i * 128:(i + 1) * 128], want_pool) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ full depth
+# One test per diffusion family at the architecture's FULL depth on a 256-px image against the fp32 CPU oracle: error accumulation over
+# 28 DiT blocks / 24 MMDiT blocks, and the whole VAE encoder at a resolution where every down block has real spatial extent (the
+# 9,216-token mid-block attention of the 768-px towers is 1,024 tokens here; the code path - GEMM scores -> softmax_rows -> P.V - is
+# the same).  Tolerance = max(1.5 x the oracle's own bf16 error, 2e-2), like the ViT towers.
+def _fast_cuda(monkeypatch):
+    monkeypatch.setenv("VISREP_FAST_SYNTHETIC", "cuda")                   # multi-GB weight sets: drawn in HBM, the same tensors feed the oracle
+
+
+def test_dit_xl2_full_depth_parity(monkeypatch):
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.dit_engine import DiTEngine
+    from oracle import dit as ODT
+    _fast_cuda(monkeypatch)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sp = SW.DIT_SPECS["facebook/DiT-XL-2-512"]
+    assert sp.core.layers == 28
+    wd, wv = SW.synthetic_dit(sp.core, 131), SW.synthetic_vae(sp.vae, 132)           # all 28 blocks
+    rs = np.random.RandomState(18)
+    img = torch.from_numpy(rs.uniform(-1, 1, (1, 3, 256, 256)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((1, 4, 32, 32)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((1, 4, 32, 32)).astype(np.float32))
+    got = DiTEngine(sp, wd, wv, DEV, up_ft_index=-1).forward(img, t=261, post_noise=post, ddim_noise=ddim)
+    want = ODT.dit_features(sp, wd, wv, img, post, ddim, t=261, up_ft_index=-1)
+    ref_bf16 = ODT.dit_features(sp, wd, wv, img, post, ddim, t=261, up_ft_index=-1, dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert got.shape == want.shape and e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)
+
+
+def test_sd3_medium_full_depth_parity(monkeypatch):
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.sd3_engine import Sd3Engine
+    from oracle import sd3 as O3
+    _fast_cuda(monkeypatch)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sp = SW.SD3_SPECS["stabilityai/stable-diffusion-3-medium-diffusers"]
+    assert sp.core.layers == 24
+    wc, wv = SW.synthetic_sd3(sp.core, 161), SW.synthetic_vae(sp.vae, 162)           # all 24 joint blocks (the last one context_pre_only)
+    rs = np.random.RandomState(19)
+    img = torch.from_numpy(rs.uniform(-1, 1, (1, 3, 256, 256)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((1, 16, 32, 32)).astype(np.float32))
+    noise = torch.from_numpy((0.05 * rs.standard_normal((1, 16, 32, 32))).astype(np.float32))
+    pe = torch.from_numpy(rs.standard_normal((1, 77 + 256, 4096)).astype(np.float32))
+    pe[:, 77:] = 0
+    pooled = torch.from_numpy(rs.standard_normal((1, 2048)).astype(np.float32))
+    got = Sd3Engine(sp, wc, wv, DEV, up_ft_index=-1).forward(img, pe, t=2, post_noise=post, ddim_noise=noise, pooled=pooled)
+    want = O3.sd3_features(sp, wc, wv, img, pe, pooled, post, noise, t=2, up_ft_index=-1)
+    ref_bf16 = O3.sd3_features(sp, wc, wv, img, pe, pooled, post, noise, t=2, up_ft_index=-1, dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got, want), rel_err(ref_bf16, want)
+    assert got.shape == want.shape and e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)
+
+
+def test_sd15_full_depth_256px_parity(monkeypatch):
+    """SD1.5: the whole VAE encoder + every down block, the mid block and up block 0 of the real UNet at 256 px."""
+    from types import SimpleNamespace
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import builder as B
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    args = SimpleNamespace(vision_tower='runwayml/stable-diffusion-v1-5', up_ft_index=0, t=261, prompt="a photo of a cat",
+                           ensemble_size=1, img_size=256)
+    feat = B.build_diffusion_vision_tower(args).vision_tower
+    sp = feat.spec
+    rs = np.random.RandomState(25)
+    img = torch.from_numpy(rs.uniform(-1, 1, (1, 3, 256, 256)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((1, 4, 32, 32)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((1, 4, 32, 32)).astype(np.float32))
+    pe = feat.encode_prompt(args.prompt)
+    got = feat.forward(img, args.prompt, t=261, up_ft_index=0, ensemble_size=1, post_noise=post, ddim_noise=ddim)     # [c, h, w]
+    assert got.shape == (1280, 8, 8)
+    wu = {k: v for k, v in feat._wu.items() if not k.startswith(("up_blocks.1", "up_blocks.2", "up_blocks.3"))}
+    want = OD.sd_features(sp, wu, feat._wv, img, pe.float().cpu(), post, ddim, t=261)                                 # [1, 64, 1280]
+    ref_bf16 = OD.sd_features(sp, wu, feat._wv, img, pe.float().cpu(), post, ddim, t=261, dtype=torch.bfloat16)
+    got_tok = got.permute(1, 2, 0).reshape(1, 64, 1280)
+    e_hip, e_ref = rel_err(got_tok, want), rel_err(ref_bf16, want)
+    assert e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)

@@ -99,6 +99,15 @@ def test_specs_and_interpolation():
     assert w["cls"] is None and w["patch_b"] is not None and len(w["layers"]) == 3
     w2 = VW.synthetic_weights(VW.tiny_spec("siglip", d=128, heads=2, mlp=256), seed=3)
     assert torch.equal(w["layers"][1]["wqkv"], w2["layers"][1]["wqkv"])                    # RandomState stream is stable
+    # a change of resolution always resizes from the checkpoint's own grid, once (HF interpolate_pos_encoding: 37 -> 24), never from an
+    # already-resized table (37 -> 16 -> 24); ADVICE r2
+    native = VW.SPECS['facebook/dinov2-large'].at_resolution(37 * 14)
+    w0 = {"pos": pos, "layers": []}
+    s224, w224 = VW.weights_at_resolution(native, w0, 224)
+    s336, w336 = VW.weights_at_resolution(s224, w224, 336)
+    assert w224["pos"].shape[0] == 257 and w336["pos"].shape[0] == 577
+    assert torch.equal(w336["pos"], VW.interpolate_pos(pos, True, 24))
+    assert not torch.allclose(w336["pos"], VW.interpolate_pos(VW.interpolate_pos(pos, True, 16), True, 24), atol=1e-3)
     flat = VW.flatten(w)
     back = VW.unflatten(flat)
     assert torch.equal(back["layers"][2]["w2"], w["layers"][2]["w2"]) and back["cls"] is None

@@ -159,6 +159,28 @@ def test_two_rank_sweep_and_encoder_sharded_a_score_equal_single_process(cpu_ops
             assert abs(enc[st.name] - single["per_setting"][st.name]["A"]) < 1e-12, st.name
 
 
+def test_shard_plan_keeps_launches_full_at_world_8():
+    """the per-category tower launches were 12-13 images at world 8.  Now one pass over a setting's 1,800 C images:
+    every rank's launches stay near the setting's launch batch, all of one or two shapes, and no collective is needed for the pairs."""
+    spair = S.synthetic_spair()
+    assert sum(c.n_images for c in spair) == 1800 and sum(len(c.thresholds) for c in spair) == 12234
+    for world in (1, 2, 4, 8):
+        for st in S.SETTINGS:
+            plan = S.c_launch_plan(spair, st.batch, world)
+            per = -(-1800 // world)
+            assert sum(plan) == per and max(plan) <= st.batch and max(plan) - min(plan) <= 1 and len(set(plan)) <= 2
+            if st.batch == 16:
+                assert min(plan) >= 15                                   # diffusion towers: 225 images -> 15 launches of 15
+            else:
+                assert min(plan) >= min(64, per)                         # ViT towers: >= 64 rows per launch
+            shapes = S.launch_shapes(st, 100, spair, world - 1, world)
+            assert set(plan) <= set(shapes) and len(set(shapes)) <= 4     # what SettingModel.warm() captures in setup
+        own = S.category_owners(spair, world)
+        load = [sum(len(c.thresholds) for c, o in zip(spair, own) if o == r) for r in range(world)]
+        assert sorted(set(own)) == list(range(world)) and max(load) <= 12234 / world + max(len(c.thresholds) for c in spair)
+    assert S.plan_launches(0, 16) == [] and S.plan_launches(5, 16) == [5] and S.plan_launches(33, 16) == [11, 11, 11]
+
+
 def test_settings_table_is_the_papers():
     """policy/fit.py:20 lists the 13 settings; every tower id is in the drop-in registry; the A keys are compute.py:10's names."""
     from law_of_vision_representation_in_mllms_amd.llava.model.llava_arch import build_function_mapping
