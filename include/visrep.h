@@ -177,10 +177,37 @@ int visrep_groupnorm_f32(const float* x, const float* gamma, const float* beta, 
  * get_distance_mutual_nn): raw Gram matrices of image pairs from a position-major fp32 bank [n_images, PP, C] (gather by index),
  * normalize_feats' row factors r = 1 / (|x| + eps) (pck_train.py:24-29), and per pair the mean cdist of the mutual nearest neighbours
  * of the two L2-normalised descriptor sets: out[z] fp32 (nan when a pair has none, like torch's empty mean).  gram [n_pairs, PP, PP],
- * r1 / r2 [n_pairs, PP] (the factors of each pair's source / target map), PP <= 1024. */
+ * r1 / r2 [n_pairs, PP] (the factors of each pair's source / target map, eps = the epsilon they were built with), PP <= 4096
+ * (60 x 60 maps). */
 int visrep_gram_pairs_f32(const float* bank, const int* idx1, const int* idx2, int n_pairs, int PP, int C, float* gram, void* stream);
 int visrep_row_rnorm_f32(const float* x, long rows, int C, float eps, float* r, void* stream);
-int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float* out, void* stream);
+int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float eps, float* out, void* stream);
+
+/* ---- JPEG decode for the device input pipeline.  Replaces PIL's Image.open(path).convert('RGB') of the reference's
+ * image loaders (C_score/extract_feature.py:65-66, llava/mm_utils.py:78-95, llava/feature/extract.py:198-214) bit for bit; what PIL runs
+ * underneath is libjpeg-turbo's default decode (jidctint.c islow IDCT, jdsample.c fancy upsampling, jdcolor.c ycc_rgb_convert).
+ * HOST: visrep_jpeg_info parses the headers (rc != 0: not a decodable JPEG stream; rc == 0 and info->unsupported != 0: a valid file this
+ * decoder does not take - progressive, arithmetic, 12-bit, CMYK, multi-scan, unusual chroma layouts - visrep_last_error() says which; the
+ * Python side lets PIL decode such a file).  visrep_jpeg_entropy_decode: baseline Huffman decode into QUANTISED coefficients, int16,
+ * natural 8x8 order, component planes of whole MCUs one after the other (info->coef_count values), and the components' quantisation
+ * tables qtab[ncomp][64] (natural order).  Both run on the calling host thread, thread-safe, no GPU needed.
+ * DEVICE: visrep_jpeg_reconstruct turns a BATCH of decoded images into packed RGB u8 [H, W, 3] each: dequantisation + islow IDCT into
+ * the `planes` scratch, then fancy chroma upsampling + YCbCr -> RGB.  desc: n_images x 32 int64 (device) - coefficient / plane offsets
+ * per component, block grid, component and image sizes, offsets of the image's RGB output and quantisation tables
+ * (law_of_vision_representation_in_mllms_amd/device_jpeg.py builds it); max_blocks / max_pixels: the largest image's. */
+typedef struct VisrepJpegInfo {
+    int width, height, ncomp;          /* ncomp 1 (grey) or 3 (YCbCr) */
+    int hs[3], vs[3], hmax, vmax;      /* sampling factors */
+    int mcus_w, mcus_h;
+    int blocks_w[3], blocks_h[3];      /* block grid per component (whole MCUs) */
+    int comp_w[3], comp_h[3];          /* real samples per component (jdmaster.c downsampled_width / height) */
+    int restart_interval, progressive, unsupported;
+    long coef_count;
+} VisrepJpegInfo;
+int visrep_jpeg_info(const void* data, size_t n, VisrepJpegInfo* info);
+int visrep_jpeg_entropy_decode(const void* data, size_t n, int16_t* coef, uint16_t* qtab);
+int visrep_jpeg_reconstruct(const void* coef, const void* qtab, const void* desc, int n_images, long max_blocks, long max_pixels,
+                            void* planes, void* rgb, void* stream);
 
 /* ---- A score (A_score/compute.py:12-15,54-72): scores[img] = mean_t max_s cos(other[img][t], ref[img][s]).
  * other [n_img,Nt,D], ref [n_img,Nr,D] contiguous, dtype VISREP_BF16 (D%16==0) or VISREP_F32 (D%8==0);

@@ -134,6 +134,7 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     idx = np.stack([kpts_to_patch_idx(args, k1[i], P) for i in range(N)]).astype(np.int32) if N else np.zeros((0, K), np.int32)
     nkp = torch.full((N,), K, dtype=torch.int32)
     sl = slice(lo, hi)
+    _check_patch_idx(idx[sl], P)
     src, trg = torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy())
     xy = cscore_ops.transfer(bank_t, src, trg, torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW,
                              soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, split=split, layout=layout)
@@ -210,15 +211,19 @@ def _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t
     K = kps.shape[1]
     used = torch.arange(K) if used_points is None else used_points
     permute_list = flip_permutation(table, used.tolist(), K)
-    if bank is not None and len(bank) > 4:
-        flip_bank = bank[4]                                                    # caller-provided mirrored maps, same slots
-    else:
-        flip_bank, _ = build_feature_bank(args, aggre_net, files, P, dev, models, flip=True)
-        flip_bank = flip_bank.transpose(1, 2).contiguous()
-    n_img = bank_t.shape[0]
-    both = torch.cat([bank_t, flip_bank.to(bank_t.device)], 0)                 # mirrored map of image i = bank entry n_img + i
-    k1, k2 = kps[0::2], kps[1::2]
     lo, hi = sl.start, sl.stop
+    n_img = bank_t.shape[0]
+    if bank is not None and len(bank) > 4:
+        flip_bank = bank[4]                                                    # caller-provided mirrored maps, same slots as the bank
+        src_f = src + n_img
+    else:
+        # only SOURCE images are ever mirrored (get_patch_descriptors(flip=True) flips img1, pck_train.py:82-94): read the `_flip.pt`
+        # files of this rank's distinct sources - a dataset with flip features for the sources only evaluates like in the reference
+        flip_bank, fslot = build_feature_bank(args, aggre_net, files[0::2][lo:hi], P, dev, models, flip=True)
+        flip_bank = flip_bank.transpose(1, 2).contiguous()
+        src_f = torch.from_numpy(fslot.astype(np.int64)).to(src.dtype) + n_img
+    both = torch.cat([bank_t, flip_bank.to(bank_t.device)], 0)                 # mirrored maps behind the bank
+    k1, k2 = kps[0::2], kps[1::2]
     idx_f = np.zeros((hi - lo, K), np.int32)
     for n, i in enumerate(range(lo, hi)):
         vis = k1[i][:, 2] * k2[i][:, 2] > 0
@@ -226,17 +231,26 @@ def _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t
         if flipped.shape[0] != K:            # the flip table does not cover every key-point column (the reference's indexing breaks too)
             raise ValueError(f"flip table of {category!r} covers {flipped.shape[0]} of the {K} key points")
         idx_f[n] = kpts_to_patch_idx(args, flipped, P)
+    _check_patch_idx(idx_f, P)
     nkp = torch.full((hi - lo,), K, dtype=torch.int32)
-    xy_f = cscore_ops.transfer(both, src + n_img, trg, torch.from_numpy(idx_f), nkp, P, window=args.SOFT_EVAL_WINDOW,
+    xy_f = cscore_ops.transfer(both, src_f, trg, torch.from_numpy(idx_f), nkp, P, window=args.SOFT_EVAL_WINDOW,
                                soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, layout="pc")
     d_orig = cscore_ops.mutual_nn_distance(both, src, trg, P).cpu()
-    d_flip = cscore_ops.mutual_nn_distance(both, src + n_img, trg, P).cpu()
+    d_flip = cscore_ops.mutual_nn_distance(both, src_f, trg, P).cpu()
     out = xy.clone()
     xy_c, xyf_c = xy.cpu(), xy_f.cpu()
     for n, i in enumerate(range(lo, hi)):
         vis = k1[i][:, 2] * k2[i][:, 2] > 0
         out[n] = optimized_kps_1_to_2(args, xy_c[n], xyf_c[n], k1[i], k2[i], d_flip[n], d_orig[n], vis, permute_list).to(out.device)
     return out
+
+
+def _check_patch_idx(idx, P):
+    """A key point on the far border of the annotation frame (x or y = ANNO_SIZE, e.g. x = 0 mirrored) maps to patch column / row P: the
+    reference's tensor indexing raises IndexError there (utils_correspondence.py:360); the kernel indexes unclamped, so refuse first."""
+    if idx.size and (idx.min() < 0 or idx.max() >= P * P):
+        bad = int(idx.max() if idx.max() >= P * P else idx.min())
+        raise IndexError(f"index {bad} is out of bounds for dimension 2 with size {P * P}")
 
 
 def _f32(alphas):

@@ -31,6 +31,13 @@ class VitWeights(C.Structure):
         ("layers", C.POINTER(VitLayer))]
 
 
+class JpegInfo(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int), ("hs", C.c_int * 3), ("vs", C.c_int * 3), ("hmax", C.c_int),
+                ("vmax", C.c_int), ("mcus_w", C.c_int), ("mcus_h", C.c_int), ("blocks_w", C.c_int * 3), ("blocks_h", C.c_int * 3),
+                ("comp_w", C.c_int * 3), ("comp_h", C.c_int * 3), ("restart_interval", C.c_int), ("progressive", C.c_int),
+                ("unsupported", C.c_int), ("coef_count", C.c_long)]
+
+
 # name -> (restype, argtypes); every symbol include/visrep.h declares
 _vp, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 SIGNATURES = {
@@ -74,13 +81,16 @@ SIGNATURES = {
     "visrep_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_row_rnorm_f32": (_i, [_vp, _l, _i, _f, _vp, _vp]),
-    "visrep_mutual_nn_distance": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "visrep_mutual_nn_distance": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_ascore_row_scale": (_i, [_vp, C.c_long, _i, _i, _vp, _vp]),
     "visrep_ascore_maxcos_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_cscore_transfer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "visrep_pck_count": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
+    "visrep_jpeg_info": (_i, [_vp, _sz, C.POINTER(JpegInfo)]),
+    "visrep_jpeg_entropy_decode": (_i, [_vp, _sz, _vp, _vp]),
+    "visrep_jpeg_reconstruct": (_i, [_vp, _vp, _vp, _i, _l, _l, _vp, _vp, _vp]),
 }
 
 _lock = threading.Lock()

@@ -23,7 +23,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
 SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "gemm_bf16_v5.hip", "attention.hip", "attention_ab.hip", "rowops.hip", "convnet.hip", "ascore.hip",
-           "cscore.hip", "f32ops.hip", "visrep_abi.hip"]
+           "cscore.hip", "f32ops.hip", "jpeg_decode.hip", "visrep_abi.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]

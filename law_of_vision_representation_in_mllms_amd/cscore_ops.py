@@ -93,20 +93,21 @@ def mutual_nn_distance(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tenso
     bank = bank.contiguous()
     dev = bank.device
     n_img, PP, C_ = bank.shape
-    if PP % 4 or C_ % 4 or PP > 1024:
-        raise ValueError("mutual_nn_distance needs P*P and C multiples of 4 and P <= 32")
+    if PP % 4 or C_ % 4 or PP > 4096:
+        raise ValueError("mutual_nn_distance needs P*P and C multiples of 4 and P <= 64")
     i1 = img1.to(device=dev, dtype=torch.int32).contiguous()
     i2 = img2.to(device=dev, dtype=torch.int32).contiguous()
     n = i1.shape[0]
     rn = torch.empty(n_img, PP, dtype=torch.float32, device=dev)
     _lib.check(lib.visrep_row_rnorm_f32(_lib.ptr(bank), n_img * PP, C_, float(eps), _lib.ptr(rn), _lib.stream_ptr()), "visrep_row_rnorm_f32")
     out = torch.empty(n, dtype=torch.float32, device=dev)
+    chunk = max(1, min(chunk, (2 << 30) // (4 * PP * PP)))                  # the Gram buffer stays <= 2 GiB (60 x 60 maps: 51.8 MB per pair)
     gram = torch.empty(min(chunk, max(n, 1)), PP, PP, dtype=torch.float32, device=dev)
     for s in range(0, n, chunk):
         a, b = i1[s:s + chunk].contiguous(), i2[s:s + chunk].contiguous()
         m = a.shape[0]
         _lib.check(lib.visrep_gram_pairs_f32(_lib.ptr(bank), _lib.ptr(a), _lib.ptr(b), m, PP, C_, _lib.ptr(gram), _lib.stream_ptr()), "visrep_gram_pairs_f32")
         r1, r2 = rn.index_select(0, a.long()).contiguous(), rn.index_select(0, b.long()).contiguous()
-        _lib.check(lib.visrep_mutual_nn_distance(_lib.ptr(gram), _lib.ptr(r1), _lib.ptr(r2), m, PP, C.c_void_p(out.data_ptr() + 4 * s), _lib.stream_ptr()),
+        _lib.check(lib.visrep_mutual_nn_distance(_lib.ptr(gram), _lib.ptr(r1), _lib.ptr(r2), m, PP, float(eps), C.c_void_p(out.data_ptr() + 4 * s), _lib.stream_ptr()),
                    "visrep_mutual_nn_distance")
     return out

@@ -234,12 +234,13 @@ __global__ void cscore_pck(const float* __restrict__ xy, const float* __restrict
 // utils_correspondence.py:54-73 get_distance_mutual_nn: D = cdist(F1, F2) over the L2-normalised descriptors; nn12[i] = argmin_j D[i, j],
 // nn21[j] = argmin_i D[i, j]; result = mean over the mutual pairs (nn21[nn12[i]] == i) of D[i, nn12[i]].
 // Input: the RAW Gram G = F1raw F2raw^T of the pair (visrep_gram_pairs_f32) and the normalisation factors r = 1 / (|x| + 1e-10) of both
-// sets; with a = |x| r = 1 - 1e-10 r the squared distance is a_i^2 + b_j^2 - 2 G_ij r1_i r2_j (torch.cdist's matmul form, clamped at 0).
+// sets (eps = the 1e-10 of normalize_feats); with a = |x| r = 1 - eps r the squared distance is a_i^2 + b_j^2 - 2 G_ij r1_i r2_j (torch.cdist's matmul form, clamped at 0).
 // One workgroup per pair, one wave per row (lanes over the columns, coalesced); the column minima are accumulated on the fly:
 // lane l owns columns l + 64 k and keeps their running (min, first argmin) over the rows its wave visits in increasing order.
 // Ties resolve to the smallest index like torch.argmin.
+template <int KC>                          // columns per lane: PP <= 64 * KC (16: maps up to 32 x 32; 40: 48 x 48 diffusion maps; 64: 60 x 60)
 __global__ __launch_bounds__(256) void mutual_nn_kernel(const float* __restrict__ gram, const float* __restrict__ r1, const float* __restrict__ r2,
-                                                        int PP, float* __restrict__ out) {
+                                                        int PP, float eps, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dmin = sm;                          // [PP] min distance^2 of row i
     int* nn12 = reinterpret_cast<int*>(sm + PP);          // [PP]
@@ -249,27 +250,25 @@ __global__ __launch_bounds__(256) void mutual_nn_kernel(const float* __restrict_
     const float* G = gram + (size_t)pair * PP * PP;
     const float* ra = r1 + (size_t)pair * PP;
     const float* rb = r2 + (size_t)pair * PP;
-    constexpr int KC = 16;                     // columns per lane: PP <= 1024
-    float cb[KC], cv[KC], b2[KC];
+    float cb[KC], cv[KC];
     int ci[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
         const int j = lane + 64 * k;
         cb[k] = j < PP ? rb[j] : 0.f;
-        const float b = 1.0f - 1e-10f * cb[k];
-        b2[k] = b * b;
         cv[k] = INFINITY; ci[k] = 0x7fffffff;
     }
     for (int i = wave; i < PP; i += 4) {
         const float ri = ra[i];
-        const float a = 1.0f - 1e-10f * ri, a2 = a * a;
+        const float a = 1.0f - eps * ri, a2 = a * a;
         float best = INFINITY;
         int bj = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int j = lane + 64 * k;
             if (j < PP) {
-                const float d2 = fmaxf(a2 + b2[k] - 2.0f * G[(size_t)i * PP + j] * ri * cb[k], 0.f);
+                const float b = 1.0f - eps * cb[k];
+                const float d2 = fmaxf(a2 + b * b - 2.0f * G[(size_t)i * PP + j] * ri * cb[k], 0.f);
                 if (d2 < best) { best = d2; bj = j; }              // increasing j within a lane: first minimum kept
                 if (d2 < cv[k]) { cv[k] = d2; ci[k] = i; }           // increasing i within a wave: first minimum kept
             }
@@ -337,11 +336,25 @@ extern "C" int visrep_row_rnorm_f32(const float* x, long rows, int C, float eps,
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "row_rnorm_f32: launch failed");
 }
 
-extern "C" int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float* out, void* stream) {
+template <int KC>
+static void launch_mutual_nn(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float eps, float* out, hipStream_t st) {
+    const size_t lds = (size_t)10 * PP * sizeof(float);
+    static size_t lds_set = 0;
+    if (lds > lds_set && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mutual_nn_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(mutual_nn_kernel<KC>, dim3(n_pairs), dim3(256), lds, st, gram, r1, r2, PP, eps, out);
+}
+
+extern "C" int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float eps, float* out, void* stream) {
     if (!gram || !r1 || !r2 || !out) return visrep_set_error(VISREP_ERR_ARG, "mutual_nn_distance: null pointer");
     if (n_pairs <= 0) return 0;
-    if (PP <= 0 || PP > 1024) return visrep_set_error(VISREP_ERR_SHAPE, "mutual_nn_distance: 1 <= P*P <= 1024");
-    hipLaunchKernelGGL(mutual_nn_kernel, dim3(n_pairs), dim3(256), (size_t)10 * PP * sizeof(float), (hipStream_t)stream, gram, r1, r2, PP, out);
+    if (PP <= 0 || PP > 4096) return visrep_set_error(VISREP_ERR_SHAPE, "mutual_nn_distance: 1 <= P*P <= 4096");
+    hipStream_t st = (hipStream_t)stream;
+    if (PP <= 1024) launch_mutual_nn<16>(gram, r1, r2, n_pairs, PP, eps, out, st);
+    else if (PP <= 2560) launch_mutual_nn<40>(gram, r1, r2, n_pairs, PP, eps, out, st);
+    else launch_mutual_nn<64>(gram, r1, r2, n_pairs, PP, eps, out, st);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mutual_nn_distance: launch failed");
 }
 

@@ -115,17 +115,20 @@ class VitEngine:
         self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
                                    int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
         self._ws: Dict[int, torch.Tensor] = {}
+        self._pinned = set()                 # batch sizes whose workspace a captured HIP graph refers to
 
     def workspace(self, B: int) -> torch.Tensor:
         ws = self._ws.get(B)
         if ws is None:
             nbytes = self.lib.visrep_vit_workspace_bytes(C.byref(self._cfg), B)
-            # a few batch sizes stay resident: a caller may have captured a forward at an earlier batch size into a HIP graph (the
-            # image-variation featurizer does), and a captured graph keeps using the workspace pointer it saw
-            while len(self._ws) >= 6:
-                self._ws.pop(next(iter(self._ws)))
+            # a few batch sizes stay resident; a workspace that a HIP graph captured (the image-variation featurizer records this engine's
+            # forward inside its own graph) is PINNED: a replayed graph keeps using the pointer it saw, so it is never evicted
+            for old in [b for b in self._ws if b not in self._pinned][: max(0, len(self._ws) - len(self._pinned) - 5)]:
+                self._ws.pop(old)
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[B] = ws
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            self._pinned.add(B)
         return ws
 
     @torch.no_grad()
@@ -202,6 +205,7 @@ class VitEngineF32:
         self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
                                    int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
         self._ws: Dict[int, torch.Tensor] = {}
+        self._pinned = set()                 # batch sizes whose workspace a captured HIP graph refers to
 
     def chunk(self) -> int:
         per = self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), 1)
@@ -210,10 +214,12 @@ class VitEngineF32:
     def workspace(self, B: int) -> torch.Tensor:
         ws = self._ws.get(B)
         if ws is None:
-            while len(self._ws) >= 6:
-                self._ws.pop(next(iter(self._ws)))
+            for old in [b for b in self._ws if b not in self._pinned][: max(0, len(self._ws) - len(self._pinned) - 5)]:
+                self._ws.pop(old)
             ws = torch.empty(self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), B), dtype=torch.uint8, device=self.device)
             self._ws[B] = ws
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            self._pinned.add(B)                 # a captured graph refers to this pointer: never evicted
         return ws
 
     @torch.no_grad()

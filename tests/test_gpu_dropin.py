@@ -330,6 +330,36 @@ def test_mutual_nn_distance_matches_the_reference():
         want = OC.mutual_nn_distance(OC.normalize_feats(bank[a][None]), OC.normalize_feats(bank[b][None])).item()
         assert abs(got[n].item() - want) < 1e-4, (n, got[n].item(), want)
     assert got[1].item() < 1e-3                                                                            # a map against itself
+    # 48 x 48 maps (the 768-px diffusion towers) and 60 x 60 maps (GeoAware-SC's own grid): 36 / 57 columns per lane
+    for P in (48, 60):
+        bank = torch.randn(3, P * P, 32, generator=g) + 1.5 * torch.randn(1, P * P, 32, generator=g)
+        got = cscore_ops.mutual_nn_distance(bank.to(DEV), torch.tensor([0, 2]), torch.tensor([1, 0]), P).cpu()
+        for n, (a, b) in enumerate(((0, 1), (2, 0))):
+            want = OC.mutual_nn_distance(OC.normalize_feats(bank[a][None]), OC.normalize_feats(bank[b][None])).item()
+            assert abs(got[n].item() - want) < 1e-4, (P, n, got[n].item(), want)
+    # the epsilon of normalize_feats reaches the kernel (it was hard-wired to 1e-10)
+    bank = torch.randn(2, 16 * 16, 16, generator=g)
+    got = cscore_ops.mutual_nn_distance(bank.to(DEV), torch.tensor([0]), torch.tensor([1]), 16, eps=0.5).cpu()
+    want = OC.mutual_nn_distance(OC.normalize_feats(bank[0][None], 0.5), OC.normalize_feats(bank[1][None], 0.5)).item()
+    assert abs(got[0].item() - want) < 1e-4, (got[0].item(), want)
+
+
+def test_patch_index_on_the_far_border_raises_like_the_reference():
+    """A key point at x = y = ANNO_SIZE maps to flat patch index P*P + P - 1 >= P*P: IndexError in the reference's tensor indexing
+    (utils_correspondence.py:360); the transfer kernel indexes unclamped, so compute_pck refuses before the launch."""
+    from law_of_vision_representation_in_mllms_amd.C_score import pck_train as PT
+    P, C_ = 6, 8
+    args = SimpleNamespace(NUM_PATCHES=P, SOFT_EVAL=True, SOFT_EVAL_WINDOW=2, ANNO_SIZE=840, EVAL_DATASET='spair', KPT_RESULT=False, ENSEMBLE=1,
+                           MODEL="m", ADAPT_FLIP=False, TOTAL_SAVE_RESULT=0, COMPUTE_GEOAWARE_METRICS=False)
+    bank = torch.randn(2, P * P, C_, device=DEV)
+    kps = torch.zeros(2, 3, 3)
+    kps[:, :, 2] = 1
+    kps[0, 1, :2] = 840.0                                                   # the source key point on the far corner
+    files = ["a.jpg", "b.jpg"]
+    with pytest.raises(IndexError, match="out of bounds"):
+        PT._compute_pck(args, ".", PT.DummyAggregationNetwork(), files, kps, "cat", None, np.array([100.0]), (bank, np.array([0, 1], np.int32), 0, "pc"), models=("m",))
+    kps[0, 1, :2] = 839.0
+    PT._compute_pck(args, ".", PT.DummyAggregationNetwork(), files, kps, "cat", None, np.array([100.0]), (bank, np.array([0, 1], np.int32), 0, "pc"), models=("m",))
 
 
 def test_adapt_flip_eval_on_device_matches_reference_eval(tmp_path):
