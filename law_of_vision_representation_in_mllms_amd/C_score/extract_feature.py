@@ -137,6 +137,26 @@ def _finish_on_device(a, size, device="cuda"):
     return DP.to_tensor(DP.resize_u8(dev, (size, size)), (0, 0, size, size), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
 
 
+def _prefetched_device_decode(chunks, device="cuda"):
+    """The all-device input path: host threads only parse and Huffman-decode the JPEG files of chunk i + 1 while the GPU
+    reconstructs (IDCT, chroma upsampling, colour conversion: device_jpeg), resizes (Pillow-exact bicubic) and normalises chunk i.
+    Bit-identical to _load_pixels (tests/test_gpu_jpeg.py); PNG / progressive / CMYK files go through PIL inside the decoder."""
+    from .. import device_jpeg as DJ
+    from .. import device_preprocess as DP
+    dec = getattr(_state, "jpeg_decoder", None)
+    if dec is None:
+        dec = _state.jpeg_decoder = DJ.DeviceJpegDecoder(device)
+    size = _state.img_size
+    pending = dec.submit([p for p, _ in chunks[0]]) if chunks else None
+    for i, chunk in enumerate(chunks):
+        nxt = dec.submit([p for p, _ in chunks[i + 1]]) if i + 1 < len(chunks) else None
+        imgs = dec.finish(pending)
+        if getattr(_state, "flip", False):
+            imgs = [im.flip(1) for im in imgs]                           # Image.FLIP_LEFT_RIGHT
+        yield chunk, torch.stack([DP.to_tensor(DP.resize_u8(im, (size, size)), (0, 0, size, size), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)) for im in imgs])
+        pending = nxt
+
+
 def _to_maps(f):
     # tokens [B, N, C] -> [B, C, g, g]   (extract_feature.py:82,86,90 with g = sqrt(N))
     B, N, C = f.shape
@@ -207,8 +227,12 @@ def _process_images(input_dir, output_dir, workers):
     # profiles/round1_pipeline.md); at most two batches of maps are in flight
     with ThreadPoolExecutor(max_workers=max(1, min(workers, 8))) as writers:
         inflight = []
-        stream = (_prefetched(chunks, _decode_rgb, workers, _finish_on_device) if on_device
-                  else _prefetched(chunks, _load_pixels_worker if workers > 1 else _load_pixels, workers))
+        if on_device and getattr(_state, "device_decode", True):
+            stream = _prefetched_device_decode(chunks)
+        elif on_device:
+            stream = _prefetched(chunks, _decode_rgb, workers, _finish_on_device)
+        else:
+            stream = _prefetched(chunks, _load_pixels_worker if workers > 1 else _load_pixels, workers)
         for chunk, px in stream:
             maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
             batch = [writers.submit(save, m.unsqueeze(0).clone(), out) for (_, out), m in zip(chunk, maps)]

@@ -59,6 +59,21 @@ class DeviceJpegDecoder:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.pool = ThreadPoolExecutor(max_workers=threads or min(32, os.cpu_count() or 1))
         self.stats = {"device": 0, "pil": 0, "pil_reasons": {}}
+        # two pinned staging buffers (coefficients + tables + descriptors), alternated: the upload of batch k may still be in flight
+        # while batch k + 1 is assembled.  Assembly is plain numpy memcpy - torch CPU copies wake the intra-op pool, which on a
+        # 256-core host costs more than the Huffman decode (profiles/round1_pipeline.md).
+        self._stage = [None, None]
+        self._stage_ev = [None, None]
+        self._turn = 0
+
+    def _staging(self, nbytes: int):
+        k = self._turn
+        self._turn ^= 1
+        if self._stage_ev[k] is not None:
+            self._stage_ev[k].synchronize()
+        if self._stage[k] is None or self._stage[k].numel() < nbytes:
+            self._stage[k] = torch.empty(max(nbytes, 1 << 24) * 5 // 4, dtype=torch.uint8).pin_memory()
+        return k, self._stage[k]
 
     @staticmethod
     def _host(item):
@@ -71,9 +86,17 @@ class DeviceJpegDecoder:
         except ValueError as e:                                    # corrupt entropy stream: let PIL have its say (it raises or repairs)
             return ("pil", item, str(e))
 
-    @torch.no_grad()
+    def submit(self, items: Sequence):
+        """Start the host half (parse + Huffman decode, one file per pool thread) of a batch; hand the result to finish()."""
+        return [self.pool.submit(self._host, it) for it in items]
+
     def decode(self, items: Sequence) -> List[torch.Tensor]:
-        parts = list(self.pool.map(self._host, items))
+        return self.finish(self.submit(items))
+
+    @torch.no_grad()
+    def finish(self, futures) -> List[torch.Tensor]:
+        """Device half of a submitted batch: one upload, one launch pair; returns uint8 [H, W, 3] tensors in submission order."""
+        parts = [f.result() for f in futures]
         out: List[Optional[torch.Tensor]] = [None] * len(parts)
         dev_idx = [i for i, p in enumerate(parts) if p[0] == "dev"]
         if dev_idx:
@@ -94,15 +117,25 @@ class DeviceJpegDecoder:
                 D[18], D[19], D[20], D[21], D[22], D[23], D[24] = info.width, info.height, info.ncomp, info.hmax, info.vmax, rgb_off, 192 * j
                 rgb_off = _align(rgb_off + info.width * info.height * 3)
                 max_blocks, max_pixels = max(max_blocks, nb), max(max_pixels, info.width * info.height)
-            host = torch.empty(coef_off, dtype=torch.int16).pin_memory()
-            hq = torch.zeros(len(dev_idx), 3, 64, dtype=torch.int16).pin_memory()
+            # one staging buffer = [coefficients int16 | tables uint16 [n, 3, 64] | descriptors int64 [n, 32]], one upload
+            q_off = _align(coef_off * 2)
+            d_off = _align(q_off + len(dev_idx) * 384)
+            total = d_off + desc.nbytes
+            k, stage = self._staging(total)
+            hb = stage.numpy()
+            hcoef = hb[: coef_off * 2].view(np.int16)
+            hq = hb[q_off: q_off + len(dev_idx) * 384].view(np.uint16).reshape(len(dev_idx), 3, 64)
+            hq[:] = 0
             for j, i in enumerate(dev_idx):
                 info, coef, qtab = parts[i][1:]
-                host[int(desc[j, 0]): int(desc[j, 0]) + coef.size] = torch.from_numpy(coef)
-                hq[j, : info.ncomp] = torch.from_numpy(qtab.view(np.int16))
-            dcoef = host.to(self.device, non_blocking=True)
-            dq = hq.to(self.device, non_blocking=True)
-            ddesc = torch.from_numpy(desc).to(self.device, non_blocking=True)
+                np.copyto(hcoef[int(desc[j, 0]): int(desc[j, 0]) + coef.size], coef)
+                hq[j, : info.ncomp] = qtab
+            hb[d_off: d_off + desc.nbytes] = desc.view(np.uint8).reshape(-1)
+            dbuf = stage[:total].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._stage_ev[k] = ev
+            dcoef, dq, ddesc = dbuf[: coef_off * 2], dbuf[q_off: q_off + len(dev_idx) * 384], dbuf[d_off: d_off + desc.nbytes]
             planes = torch.empty(max(plane_off, 64), dtype=torch.uint8, device=self.device)
             rgb = torch.empty(max(rgb_off, 64), dtype=torch.uint8, device=self.device)
             with torch.cuda.device(self.device):

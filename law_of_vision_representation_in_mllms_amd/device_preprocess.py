@@ -202,6 +202,21 @@ def to_tensor(img: torch.Tensor, box: Tuple[int, int, int, int], mean: Sequence[
     return out
 
 
+def expand2square_u8(img: torch.Tensor, background) -> torch.Tensor:
+    """llava/mm_utils.py:78-91 expand2square on an RGB u8 [H, W, 3] device tensor: paste centred on a square of the background colour."""
+    H, W, _ = img.shape
+    if W == H:
+        return img
+    side = max(W, H)
+    out = torch.empty(side, side, 3, dtype=torch.uint8, device=img.device)
+    out[:] = torch.tensor([int(c) for c in background], dtype=torch.uint8, device=img.device)
+    if W > H:
+        out[(W - H) // 2: (W - H) // 2 + H] = img
+    else:
+        out[:, (H - W) // 2: (H - W) // 2 + W] = img
+    return out
+
+
 class DevicePreprocessor:
     """Device twin of image_processing.SimpleImageProcessor (same geometry, same arithmetic): PIL images in, pixel batch out."""
 
@@ -229,9 +244,11 @@ class DevicePreprocessor:
             images = [images]
         out = torch.empty(len(images), 3, self.crop, self.crop, dtype=self.dtype, device=self.device)
         for i, im in enumerate(images):
-            a = np.array(im.convert("RGB"))                                      # decode stays on the host (writable copy for torch)
-            dev = torch.from_numpy(a).to(self.device, non_blocking=True)
-            size, box = self.geometry(a.shape[1], a.shape[0])
+            if isinstance(im, torch.Tensor):                                     # RGB u8 [H, W, 3] already in HBM (device_jpeg.DeviceJpegDecoder)
+                dev = im.to(self.device)
+            else:
+                dev = torch.from_numpy(np.array(im.convert("RGB"))).to(self.device, non_blocking=True)   # PIL image: decoded on the host
+            size, box = self.geometry(dev.shape[1], dev.shape[0])
             to_tensor(resize_u8(dev, size), box, self.mean, self.std, out=out[i])
         return {"pixel_values": out}
 

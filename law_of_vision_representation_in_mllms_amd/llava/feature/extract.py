@@ -72,8 +72,27 @@ def load_image(path, processor, image_aspect_ratio):
     return processor.preprocess(image, return_tensors='pt')['pixel_values'][0]
 
 
-def inference(model_args, data_args, training_args, model=None, workers=8):
-    """Returns the number of feature files this rank wrote."""
+def _device_input_stream(chunks, processor, image_aspect_ratio, device):
+    """The all-device input path: host threads parse + Huffman-decode the files of chunk i + 1 while the GPU
+    reconstructs, pads, resizes, crops and normalises chunk i (device_jpeg + device_preprocess; bit-identical to load_image)."""
+    from ... import device_jpeg as DJ
+    from ... import device_preprocess as DP
+    dec = DJ.DeviceJpegDecoder(device)
+    dproc = DP.DevicePreprocessor.like(processor, device)
+    bg = tuple(int(x * 255) for x in processor.image_mean)
+    pending = dec.submit([p for p, _ in chunks[0]]) if chunks else None
+    for i, chunk in enumerate(chunks):
+        nxt = dec.submit([p for p, _ in chunks[i + 1]]) if i + 1 < len(chunks) else None
+        imgs = dec.finish(pending)
+        if image_aspect_ratio == 'pad':
+            imgs = [DP.expand2square_u8(im, bg) for im in imgs]
+        yield chunk, dproc.preprocess(imgs)["pixel_values"]
+        pending = nxt
+
+
+def inference(model_args, data_args, training_args, model=None, workers=8, device_decode=None):
+    """Returns the number of feature files this rank wrote.  device_decode (default: VISREP_DEVICE_DECODE=1): JPEG reconstruction,
+    padding, resize and normalisation on the GPU instead of PIL + the CPU processor on the thread pool."""
     rank, world = _rank_world()
     if model is None:
         model = build_function_mapping[model_args.vision_tower](model_args)       # KeyError for ids outside the registry, as the reference
@@ -84,18 +103,28 @@ def inference(model_args, data_args, training_args, model=None, workers=8):
     bs = max(1, int(training_args.per_device_train_batch_size))
     chunks = [todo[i:i + bs] for i in range(0, len(todo), bs)]
     written = 0
-    with torch.no_grad(), ThreadPoolExecutor(max_workers=workers) as pool:
+    if device_decode is None:
+        device_decode = os.environ.get("VISREP_DEVICE_DECODE") == "1"
+    if device_decode and not hasattr(processor, "resize_to"):
+        raise ValueError("device_decode needs the ViT towers' SimpleImageProcessor geometry (the diffusion towers' resize-only processor is not ported)")
+
+    def host_stream(pool):
         submit = lambda chunk: [pool.submit(load_image, p, processor, data_args.image_aspect_ratio) for p, _ in chunk]
         pending = submit(chunks[0]) if chunks else None
         for i, chunk in enumerate(chunks):
             nxt = submit(chunks[i + 1]) if i + 1 < len(chunks) else None
-            images = torch.stack([f.result() for f in pending]).to(dtype=torch.bfloat16)
+            yield chunk, torch.stack([f.result() for f in pending])
+            pending = nxt
+
+    with torch.no_grad(), ThreadPoolExecutor(max_workers=workers) as pool:
+        stream = _device_input_stream(chunks, processor, data_args.image_aspect_ratio, model.device) if device_decode else host_stream(pool)
+        for chunk, images in stream:
+            images = images.to(dtype=torch.bfloat16)
             outputs = model(images)
             for (_, out_path), feat in zip(chunk, torch.split(outputs, 1)):
                 os.makedirs(os.path.dirname(out_path), exist_ok=True)
                 torch.save(feat.squeeze().cpu().clone(), out_path)
                 written += 1
-            pending = nxt
     return written
 
 

@@ -35,10 +35,11 @@ import contextlib
 import io
 with contextlib.redirect_stdout(io.StringIO()):
     EF.process_images(os.path.join(root, "warm", "JPEGImages"), os.path.join(root, "warm", "out"), workers=8)
-for tag, workers, devpre in (("serial decode + host resize (reference order)", 1, False), ("decode pool x8, host resize", 8, False),
-                             ("decode pool x32, host resize", 32, False), ("decode x1, device resize/normalise", 1, True),
-                             ("decode pool x32, device resize/normalise", 32, True)):
+for tag, workers, devpre, devdec in (("serial decode + host resize (reference order)", 1, False, False), ("decode pool x8, host resize", 8, False, False),
+                                     ("decode pool x32, host resize", 32, False, False), ("PIL decode pool x32, device resize/normalise", 32, True, False),
+                                     ("host Huffman x32 + device IDCT/colour/resize/normalise", 32, True, True)):
     EF._state.device_preprocess = devpre
+    EF._state.device_decode = devdec
     dst = os.path.join(root, f"features_{workers}_{int(devpre)}")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -47,6 +48,48 @@ for tag, workers, devpre in (("serial decode + host resize (reference order)", 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out[tag] = {"images_per_s": round(n / dt, 1), "seconds": round(dt, 2)}
+# decode alone: files -> RGB u8 in HBM (device decoder, batches of 64) against PIL on a 32-thread pool -> host arrays
+from law_of_vision_representation_in_mllms_amd import device_jpeg as DJ
+from concurrent.futures import ThreadPoolExecutor
+files = [os.path.join(src, f"im{i:05d}.jpg") for i in range(n)]
+dec = DJ.DeviceJpegDecoder("cuda:0", threads=32)
+dec.decode(files[:64])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+pend = dec.submit(files[:64])
+t_wait = t_fin = 0.0
+for s0 in range(0, n, 64):
+    nxt = dec.submit(files[s0 + 64: s0 + 128]) if s0 + 64 < n else None
+    a = time.perf_counter()
+    for f in pend:
+        f.result()
+    b = time.perf_counter()
+    dec.finish(pend)
+    t_wait += b - a
+    t_fin += time.perf_counter() - b
+    pend = nxt
+torch.cuda.synchronize()
+out["decode only: host Huffman x32 + device reconstruct"] = {"images_per_s": round(n / (time.perf_counter() - t0), 1), "wait_for_host_stage_s": round(t_wait, 3),
+                                                             "assemble_upload_launch_s": round(t_fin, 3), "stats": {k: v for k, v in dec.stats.items() if k != "pil_reasons"}}
+with ThreadPoolExecutor(32) as pool:
+    t0 = time.perf_counter()
+    list(pool.map(lambda f: np.asarray(Image.open(f).convert("RGB")), files))
+    out["decode only: PIL pool x32 (host arrays)"] = {"images_per_s": round(n / (time.perf_counter() - t0), 1)}
+# the whole input pipeline alone: files -> [B, 3, 224, 224] normalised pixel batches in HBM (what the tower consumes), no tower, no files out
+chunks = [[(f, None) for f in files[s0:s0 + 64]] for s0 in range(0, n, 64)]
+EF._state.img_size = 224
+for tag, gen in (("input pipeline only: host Huffman x32 + device reconstruct/resize/normalise", lambda: EF._prefetched_device_decode(chunks, "cuda:0")),
+                 ("input pipeline only: PIL decode pool x32 + device resize/normalise", lambda: EF._prefetched(chunks, EF._decode_rgb, 32, EF._finish_on_device)),
+                 ("input pipeline only: PIL decode + PIL resize pool x32 (host), upload", lambda: ((c, px.cuda()) for c, px in EF._prefetched(chunks, EF._load_pixels_worker, 32)))):
+    for _ in gen():
+        break
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cnt = 0
+    for _, px in gen():
+        cnt += px.shape[0]
+    torch.cuda.synchronize()
+    out[tag] = {"images_per_s": round(cnt / (time.perf_counter() - t0), 1)}
 # tower alone on resident pixels, same batch size
 px = torch.randn(64, 3, 224, 224).to(torch.bfloat16).cuda()
 f = EF._state.dift.forward
