@@ -31,6 +31,14 @@ struct GemmF32Args {
 
 constexpr int FBM = 128, FBN = 128, FBK = 16, FLD = 132;   // FLD: LDS row stride (floats); 132 * 4 B keeps 16-B alignment, 2-way write conflicts at most
 
+// LDS fragment pair (rows r and r + 32 of one k) and its counted wait as asm (see the K loop)
+VR_DEV unsigned lds_addr_f32(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+VR_DEV void lds_read2_f32(f32x2& f, unsigned addr) { asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(f) : "v"(addr)); }
+template <int N> VR_DEV void lds_wait2_f32(f32x2& a, f32x2& b) {
+    if (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b));
+}
+
 VR_DEV float act_f32(float x, int act) {
     switch (act) {
         case ACT_QUICK_GELU: return x * (1.0f / (1.0f + expf(-1.702f * x)));          // x * sigmoid(1.702 x) (HF QuickGELUActivation)
@@ -92,12 +100,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
         }
     }
     float4 ra[2], rw[2];
+    // Interior K-steps (and, for the [K, N] operand, interior column blocks) take one branch-free path: the per-thread tail tests of
+    // load_k4 / load_n4 inside the K loop cost a divergent branch + s_waitcnt per load (gemm_f32 ran at 0.61-0.68 of the fp32 MFMA roof
+    // with them, profiles/round3_f32.md); only the last partial K-step / the last column block keeps the element-wise path.
+    const bool n_interior = n0 + FBN <= p.N;                      // uniform
     auto fetch = [&](int k0) {
+        const bool full = k0 + FBK <= p.K;                       // uniform
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ra[j] = load_k4(arow[j], k0 + 4 * sc, p.K);
+            for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const float4*>(arow[j] + k0 + 4 * sc);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra[j] = load_k4(arow[j], k0 + 4 * sc, p.K);
+        }
         if (!p.w_kn) {
+            if (full) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) rw[j] = load_k4(wrow[j], k0 + 4 * sc, p.K);
+                for (int j = 0; j < 2; ++j) rw[j] = *reinterpret_cast<const float4*>(wrow[j] + k0 + 4 * sc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rw[j] = load_k4(wrow[j], k0 + 4 * sc, p.K);
+            }
+        } else if (full && n_interior) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rw[j] = *reinterpret_cast<const float4*>(W + (size_t)(k0 + kr + 8 * j) * p.ldw + n0 + 4 * nc);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -139,10 +165,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) fetch((kt + 1) * FBK);                 // next K-step in flight under this step's MFMAs
+        // one MFMA k-step = 2 k: lane half `hi` supplies k = 2 kk + hi.  The fragments of step kk + 1 are read BEFORE the four MFMAs of
+        // step kk are issued.  hipcc serialises them whatever the source order (ds_read, lgkmcnt(0), 4 MFMAs, ds_read, ... - the MFMAs of a
+        // step waited for that step's LDS latency), so the reads and their counted waits are asm: the compiler cannot re-merge them.
+        const unsigned aaddr = lds_addr_f32(&As[buf][hi][wm * 64 + lq]), waddr = lds_addr_f32(&Ws[buf][hi][wn * 64 + lq]);
+        f32x2 fa[2], fw[2];
+        lds_read2_f32(fa[0], aaddr);
+        lds_read2_f32(fw[0], waddr);
 #pragma unroll
-        for (int kk = 0; kk < FBK / 2; ++kk) {                  // one MFMA k-step = 2 k: lane half `hi` supplies k = 2 kk + hi
-            const float a0 = As[buf][2 * kk + hi][wm * 64 + lq], a1 = As[buf][2 * kk + hi][wm * 64 + 32 + lq];
-            const float w0 = Ws[buf][2 * kk + hi][wn * 64 + lq], w1 = Ws[buf][2 * kk + hi][wn * 64 + 32 + lq];
+        for (int kk = 0; kk < FBK / 2; ++kk) {
+            const int c = kk & 1;
+            if (kk + 1 < FBK / 2) {
+                lds_read2_f32(fa[c ^ 1], aaddr + (kk + 1) * 2 * FLD * 4);
+                lds_read2_f32(fw[c ^ 1], waddr + (kk + 1) * 2 * FLD * 4);
+                lds_wait2_f32<2>(fa[c], fw[c]);
+            } else {
+                lds_wait2_f32<0>(fa[c], fw[c]);
+            }
+            const float a0 = fa[c][0], a1 = fa[c][1], w0 = fw[c][0], w1 = fw[c][1];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w0, acc[1][0], 0, 0, 0);
@@ -172,6 +212,140 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
             }
         }
     }
+}
+
+// Fused fp32 attention forward for head width 64 (flash style, exact-fp32 MFMA): replaces the three batched launches
+// scores = scale Q K^T -> softmax rows -> P V with their [B, H, T, T] fp32 round trips through HBM (5.4 GB written, re-read three times per
+// layer at batch 256: 27 % of the fp32 tower's time for 9 % of its FLOP, profiles/round3_f32.md) by one kernel whose scores never leave
+// the registers.  Same structure as the bf16 attn_fwd<1> (attention.hip), fp32 operands:
+//   * block = 4 waves x 32 query rows; key tiles of 64 start at the image's first token (fp32 Q | K | V are plain row-major [M, 3 d]
+//     buffers, no transposed-V alignment constraint): only an image's LAST tile is masked;
+//   * S^T = K Q^T with v_mfma_f32_32x32x2_f32 (A = K fragment from LDS, B = Q fragment: 32 registers hold this lane's Q row for the
+//     whole kernel); lane (q = lane & 31, hi) then holds keys (r & 3) + 8 (r >> 2) + 4 hi of each 32-key block in register r;
+//   * O^T += V^T P^T feeds register r of S as the B operand of k-step r: the MFMA's k index is a summation index, so both operands only
+//     have to agree on the key - the A fragment is V[key(r, hi)][d] read straight from the row-major V tile;
+//   * K / V tiles are [64][65] fp32 in LDS (the odd row stride makes the column reads of the K fragments conflict free), double
+//     buffered, staged through registers; running maximum / sum in fp32, exp2 of the scaled difference like the bf16 kernel.
+// Arithmetic is fp32 throughout; against HF's eager softmax the results differ by summation order only (~1e-6 relative).
+}  // namespace
+int g_visrep_f32_unfused_attention = 0;   // diagnostic: 1 = the three-launch attention (batched Q K^T -> softmax rows -> P V) for every head width
+namespace {
+
+struct AttnF32Args {
+    const float* q; const float* k; const float* v; float* out;
+    int B, T, H, ld, ldo;
+    float sc;                                                 // scale * log2(e)
+};
+constexpr int AKT = 64, ALD = 65;
+
+__global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnF32Args p) {
+    __shared__ float Ks[2][AKT][ALD];
+    __shared__ float Vs[2][AKT][ALD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int nqt = (p.T + 127) >> 7;
+    int id = blockIdx.x;
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % p.H;
+    const int b = id / p.H;
+    const size_t tok0 = (size_t)b * p.T;
+    const int qloc = qt * 128 + wave * 32 + lq;
+    const float* qrow = p.q + (tok0 + (qloc < p.T ? qloc : p.T - 1)) * p.ld + h * 64;
+    float qf[32];                                             // B operand of k-step j: Q[q][2 j + hi]
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qf[j] = qrow[2 * j + hi];
+    f32x16 o[2];
+    o[0] = f32x16{}; o[1] = f32x16{};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntile = (p.T + AKT - 1) / AKT;
+    // staging: 64 rows x 16 float4 per tile and operand = 4 float4 per thread
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+    float4 rk[4], rv[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = t * AKT + srow + 16 * j;
+            const size_t row = tok0 + (key < p.T ? key : p.T - 1);       // keys past the image are masked below: re-read the last row
+            rk[j] = *reinterpret_cast<const float4*>(p.k + row * p.ld + h * 64 + sc4);
+            rv[j] = *reinterpret_cast<const float4*>(p.v + row * p.ld + h * 64 + sc4);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* kd = &Ks[buf][srow + 16 * j][sc4];
+            float* vd = &Vs[buf][srow + 16 * j][sc4];
+            kd[0] = rk[j].x; kd[1] = rk[j].y; kd[2] = rk[j].z; kd[3] = rk[j].w;
+            vd[0] = rv[j].x; vd[1] = rv[j].y; vd[2] = rv[j].z; vd[3] = rv[j].w;
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const bool idle = qt * 128 + wave * 32 >= p.T;            // a wave whose 32 rows are all past the sequence only stages
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) fetch(t + 1);
+        if (!idle) {
+            f32x16 s[2];
+            s[0] = f32x16{}; s[1] = f32x16{};
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][lq][2 * j + hi], qf[j], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][32 + lq][2 * j + hi], qf[j], s[1], 0, 0, 0);
+            }
+            if ((t + 1) * AKT > p.T) {                            // the image's last tile (uniform)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * AKT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.T) s[kb][r] = -INFINITY;
+            }
+            float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s[0][r], s[1][r]));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);               // finite: every tile holds at least one valid key
+            const float msc = m_new * p.sc;
+            const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, p.sc, -msc));
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], p.sc, -msc));
+                    s[kb][r] = pv;
+                    psum += pv;
+                }
+            l_run = __builtin_fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            // O^T[d][q] += sum over keys V[key][d] P[q][key]: k-step = (key block kb, register r), lane half hi supplies key(r, hi)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][key][lq], s[kb][r], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][key][32 + lq], s[kb][r], o[1], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntile) stash(buf ^ 1);                      // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    if (idle || qloc >= p.T) return;
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_run;
+    // lane holds O[q][d = dt * 32 + (r & 3) + 8 (r >> 2) + 4 hi]
+    float* orow = p.out + (tok0 + qloc) * p.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 v4 = {o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv};
+            *reinterpret_cast<float4*>(orow + dt * 32 + rg * 8 + hi * 4) = v4;
+        }
 }
 
 // LayerNorm over the last dimension, fp32 throughout, two-pass variance (mean first, then the centred squares) - one wave per row
@@ -420,17 +594,24 @@ extern "C" int visrep_vit_forward_f32(const visrep_vit_config* c, const visrep_v
         a.alpha = 1.f; a.nb2 = 1;
         a.A = h; a.lda = d; a.K = d; a.M = M; a.W = (const float*)W.wqkv; a.ldw = d; a.N = 3 * d; a.C = qkv; a.ldc = 3 * d; a.bias = W.bqkv; a.epi = EPI_BIAS;
         VR_TRY(launch_gemm_f32(a, 1, s));
+        if (dh == 64 && !g_visrep_f32_unfused_attention) {
+            // fused flash-style fp32 attention: scores stay in registers (attn_f32_kernel)
+            AttnF32Args at{qkv, qkv + d, qkv + 2 * d, h, B, T, H, 3 * d, d, scale * 1.4426950408889634f};
+            hipLaunchKernelGGL(attn_f32_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
+            if (hipGetLastError() != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32: attention launch failed");
+        } else {
         // scores[b, head] = scale * Q K^T   (batched over image b1 and head b2)
-        GemmF32Args q{};
-        q.A = qkv; q.lda = 3 * d; q.W = qkv + d; q.ldw = 3 * d; q.C = sc; q.ldc = L.lds; q.M = T; q.N = T; q.K = dh; q.epi = EPI_BIAS; q.alpha = scale;
-        q.nb2 = H; q.sA1 = (long)T * 3 * d; q.sA2 = dh; q.sW1 = (long)T * 3 * d; q.sW2 = dh; q.sC1 = (long)H * T * L.lds; q.sC2 = (long)T * L.lds;
-        VR_TRY(launch_gemm_f32(q, B * H, s));
-        VR_TRY(visrep_softmax_rows_f32(sc, L.lds, (long)B * H * T, T, stream));
-        // context[b, :, head] = P V
-        GemmF32Args v{};
-        v.A = sc; v.lda = L.lds; v.W = qkv + 2 * d; v.ldw = 3 * d; v.w_kn = 1; v.C = h; v.ldc = d; v.M = T; v.N = dh; v.K = T; v.epi = EPI_BIAS; v.alpha = 1.f;
-        v.nb2 = H; v.sA1 = (long)H * T * L.lds; v.sA2 = (long)T * L.lds; v.sW1 = (long)T * 3 * d; v.sW2 = dh; v.sC1 = (long)T * d; v.sC2 = dh;
-        VR_TRY(launch_gemm_f32(v, B * H, s));
+            GemmF32Args q{};
+            q.A = qkv; q.lda = 3 * d; q.W = qkv + d; q.ldw = 3 * d; q.C = sc; q.ldc = L.lds; q.M = T; q.N = T; q.K = dh; q.epi = EPI_BIAS; q.alpha = scale;
+            q.nb2 = H; q.sA1 = (long)T * 3 * d; q.sA2 = dh; q.sW1 = (long)T * 3 * d; q.sW2 = dh; q.sC1 = (long)H * T * L.lds; q.sC2 = (long)T * L.lds;
+            VR_TRY(launch_gemm_f32(q, B * H, s));
+            VR_TRY(visrep_softmax_rows_f32(sc, L.lds, (long)B * H * T, T, stream));
+            // context[b, :, head] = P V
+            GemmF32Args v{};
+            v.A = sc; v.lda = L.lds; v.W = qkv + 2 * d; v.ldw = 3 * d; v.w_kn = 1; v.C = h; v.ldc = d; v.M = T; v.N = dh; v.K = T; v.epi = EPI_BIAS; v.alpha = 1.f;
+            v.nb2 = H; v.sA1 = (long)H * T * L.lds; v.sA2 = (long)T * L.lds; v.sW1 = (long)T * 3 * d; v.sW2 = dh; v.sC1 = (long)T * d; v.sC2 = dh;
+            VR_TRY(launch_gemm_f32(v, B * H, s));
+        }
         // out projection + LayerScale + residual (in place on x)
         a.A = h; a.W = (const float*)W.wo; a.N = d; a.C = x; a.ldc = d; a.bias = W.bo; a.epi = EPI_RESID; a.resid = x; a.ls = W.ls1;
         VR_TRY(launch_gemm_f32(a, 1, s));

@@ -142,6 +142,29 @@ def test_f32_tower_hidden_states_and_chunk_invariance():
     assert torch.equal(a[: px.shape[0]], eng.forward(px.to(DEV)))
 
 
+@pytest.mark.parametrize("family,image,patch", [("clip", 70, 14), ("dinov2", 154, 14), ("siglip", 48, 16)])
+def test_fused_f32_attention_matches_the_three_launch_path_and_the_oracle(family, image, patch):
+    """Head width 64 runs the fused flash-style fp32 attention (attn_f32_kernel: scores never leave the registers); the three-launch
+    path (batched Q K^T -> softmax rows -> P V through HBM, what other head widths run) and the fp32 oracle are the checks.  Token counts
+    26 (one partial key tile), 122 (two tiles, the second masked from key 58) and 9."""
+    import ctypes
+    spec = VW.tiny_spec(family, image_size=image, patch=patch, d=128, heads=2, mlp=256, layers=3)           # head width 64
+    w = VW.synthetic_weights(spec, seed=5)
+    px = torch.from_numpy(np.random.RandomState(3).standard_normal((3, 3, image, image)).astype(np.float32))
+    eng = engine.VitEngineF32(spec, w, DEV)
+    flag = ctypes.c_int.in_dll(_lib.load(), "g_visrep_f32_unfused_attention")
+    fused = eng.forward(px.to(DEV))
+    flag.value = 1
+    try:
+        unfused = eng.forward(px.to(DEV))
+    finally:
+        flag.value = 0
+    want = OV.vit_hidden_states(spec, w, px)[spec.layers]
+    assert rel(fused, unfused) < 2e-6 and rel(fused, want) < 5e-6 and rel(unfused, want) < 5e-6
+    assert torch.equal(fused, eng.forward(px.to(DEV)))                         # deterministic
+    assert torch.equal(fused[1:2], eng.forward(px[1:2].to(DEV)))               # and independent of the batch around an image
+
+
 def test_tower_class_precision_switch(monkeypatch):
     from law_of_vision_representation_in_mllms_amd.llava.model import llava_arch as LA
     spec = VW.tiny_spec("dinov2", image_size=42, patch=14, d=128, heads=2, mlp=256, layers=3)

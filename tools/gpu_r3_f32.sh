@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r3f32
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/tools/f32_probe.py 64 > $O/probe.log 2>&1
+cat $O/probe.log | grep -v amdgpu
+cd $R; python tools/summarize_pmc.py gpurun_out/r3f32 "." 2>&1 | head -24
