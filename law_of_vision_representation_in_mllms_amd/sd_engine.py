@@ -82,6 +82,12 @@ def geglu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+# Injection point for reproducible features: callable(images [B*ensemble, 3, H, W] on the device, noise shape) -> (post_noise,
+# ddim_noise).  None = the reference's behaviour, two torch.randn draws per call.  The towers' forward(images) has no noise arguments
+# (llava's tower protocol), so a test that needs the SAME features for the same image whatever the batch around it sets this.
+NOISE_FN = None
+
+
 def attention(q, k, vt, out_cols: int, B: int, Tq: int, Tk: int, H: int, head_dim: int, scale: float, kv_shared: bool,
               causal: bool = False) -> torch.Tensor:
     lib = _lib.require_gpu()
@@ -524,6 +530,8 @@ class SdEngine:
         Be = B * ensemble_size
         f = 2 ** (len(sp.vae.block_out) - 1)
         shape = (Be, sp.vae.latent_channels, x.shape[2] // f, x.shape[3] // f)
+        if post_noise is None and ddim_noise is None and NOISE_FN is not None:
+            post_noise, ddim_noise = NOISE_FN(x, shape)
         post = torch.randn(shape, device=self.device) if post_noise is None else post_noise.to(self.device, torch.float32).contiguous()
         ddim = torch.randn(shape, device=self.device) if ddim_noise is None else ddim_noise.to(self.device, torch.float32).contiguous()
         if tuple(post.shape) != shape or tuple(ddim.shape) != shape:

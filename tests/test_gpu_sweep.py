@@ -109,6 +109,88 @@ def test_encoder_sharded_a_score_equals_image_sharded_on_device(tiny_registry):
         assert abs(a["per_setting"][st.name]["A"] - b[st.name]) < 1e-12, st.name
 
 
+# ------------------------------------------------------------------------------------------------ all thirteen setting KINDS
+def _tiny_diffusion_registry(monkeypatch):
+    """Tiny architectures behind the six diffusion tower ids (synthetic weights), and a noise source that depends on the image only."""
+    from dataclasses import replace
+    from law_of_vision_representation_in_mllms_amd import sd_engine as SE, sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM import diffusion_encoder as DE
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM.src.models import dift_sd as DS, dift_sd3 as D3
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    txt = lambda act="quick_gelu": SW.TextSpec(vocab=99, d=64, mlp=128, layers=2, heads=1, max_pos=11, act=act)
+    xl = SW.tiny_sdxl_spec()
+    xl = replace(xl, unet=replace(xl.unet, cross_dim=128))                     # two 64-wide text encoders, concatenated
+    monkeypatch.setitem(SW.SD_SPECS, S.SD15, SW.tiny_sd_spec("tiny-sd15"))
+    monkeypatch.setitem(SW.SD_SPECS, S.SD21, SW.tiny_sd_spec("tiny-sd21", linear_projection=True))
+    monkeypatch.setitem(SW.SD_SPECS, S.SDXL, xl)
+    for k, v in ((S.SD15, txt()), (S.SD21, txt("gelu")), (S.SDXL, txt())):
+        monkeypatch.setitem(DS._SYNTH_TEXT, k, v)
+    monkeypatch.setitem(DS._SYNTH_TEXT_2, S.SDXL, txt("gelu"))
+    monkeypatch.setitem(SW.DIT_SPECS, S.DIT, SW.tiny_dit_spec())
+    s3 = SW.tiny_sd3_spec()
+    monkeypatch.setitem(SW.SD3_SPECS, S.SD3, replace(s3, core=replace(s3.core, joint_dim=128, pooled_dim=128)))
+    monkeypatch.setattr(D3, "_SYNTH_TEXT", (txt(), txt("gelu")))
+    widths = {S.SD15: 128, S.SD21: 128, S.SDXL: 128, S.IMSD: 128, S.DIT: 4 * 8 * 72, S.SD3: 4 * 2 * 64}
+    for k, v in widths.items():
+        monkeypatch.setitem(DE.feature_hid_size_mapping, k, v)
+
+    def noise(x, shape):                                                        # per image: a fixed function of its pixels
+        out = []
+        for k in range(2):
+            rows = []
+            for i in range(shape[0]):
+                g = torch.Generator(device=x.device).manual_seed(int(x[i].float().abs().sum().item() * 64) % (2 ** 31) + k)
+                rows.append(torch.randn(shape[1:], generator=g, device=x.device))
+            out.append(torch.stack(rows))
+        return out
+    monkeypatch.setattr(SE, "NOISE_FN", noise)
+
+
+ALL13 = SETTINGS[:2] + (S.Setting("OpenCLIP", "openclip", (S.OPENCLIP,), 42, 4), SETTINGS[2], S.Setting("SDim", "imsd", (S.IMSD,), 64, 3),
+                        S.Setting("SD1.5", "sd1.5", (S.SD15,), 64, 4), S.Setting("SDXL", "sdxl", (S.SDXL,), 64, 3), S.Setting("DiT", "dit", (S.DIT,), 64, 4),
+                        S.Setting("SD3", "sd3", (S.SD3,), 64, 3), S.Setting("SD2.1", "sd2.1", (S.SD21,), 64, 4), SETTINGS[3], SETTINGS[4],
+                        S.Setting("CLIP336+DINOv2", "clip336+dino", (S.CLIP336, S.DINOV2), 56, 3))
+
+
+def test_sweep_covers_all_thirteen_setting_kinds(tiny_registry, monkeypatch):
+    """the sweep test covered 5 of the 13 settings.  All thirteen kinds (policy/fit.py:20) with tiny architectures: every
+    setting's A score and weighted PCK out of run_sweep (one batched, image-sharded tower pass, banks scattered by category owner) must
+    equal the SAME towers run one image at a time through the oracle score functions - which pins the sweep's own plumbing (launch plan
+    and its tails, '.'-fusion concat and `split`, bank rows, map layout) for the diffusion and 336-fusion settings too."""
+    monkeypatch.setitem(VW.SPECS, S.OPENCLIP, VW.tiny_spec("clip", act="gelu", image_size=42, patch=14, d=128, heads=2, mlp=256, layers=3))
+    monkeypatch.setitem(TINY, S.OPENCLIP, VW.SPECS[S.OPENCLIP])
+    _tiny_diffusion_registry(monkeypatch)
+    assert [s.name for s in ALL13] == [s.name for s in S.SETTINGS]
+    models = {}
+
+    def build(st):
+        models[st.name] = S.SettingModel(st, DEV, hidden=HIDDEN, precision="bf16", fast_weights=False)
+        return models[st.name]
+    spair = spair_small()
+    out = S.run_sweep(ALL13, N_A, spair, DEV, build=build)
+    assert out["settings"] == 13
+    pix = lambda ids, size: S.synthetic_pixels(ids, size, DEV, torch.bfloat16)
+    one = lambda m, gid: m.tokens(pix([gid], m.setting.size))                   # batch of one: no launch plan, no bank
+    feats = {st.key: torch.cat([models[st.name].project(one(models[st.name], i)).float().cpu() for i in range(N_A)]) for st in ALL13}
+    for st in ALL13:
+        m, ent = models[st.name], out["per_setting"][st.name]
+        A = OA.a_score(list(feats[st.key]), list(feats["clip336"]), list(feats["clip224"]))[0]
+        assert abs(ent["A"] - A) <= 2e-3 * abs(A) + 1e-4, (st.name, ent["A"], A)   # bf16 features; the sweep's score kernel vs the fp64 oracle
+        per_cat, weights = [], []
+        for ci, cat in enumerate(spair):
+            maps = torch.cat([one(m, ci * 100000 + i).float().cpu() for i in range(cat.n_images)])
+            P = int(round(maps.shape[1] ** 0.5))
+            fl = []
+            for sl in cat.slot:
+                mp = maps[int(sl)]
+                if len(st.towers) == 2:
+                    mp = OC.normalize_feats_two(mp[None], m.split)[0]
+                fl.append(mp.t().reshape(1, -1, P, P))
+            per_cat.append(OC.category_pck(fl, list(range(len(cat.thresholds))), cat.kps, cat.thresholds, P)[1][:3])
+            weights.append(len(cat.thresholds))
+        np.testing.assert_allclose(ent["pck"], OC.weighted_pcks(per_cat, weights), atol=0.04, err_msg=st.name)   # <= 1-2 of ~150 key points may flip
+
+
 def _torchrun(n, *cmd, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     port = 29600 + os.getpid() % 300
