@@ -50,6 +50,11 @@ int visrep_set_gemm_variant(int variant);
  * by MFMA (csrc/attention_ab.hip; measured equal-to-slower, profiles/round3_attention.md).  Returns the previous value.  Results
  * agree to the bf16 rounding of P. */
 int visrep_set_attn_variant(int variant);
+/* Tile shape of the bf16 A-score Gram (visrep_ascore_maxcos*): 0 (default) = whichever launches the smaller tile area for (Nt, Nr);
+ * 1 = one 128 x 128 tile per workgroup; 2 = persistent ping-pong tiles of 192 or 256 rows per operand (the GEMM default's structure;
+ * 576 = 3 x 192, 256 = 1 x 256).
+ * Returns the previous value.  Results are identical up to fp32 summation order (none: both sum k in the same order per MFMA chain). */
+int visrep_set_ascore_variant(int variant);
 /* Timing-only ablation of GEMM variant 2 (bit 0: skip MFMAs, bit 1: skip the LDS-DMA loads, bit 2: skip the fragment reads):
  * results are WRONG for mask != 0; used by tools/gemm_ablate.py to attribute cycles.  Returns the previous mask. */
 int visrep_debug_gemm_ablation(int mask);
@@ -309,6 +314,18 @@ int visrep_resample_u8(const void* in, void* out, long n_lines, int out_len, int
  * out: [3, crop_h, crop_w] VISREP_F32 or VISREP_BF16. */
 int visrep_u8hwc_to_chw_norm(const void* in, int H, int W, int x0, int y0, int crop_h, int crop_w, const float* mean3, const float* std3,
                              void* out, int dtype, void* stream);
+
+/* Both resampling passes + crop + ToTensor + Normalize for a BATCH of images of different sizes in two launches - what
+ * `processor.preprocess(expand2square(Image.open(p).convert('RGB')))` (llava/feature/extract.py:198-214, llava/mm_utils.py:78-95) and
+ * `Image.open(p).convert('RGB').resize((s, s))` + `(x / 255 - 0.5) * 2` (C_score/extract_feature.py:65-70) do per image, bit for bit.
+ * desc: DEVICE int64 [n_images][24]: 0 source pointer (uint8 [H, W, 3] on the device), 1 H, 2 W, 3-4 canvas height / width (= H, W, or
+ * the padded square of expand2square), 5-6 row / column of the image inside the canvas, 7 background colour r | g << 8 | b << 16,
+ * 8 mirror the image left-right (pck_train.py:112), 9 pointer to this image's scratch [rows, crop_w, 3] for the horizontal pass,
+ * 10-11 first canvas row / row count of that scratch (the rows the vertical pass reads), 12-14 horizontal bounds pointer / coefficient
+ * pointer / ksize (ksize 0: no horizontal resize), 15-17 the same for the vertical pass, 18-19 crop origin x0, y0 in the resized image.
+ * max_mid_rows = max over images of field 11 with ksize != 0 (0: no image needs a horizontal pass).  out: [n_images, 3, crop_h, crop_w]. */
+int visrep_preprocess_u8_batch(const void* desc, int n_images, long max_mid_rows, int crop_h, int crop_w, const float* mean3,
+                               const float* std3, void* out, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -151,9 +151,8 @@ def _prefetched_device_decode(chunks, device="cuda"):
     for i, chunk in enumerate(chunks):
         nxt = dec.submit([p for p, _ in chunks[i + 1]]) if i + 1 < len(chunks) else None
         imgs = dec.finish(pending)
-        if getattr(_state, "flip", False):
-            imgs = [im.flip(1) for im in imgs]                           # Image.FLIP_LEFT_RIGHT
-        yield chunk, torch.stack([DP.to_tensor(DP.resize_u8(im, (size, size)), (0, 0, size, size), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)) for im in imgs])
+        yield chunk, DP.preprocess_batch(imgs, [(size, size)] * len(imgs), [(0, 0, size, size)] * len(imgs), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5),
+                                         flip=getattr(_state, "flip", False))       # flip: Image.FLIP_LEFT_RIGHT, folded into the fetch
         pending = nxt
 
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "visrep_last_error": (_sz, [C.c_char_p, _sz]),
     "visrep_set_gemm_variant": (_i, [_i]),
     "visrep_set_attn_variant": (_i, [_i]),
+    "visrep_set_ascore_variant": (_i, [_i]),
     "visrep_debug_gemm_ablation": (_i, [_i]),
     "visrep_debug_gemm_timing_buffer": (_i, [_vp]),
     "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "visrep_nchw_to_tokens": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_resample_u8": (_i, [_vp, _vp, _l, _i, _i, _l, _l, _l, _l, _vp, _vp, _i, _vp]),
     "visrep_u8hwc_to_chw_norm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _vp]),
+    "visrep_preprocess_u8_batch": (_i, [_vp, _i, C.c_long, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _vp]),
     "visrep_resize_bilinear": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_sd_noisy_latents": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "visrep_mean_groups": (_i, [_vp, _vp, _i, _i, _l, _vp]),

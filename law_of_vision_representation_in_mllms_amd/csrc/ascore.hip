@@ -14,8 +14,12 @@
 //             bf16 inputs: v_mfma_f32_32x32x16_bf16 (products exact in fp32, fp32 accumulate)
 //             fp32 inputs: 4 x v_mfma_f32_32x32x2_f32 per 16-B load (exact fp32 FMA chain)
 //   pass 3  ascore_finalize  : score[img] = sum(partials) / Nt   (fixed order -> deterministic)
+#include <type_traits>
+
 #include "common.h"
 #include "visrep_internal.h"
+
+int g_visrep_ascore_variant = 0;   // 0 = pick by launched tile area, 1 = 128 x 128 tiles, 2 = persistent ping-pong tiles (visrep_set_ascore_variant)
 
 namespace {
 
@@ -272,6 +276,238 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
     }
 }
 
+// ---- persistent ping-pong Gram (round 3): the structure of the default GEMM (gemm_bf16_v5.hip) at tile sizes that divide the token
+// stacks.  576 = 4.5 tiles of 128: the 128 x 128 kernel above launches 25 tile pairs per image for 20.25 tile pairs of work, and two
+// 128 x 128 workgroups per CU pull 64 KB of operands per 1024 matrix-pipe cycles through the CU's L2 port (62 B/clk at MFMA peak).
+// Here a tile is TM x TN with TM, TN in {192, 256} picked per operand (576 = 3 x 192, 256 = 1 x 256, 729 -> 768): no dead area on
+// the encoder shapes of the sweep.  Eight waves in two groups of four skewed by one barrier (one wave per SIMD is always in an MFMA
+// segment), wave tile (TM / 2) x (TN / 4) = MI x NJ accumulators of 16x16x32, K-tiles of 64 in 128-byte LDS rows, a ring of five 32-KB
+// operand slots fed by LDS-DMA with counted waits (X0 W0 X1 W1 ...: while tile s is consumed W(s+1) and X(s+2) stream in), hand-written
+// fragment reads (MI + NJ ds_read_b128 per k-half against MI * NJ MFMAs), persistent XCD-contiguous tile walk: the 32 workgroups of
+// an XCD work on 32 consecutive tiles (a few images) and walk D in step, so an operand slab is fetched from HBM once.  The barrier /
+// hazard ledger is gemm_bf16_v5.hip's (OWN_ = false) with TM / 64 and TN / 64 LDS-DMA pieces per wave instead of four.
+// Epilogue: scale by c_ref, mask s >= Nr, row max over the wave's TN / 4 reference rows -> partial[img][t][4 nt + wn]; the finalize
+// kernel takes the max over the 4 * nnt parts.
+constexpr int P_TK = 64, P_SLOT = 256 * P_TK * 2, P_NSLOT = 5, P_LDS = P_NSLOT * P_SLOT;   // 32 KB x 5 = all of the CU's LDS
+
+VR_DEV unsigned a_lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+// Fragment reads and their wait are asm: hipcc cannot tell an LDS read from the bytes an in-flight LDS-DMA will write and would put
+// s_waitcnt vmcnt(0) in front of every read it can see, draining the prefetch ring.  The wait names every destination read-write, so no
+// consumer (or copy) of a fragment can be scheduled above it; ordering against the DMA is the ledger of gemm_bf16_v5.hip.
+template <int OFF> VR_DEV void a_read(bf16x8& f, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF)); }
+template <int N> VR_DEV void a_reads(bf16x8 (&f)[N], unsigned addr) {
+    a_read<0>(f[0], addr); a_read<2048>(f[1], addr); a_read<4096>(f[2], addr);
+    if constexpr (N > 3) a_read<6144>(f[3], addr);
+    if constexpr (N > 4) { a_read<8192>(f[4], addr); a_read<10240>(f[5], addr); }
+    if constexpr (N > 6) { a_read<12288>(f[6], addr); a_read<14336>(f[7], addr); }
+}
+#define A_PIN3(f) "+v"(f[0]), "+v"(f[1]), "+v"(f[2])
+#define A_PIN4(f) A_PIN3(f), "+v"(f[3])
+#define A_PIN6(f) A_PIN4(f), "+v"(f[4]), "+v"(f[5])
+#define A_PIN8(f) A_PIN6(f), "+v"(f[6]), "+v"(f[7])
+template <int N> VR_DEV void a_pin(bf16x8 (&f)[N], bool wait) {      // wait: s_waitcnt lgkmcnt(0) in the statement; else a pure ordering point
+    static_assert(N == 3 || N == 4 || N == 6 || N == 8, "fragment count");
+    if (wait) {
+        if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : A_PIN3(f));
+        if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : A_PIN4(f));
+        if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(0)" : A_PIN6(f));
+        if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(0)" : A_PIN8(f));
+    } else {
+        if constexpr (N == 3) asm volatile("" : A_PIN3(f));
+        if constexpr (N == 4) asm volatile("" : A_PIN4(f));
+        if constexpr (N == 6) asm volatile("" : A_PIN6(f));
+        if constexpr (N == 8) asm volatile("" : A_PIN8(f));
+    }
+}
+VR_DEV void a_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> VR_DEV void a_wait_vm() {
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
+
+template <int MI, int NJ>
+__global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
+    constexpr int TM = 32 * MI, TN = 64 * NJ;                  // 192 or 256 target rows x 192 or 256 reference rows per tile
+    constexpr int PX = TM / 64, PW = TN / 64;                  // 8-row LDS-DMA pieces per wave and K-tile
+    static_assert((MI == 6 || MI == 8) && (NJ == 3 || NJ == 4), "tile shapes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int ntt = (p.Nt + TM - 1) / TM, nnt = (p.Nr + TN - 1) / TN, per_img = ntt * nnt, ntiles = p.n_img * per_img;
+    // ---- persistent tile list: XCD-contiguous chunks (block b runs on XCD b % 8), strided by the blocks of that XCD
+    int t_start, t_stride, t_count;
+    {
+        const int G = gridDim.x;
+        const int nx = G < 8 ? G : 8;
+        const int x = blockIdx.x % nx, j = blockIdx.x / nx;
+        const int per = (G + nx - 1 - x) / nx;
+        const int q = ntiles / nx, r = ntiles % nx;
+        const int cstart = x * q + (x < r ? x : r), csize = q + (x < r ? 1 : 0);
+        t_start = cstart + j;
+        t_stride = per;
+        t_count = j < csize ? (csize - j + per - 1) / per : 0;
+    }
+    if (t_count == 0) return;                                  // uniform per block: no barrier has been executed yet
+    auto decode = [&](int i, int& img, int& m0, int& n0, int& nt) {
+        const int ii = i < t_count ? i : t_count - 1;          // run-ahead loads past the end re-read the last tile (never consumed)
+        const int t = t_start + ii * t_stride;
+        img = t / per_img;
+        const int rem = t - img * per_img;
+        const int tt = rem / nnt;
+        nt = rem - tt * nnt;
+        m0 = tt * TM;
+        n0 = nt * TN;
+    };
+    const int nk = p.D / P_TK;
+    const int S = t_count * nk;
+
+    // ---- LDS-DMA cursors: wave w stages rows [8 PX w, 8 PX (w + 1)) of the target tile and [8 PW w, ..) of the reference tile, 8 rows x
+    //      128 B per instruction; lane -> (row = base + 8 j + lane>>3, physical slot lane&7) fetches logical slot (lane&7) ^ ((row>>1)&7)
+    struct Cur { const bf16_t* q[4]; int k, ti, idx; };
+    Cur cx, cw;
+    const bf16_t* other = reinterpret_cast<const bf16_t*>(p.other);
+    const bf16_t* refp = reinterpret_cast<const bf16_t*>(p.ref);
+    auto set_x = [&](Cur& c) {
+        int img, m0, n0, nt; decode(c.ti, img, m0, n0, nt);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int rt = wave * (8 * PX) + j * 8 + (lane >> 3);
+            int r = m0 + rt; r = r < p.Nt ? r : p.Nt - 1;       // rows past the end are computed and masked
+            c.q[j] = other + ((size_t)img * p.Nt + r) * p.D + (((lane & 7) ^ ((rt >> 1) & 7)) << 3);
+        }
+    };
+    auto set_w = [&](Cur& c) {
+        int img, m0, n0, nt; decode(c.ti, img, m0, n0, nt);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int rt = wave * (8 * PW) + j * 8 + (lane >> 3);
+            int r = n0 + rt; r = r < p.Nr ? r : p.Nr - 1;
+            c.q[j] = refp + ((size_t)img * p.Nr + r) * p.D + (((lane & 7) ^ ((rt >> 1) & 7)) << 3);
+        }
+    };
+    cx.k = cw.k = 0; cx.ti = cw.ti = 0; cx.idx = cw.idx = 0;
+    set_x(cx); set_w(cw);
+    auto issue_x = [&]() {
+        char* dst = smem + ((2 * cx.idx) % P_NSLOT) * P_SLOT + wave * (1024 * PX);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) glds16(cx.q[j] + cx.k, dst + j * 1024);
+        ++cx.idx; cx.k += P_TK;
+        if (cx.k == p.D) { cx.k = 0; ++cx.ti; set_x(cx); }
+    };
+    auto issue_w = [&]() {
+        char* dst = smem + ((2 * cw.idx + 1) % P_NSLOT) * P_SLOT + wave * (1024 * PW);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) glds16(cw.q[j] + cw.k, dst + j * 1024);
+        ++cw.idx; cw.k += P_TK;
+        if (cw.k == p.D) { cw.k = 0; ++cw.ti; set_w(cw); }
+    };
+    // ---- fragment reads: row = base16 + (lane&15), logical slot 4 h + (lane>>4), physical = logical ^ ((row>>1)&7); 16-row steps (and the
+    //      group / wave bases, multiples of 16 rows) leave (row>>1)&7 alone, the k-half only flips slot bit 2
+    const int fr = lane & 15, hi = lane >> 4;
+    const int fbase = fr * 128 + ((hi ^ ((fr >> 1) & 7)) << 4);
+    const int xbase = grp * (16 * MI) * 128 + fbase;
+    const int wbase = wn * (16 * NJ) * 128 + fbase;
+
+    // ---- prologue: X0, W0 landed and visible, X1 in flight
+    issue_x(); issue_w(); issue_x();
+    a_wait_vm<PX>();
+    a_barrier();
+    const unsigned lds0 = a_lds_addr(smem);
+    auto body = [&](auto G_) {
+        constexpr int G = decltype(G_)::value;
+        f32x4 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int kt = 0, ti = 0;
+        if (G == 1) a_barrier();                               // skew: group 1 runs one barrier interval behind
+        for (int s = 0; s < S; ++s) {
+            const unsigned sx = lds0 + (unsigned)((2 * s) % P_NSLOT) * P_SLOT, sw = lds0 + (unsigned)((2 * s + 1) % P_NSLOT) * P_SLOT;
+            bf16x8 xf[MI], wf[NJ];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // L(h): the k-half's fragment reads + the LDS-DMA pieces of W(s+1) (h = 0) / X(s+2) (h = 1)
+                __builtin_amdgcn_s_setprio(1);
+                a_reads(wf, (sw + wbase) ^ (h << 6));           // W first: the MFMA segment starts with wf[0..] x xf[0]
+                a_reads(xf, (sx + xbase) ^ (h << 6));
+                if (h == 0) issue_w(); else issue_x();
+                if (h == 1 && G == 1) a_wait_vm<PX>();          // group 1's loads are needed by group 0 one barrier later
+                a_pin(xf, true);
+                a_pin(wf, false);
+                __builtin_amdgcn_s_setprio(0);
+                a_barrier();
+                // M(h): MI x NJ MFMAs and nothing else
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                if (h == 0) a_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // keep the counted wait behind the segment's MFMAs
+            if (G == 0) a_wait_vm<PX>();
+            if (++kt == nk) {
+                kt = 0;
+                int img, m0, n0, nt; decode(ti, img, m0, n0, nt); ++ti;
+                const int mb = m0 + grp * (16 * MI), nb = n0 + wn * (16 * NJ);
+                const float* cr = p.c_ref + (size_t)img * p.Nr;
+                float rm[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) rm[i] = -INFINITY;
+                // lane holds G[t = mb + 16 i + fr][s = nb + 16 j + 4 hi + e]
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int sidx = nb + j * 16 + hi * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = sidx + e < p.Nr;
+                        const float c = ok ? cr[sidx + e] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) rm[i] = fmaxf(rm[i], ok ? acc[i][j][e] * c : -INFINITY);
+                    }
+                }
+                const int nparts = 4 * nnt;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    float v = rm[i];
+                    v = fmaxf(v, __shfl_xor(v, 16));
+                    v = fmaxf(v, __shfl_xor(v, 32));
+                    const int t = mb + i * 16 + fr;
+                    if (hi == 0 && t < p.Nt) p.partial[((size_t)img * p.Nt + t) * nparts + nt * 4 + wn] = v;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            a_barrier();
+        }
+        if (G == 0) a_barrier();                               // group 1 executed one extra barrier up front
+    };
+    if (grp == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the (unused) run-ahead loads before exit
+}
+
+template <int MI, int NJ>
+int launch_pp(const AScoreArgs& a, float* scores, hipStream_t s) {
+    constexpr int TM = 32 * MI, TN = 64 * NJ;
+    static bool attr = false;
+    static int ncu = 256;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_pp<MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        attr = true;
+    }
+    const int nnt = (a.Nr + TN - 1) / TN, ntiles = a.n_img * ((a.Nt + TM - 1) / TM) * nnt;
+    hipLaunchKernelGGL((ascore_maxcos_pp<MI, NJ>), dim3(ntiles < ncu ? ntiles : ncu), dim3(512), P_LDS, s, a);
+    return 4 * nnt;                                            // parts per target row in a.partial
+}
+
 // score[img] = (1 / Nt) * sum_t c_other[t] * max over the reference tiles of rowmax[img][t][.]   (c_other > 0 commutes with the max);
 // one wave per image, lanes stride t, fixed-order wave reduction -> deterministic
 __global__ __launch_bounds__(256) void ascore_finalize_tiles(const float* __restrict__ rowmax, const float* __restrict__ c_other, float* __restrict__ score,
@@ -308,7 +544,18 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
     if (!c_ref_in && row_scales<T>(ref, (long)n_img * Nr, D, c_ref, s)) return VISREP_ERR_LAUNCH;
     AScoreArgs a{other, ref, c_other_in ? c_other_in : c_other, c_ref_in ? c_ref_in : c_ref, partial, n_img, Nt, Nr, D};
     int ntt = (Nt + 63) / 64;
-    if (tiled) {                                               // production path: LDS-tiled MFMA kernel, one 128 x 128 tile per workgroup
+    // tile shape: the candidate that launches the smallest tile area; ties go to the ping-pong kernel and there to the larger tile
+    auto cover = [](int n, int t) { return (long)((n + t - 1) / t) * t; };
+    const int tm = cover(Nt, 256) <= cover(Nt, 192) ? 256 : 192, tn = cover(Nr, 256) <= cover(Nr, 192) ? 256 : 192;
+    const long area128 = cover(Nt, 128) * cover(Nr, 128), area_pp = cover(Nt, tm) * cover(Nr, tn);
+    const bool pp = g_visrep_ascore_variant == 2 || (g_visrep_ascore_variant == 0 && area_pp <= area128);
+    if (tiled && pp) {
+        const int parts = tm == 192 ? (tn == 192 ? launch_pp<6, 3>(a, scores, s) : launch_pp<6, 4>(a, scores, s))
+                                    : (tn == 192 ? launch_pp<8, 3>(a, scores, s) : launch_pp<8, 4>(a, scores, s));
+        hipLaunchKernelGGL(ascore_finalize_tiles, dim3((n_img + 3) / 4), dim3(256), 0, s, partial, a.c_other, scores, n_img, Nt, parts);
+        return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
+    }
+    if (tiled) {                                               // LDS-tiled MFMA kernel, one 128 x 128 tile per workgroup
         ntt = (Nt + A_BM - 1) / A_BM;
         const int nnt = (Nr + A_BN - 1) / A_BN;
         static bool attr = false;
@@ -326,9 +573,17 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
 
 extern "C" size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr) {
     // row scales of both operands + the larger of the two partial layouts: [n_img, ceil(Nt / 64)] block sums (direct kernels) or
-    // [n_img, Nt, ceil(Nr / 128)] per-row maxima of the tiled bf16 kernel
-    const size_t direct = (size_t)n_img * ((Nt + 63) / 64), tiled = (size_t)n_img * Nt * ((Nr + 127) / 128);
+    // [n_img, Nt, parts] per-row maxima of the tiled bf16 kernels (one part per 128-row reference tile, or four per 192- / 256-row tile)
+    const size_t parts = (size_t)4 * ((Nr + 191) / 192);       // >= ceil(Nr / 128) and >= 4 * ceil(Nr / 256): covers every tile shape
+    const size_t direct = (size_t)n_img * ((Nt + 63) / 64), tiled = (size_t)n_img * Nt * parts;
     return sizeof(float) * ((size_t)n_img * Nt + (size_t)n_img * Nr + (direct > tiled ? direct : tiled));
+}
+
+extern "C" int visrep_set_ascore_variant(int v) {
+    if (v < 0 || v > 2) return visrep_set_error(VISREP_ERR_SHAPE, "ascore variant: 0 (by tile area), 1 (128 x 128 tiles) or 2 (persistent ping-pong tiles)");
+    const int old = g_visrep_ascore_variant;
+    g_visrep_ascore_variant = v;
+    return old;
 }
 
 extern "C" int visrep_ascore_row_scale(const void* x, long rows, int D, int dtype, float* scale, void* stream) {

@@ -430,6 +430,113 @@ __global__ __launch_bounds__(256) void u8hwc_to_chw_norm(const uint8_t* __restri
 }
 }  // namespace
 
+// ---- the same two passes + crop + normalisation for a whole batch of images of DIFFERENT sizes in two launches (round 3): one int64
+// descriptor per image (PD_*) names the source image, an optional virtual canvas around it (llava/mm_utils.py:78-91 expand2square: the
+// image pasted centred on a square of the background colour), an optional mirror (Image.FLIP_LEFT_RIGHT), the two coefficient tables
+// and the crop.  Pass 1 resamples horizontally only the canvas rows the vertical pass will touch and only the columns inside the crop;
+// pass 2 resamples vertically, crops and normalises straight into out[img].  Same integer arithmetic as resample_u8, same float
+// expression as u8hwc_to_chw_norm: bit-identical to the per-image route.
+namespace {
+enum { PD_SRC = 0, PD_H, PD_W, PD_VH, PD_VW, PD_PADY, PD_PADX, PD_BG, PD_FLIP, PD_MID, PD_R0, PD_NR, PD_HB, PD_HK, PD_HKS, PD_VB, PD_VK, PD_VKS,
+       PD_X0, PD_Y0, PD_FIELDS = 24 };
+
+struct PdImage {
+    const uint8_t* src; long H, W, pady, padx; unsigned bg; bool flip;
+    VR_DEV explicit PdImage(const long long* D)
+        : src(reinterpret_cast<const uint8_t*>(D[PD_SRC])), H(D[PD_H]), W(D[PD_W]), pady(D[PD_PADY]), padx(D[PD_PADX]), bg((unsigned)D[PD_BG]), flip(D[PD_FLIP] != 0) {}
+    VR_DEV int px(long y, long x, int c) const {                // pixel (y, x) of the canvas: the (mirrored) image or the background
+        const long ry = y - pady;
+        long rx = x - padx;
+        if (ry < 0 || ry >= H || rx < 0 || rx >= W) return (int)((bg >> (8 * c)) & 255u);
+        if (flip) rx = W - 1 - rx;
+        return (int)src[(ry * W + rx) * 3 + c];
+    }
+};
+
+__global__ __launch_bounds__(256) void preprocess_h_pass(const long long* __restrict__ desc, int crop_w) {
+    const long long* D = desc + (long)blockIdx.y * PD_FIELDS;
+    const int ks = (int)D[PD_HKS];
+    if (ks == 0) return;                                        // canvas width == resized width: pass 2 reads the canvas itself
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // (row - R0, x inside the crop)
+    if (idx >= D[PD_NR] * crop_w) return;
+    const int x = (int)(idx % crop_w);
+    const long rr = idx / crop_w;
+    const int xx = (int)D[PD_X0] + x;
+    const int* bounds = reinterpret_cast<const int*>(D[PD_HB]);
+    const int* k = reinterpret_cast<const int*>(D[PD_HK]) + (long)xx * ks;
+    const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    const PdImage im(D);
+    const long row = D[PD_R0] + rr;
+    uint8_t* mid = reinterpret_cast<uint8_t*>(D[PD_MID]) + idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int ss = 1 << 21;
+        for (int i = 0; i < cnt; ++i) ss += im.px(row, xmin + i, c) * k[i];
+        ss >>= 22;
+        mid[c] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+    }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void preprocess_v_pass(const long long* __restrict__ desc, void* __restrict__ out, int crop_h, int crop_w, float m0,
+                                                         float m1, float m2, float s0, float s1, float s2) {
+    const long long* D = desc + (long)blockIdx.y * PD_FIELDS;
+    const int idx = blockIdx.x * 256 + threadIdx.x;             // (y, x) inside the crop
+    if (idx >= crop_h * crop_w) return;
+    const int x = idx % crop_w, y = idx / crop_w;
+    const int hks = (int)D[PD_HKS], vks = (int)D[PD_VKS];
+    const int yy = (int)D[PD_Y0] + y, xx = (int)D[PD_X0] + x;
+    const PdImage im(D);
+    const uint8_t* mid = reinterpret_cast<const uint8_t*>(D[PD_MID]);
+    const long r0 = D[PD_R0];
+    auto fetch = [&](long row, int c) -> int { return hks ? (int)mid[((row - r0) * crop_w + x) * 3 + c] : im.px(row, xx, c); };
+    int ymin = yy, cnt = 1;
+    const int* k = nullptr;
+    if (vks) {
+        const int* bounds = reinterpret_cast<const int*>(D[PD_VB]);
+        ymin = bounds[2 * yy];
+        cnt = bounds[2 * yy + 1];
+        k = reinterpret_cast<const int*>(D[PD_VK]) + (long)yy * vks;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int u;
+        if (vks) {
+            int ss = 1 << 21;
+            for (int i = 0; i < cnt; ++i) ss += fetch(ymin + i, c) * k[i];
+            ss >>= 22;
+            u = ss < 0 ? 0 : (ss > 255 ? 255 : ss);
+        } else {
+            u = fetch(yy, c);
+        }
+        const float v = (float)u / 255.0f;
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const float o = (v - mean) / sd;
+        const long oi = (((long)blockIdx.y * 3 + c) * crop_h + y) * crop_w + x;
+        if (F32) reinterpret_cast<float*>(out)[oi] = o;
+        else reinterpret_cast<bf16_t*>(out)[oi] = (bf16_t)(pack_bf16(o, 0.f) & 0xffffu);
+    }
+}
+}  // namespace
+
+extern "C" int visrep_preprocess_u8_batch(const void* desc, int n_images, long max_mid_rows, int crop_h, int crop_w, const float* mean3,
+                                          const float* std3, void* out, int dtype, void* stream) {
+    if (n_images <= 0) return 0;
+    if (!desc || !out || !mean3 || !std3) return visrep_set_error(VISREP_ERR_ARG, "preprocess_u8_batch: null pointer (mean3 / std3 are HOST arrays)");
+    if (crop_h <= 0 || crop_w <= 0 || max_mid_rows < 0) return visrep_set_error(VISREP_ERR_SHAPE, "preprocess_u8_batch: empty crop");
+    if (dtype != VISREP_F32 && dtype != VISREP_BF16) return visrep_set_error(VISREP_ERR_ARG, "preprocess_u8_batch: dtype must be bf16 (0) or f32 (1)");
+    hipStream_t st = (hipStream_t)stream;
+    const long long* d = reinterpret_cast<const long long*>(desc);
+    if (max_mid_rows > 0)
+        hipLaunchKernelGGL(preprocess_h_pass, dim3((unsigned)((max_mid_rows * crop_w + 255) / 256), n_images), dim3(256), 0, st, d, crop_w);
+    const dim3 grid((unsigned)(((long)crop_h * crop_w + 255) / 256), n_images);
+    if (dtype == VISREP_F32)
+        hipLaunchKernelGGL(preprocess_v_pass<true>, grid, dim3(256), 0, st, d, out, crop_h, crop_w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else
+        hipLaunchKernelGGL(preprocess_v_pass<false>, grid, dim3(256), 0, st, d, out, crop_h, crop_w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    return launched("preprocess_u8_batch: launch failed");
+}
+
 extern "C" int visrep_resample_u8(const void* in, void* out, long n_lines, int out_len, int channels, long in_line_stride,
                                   long in_elem_stride, long out_line_stride, long out_elem_stride, const int* bounds, const int* kk, int ksize,
                                   void* stream) {

@@ -107,6 +107,7 @@ def resample_reference(img: np.ndarray, size: Tuple[int, int], filter: str = "bi
 
 
 _TABLES = {}
+_HOST_BOUNDS = {}
 
 
 def _device_tables(n_in, n_out, device, filter="bicubic"):
@@ -114,6 +115,7 @@ def _device_tables(n_in, n_out, device, filter="bicubic"):
     if key not in _TABLES:
         bounds, kk, ksize = pil_coeffs(n_in, n_out, filter)
         _TABLES[key] = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
+        _HOST_BOUNDS[(n_in, n_out, filter)] = bounds.reshape(-1, 2)
     return _TABLES[key]
 
 
@@ -202,6 +204,106 @@ def to_tensor(img: torch.Tensor, box: Tuple[int, int, int, int], mean: Sequence[
     return out
 
 
+PD_FIELDS = 24            # int64 fields per image descriptor (csrc/convnet.hip: PD_*; include/visrep.h visrep_preprocess_u8_batch)
+
+
+class _PinnedRing:
+    """A few pinned host buffers handed out in turn, each guarded by the event of the upload that last read it: descriptor uploads
+    stay asynchronous (a pageable `tensor.to(device)` would block the host behind everything already queued on the stream, e.g. the
+    previous batch's tower forward)."""
+
+    def __init__(self, n=4):
+        self.buf, self.ev, self.turn = [None] * n, [None] * n, 0
+
+    def upload(self, host: np.ndarray, device) -> torch.Tensor:
+        k = self.turn
+        self.turn = (k + 1) % len(self.buf)
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        raw = host.view(np.uint8).reshape(-1)
+        if self.buf[k] is None or self.buf[k].numel() < raw.size:
+            self.buf[k] = torch.empty(max(raw.size, 1 << 16), dtype=torch.uint8).pin_memory()
+        self.buf[k].numpy()[: raw.size] = raw
+        dev = self.buf[k][: raw.size].to(device, non_blocking=True)
+        self.ev[k] = torch.cuda.Event()
+        self.ev[k].record(torch.cuda.current_stream(device))
+        return dev
+
+
+_RING = _PinnedRing()
+
+
+def preprocess_batch(images: Sequence[torch.Tensor], sizes: Sequence[Tuple[int, int]], boxes: Sequence[Tuple[int, int, int, int]],
+                     mean: Sequence[float], std: Sequence[float], dtype=torch.float32, pad_background=None, flip: bool = False,
+                     filter: str = "bicubic", out: torch.Tensor = None) -> torch.Tensor:
+    """images: uint8 [H, W, 3] device tensors of any sizes; sizes[i] = (ow, oh) the resize target; boxes[i] = (left, top, w, h) the crop
+    in the resized image (all crops the same w x h) -> [n, 3, h, w] normalised pixels, in TWO launches for the whole batch
+    (visrep_preprocess_u8_batch).  pad_background = (r, g, b): the image is first pasted centred on a square canvas of that colour
+    (llava/mm_utils.py:78-91 expand2square); flip: mirrored left-right first (pck_train.py:112).  Bit-identical to
+    to_tensor(resize_u8(img)) per image, i.e. to PIL + the CPU processors."""
+    import ctypes as C
+    lib = _lib.require_gpu()
+    n = len(images)
+    if not (n == len(sizes) == len(boxes)):
+        raise ValueError("preprocess_batch: images, sizes and boxes must have the same length")
+    _, _, cw, ch = boxes[0]
+    device = images[0].device if n else torch.device("cuda")
+    if out is None:
+        out = torch.empty(n, 3, ch, cw, dtype=dtype, device=device)
+    if n == 0:
+        return out
+    desc = np.zeros((n, PD_FIELDS), np.int64)
+    mid_off, max_rows, keep = 0, 0, []
+    for i, (im, (ow, oh), (l, t, w, h)) in enumerate(zip(images, sizes, boxes)):
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or not im.is_cuda:
+            raise ValueError("preprocess_batch wants uint8 [H, W, 3] device tensors")
+        if (w, h) != (cw, ch) or l < 0 or t < 0 or l + w > ow or t + h > oh:
+            raise ValueError("preprocess_batch: every crop must have the same size and lie inside its resized image")
+        im = im.contiguous()
+        keep.append(im)
+        H, W = int(im.shape[0]), int(im.shape[1])
+        VH, VW, py, px, bg = H, W, 0, 0, 0
+        if pad_background is not None and W != H:
+            VH = VW = max(W, H)
+            py, px = ((W - H) // 2, 0) if W > H else (0, (H - W) // 2)
+            bg = int(pad_background[0]) | int(pad_background[1]) << 8 | int(pad_background[2]) << 16
+        D = desc[i]
+        D[0:9] = (im.data_ptr(), H, W, VH, VW, py, px, bg, int(bool(flip)))
+        r0, nr = t, h                                              # canvas rows the second pass reads
+        if VH != oh:
+            vb, vk, vks = _device_tables(VH, oh, device, filter)
+            D[15:18] = (vb.data_ptr(), vk.data_ptr(), vks)
+            bh = _host_bounds(VH, oh, filter)
+            r0 = int(bh[t, 0])
+            nr = int(bh[t + h - 1, 0] + bh[t + h - 1, 1]) - r0
+        if VW != ow:
+            hb, hk, hks = _device_tables(VW, ow, device, filter)
+            D[12:15] = (hb.data_ptr(), hk.data_ptr(), hks)
+            D[9] = mid_off                                         # offset now, pointer once the scratch exists
+            mid_off += (nr * cw * 3 + 63) // 64 * 64
+            max_rows = max(max_rows, nr)
+        D[10:12] = (r0, nr)
+        D[18:20] = (l, t)
+    scratch = torch.empty(max(mid_off, 64), dtype=torch.uint8, device=device)
+    desc[:, 9] += scratch.data_ptr()
+    ddesc = _RING.upload(desc, device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    with torch.cuda.device(device):
+        rc = lib.visrep_preprocess_u8_batch(_lib.ptr(ddesc), n, max_rows, ch, cw, m, s, _lib.ptr(out), _lib.F32 if out.dtype == torch.float32 else _lib.BF16,
+                                            _lib.stream_ptr())
+    _lib.check(rc, "visrep_preprocess_u8_batch")
+    ddesc.record_stream(torch.cuda.current_stream(device))
+    scratch.record_stream(torch.cuda.current_stream(device))
+    return out
+
+
+def _host_bounds(n_in, n_out, filter="bicubic"):
+    key = (n_in, n_out, filter)
+    if key not in _HOST_BOUNDS:
+        _HOST_BOUNDS[key] = pil_coeffs(n_in, n_out, filter)[0].reshape(-1, 2)
+    return _HOST_BOUNDS[key]
+
+
 def expand2square_u8(img: torch.Tensor, background) -> torch.Tensor:
     """llava/mm_utils.py:78-91 expand2square on an RGB u8 [H, W, 3] device tensor: paste centred on a square of the background colour."""
     H, W, _ = img.shape
@@ -242,14 +344,24 @@ class DevicePreprocessor:
     def preprocess(self, images, return_tensors="pt"):
         if not isinstance(images, (list, tuple)):
             images = [images]
-        out = torch.empty(len(images), 3, self.crop, self.crop, dtype=self.dtype, device=self.device)
-        for i, im in enumerate(images):
+        return {"pixel_values": self.preprocess_padded(images, None)}
+
+    @torch.no_grad()
+    def preprocess_padded(self, images, pad_background):
+        """preprocess() of expand2square(image, pad_background) (llava/mm_utils.py:78-95 `image_aspect_ratio == 'pad'`) without building the
+        square: padding, both resize passes, crop and normalisation of the whole batch are two launches (preprocess_batch)."""
+        dev = []
+        for im in images:
             if isinstance(im, torch.Tensor):                                     # RGB u8 [H, W, 3] already in HBM (device_jpeg.DeviceJpegDecoder)
-                dev = im.to(self.device)
+                dev.append(im.to(self.device))
             else:
-                dev = torch.from_numpy(np.array(im.convert("RGB"))).to(self.device, non_blocking=True)   # PIL image: decoded on the host
-            size, box = self.geometry(dev.shape[1], dev.shape[0])
-            to_tensor(resize_u8(dev, size), box, self.mean, self.std, out=out[i])
-        return {"pixel_values": out}
+                dev.append(torch.from_numpy(np.array(im.convert("RGB"))).to(self.device, non_blocking=True))   # PIL image: decoded on the host
+        geo = []
+        for d in dev:
+            H, W = int(d.shape[0]), int(d.shape[1])
+            if pad_background is not None:
+                H = W = max(H, W)
+            geo.append(self.geometry(W, H))
+        return preprocess_batch(dev, [g[0] for g in geo], [g[1] for g in geo], self.mean, self.std, self.dtype, pad_background)
 
     __call__ = preprocess

@@ -84,9 +84,7 @@ def _device_input_stream(chunks, processor, image_aspect_ratio, device):
     for i, chunk in enumerate(chunks):
         nxt = dec.submit([p for p, _ in chunks[i + 1]]) if i + 1 < len(chunks) else None
         imgs = dec.finish(pending)
-        if image_aspect_ratio == 'pad':
-            imgs = [DP.expand2square_u8(im, bg) for im in imgs]
-        yield chunk, dproc.preprocess(imgs)["pixel_values"]
+        yield chunk, dproc.preprocess_padded(imgs, bg if image_aspect_ratio == 'pad' else None)
         pending = nxt
 
 

@@ -36,7 +36,7 @@ def test_error_reporting_without_gpu_work():
     rc = lib.visrep_gemm_bf16(None, 0, None, 0, None, None, 0, 1, 128, 64, 0, 0, None, None, None)
     assert rc == -1
     assert "null" in _lib.last_error()
-    assert lib.visrep_ascore_workspace_bytes(2, 10, 7) == 4 * (20 + 14 + 20)        # row scales of both operands + [n, Nt, ceil(Nr / 128)] row maxima
+    assert lib.visrep_ascore_workspace_bytes(2, 10, 7) == 4 * (20 + 14 + 80)        # row scales of both operands + [n, Nt, 4 * ceil(Nr / 192)] row maxima
 
 
 def test_compute_paths_fail_loudly_without_gpu():

@@ -201,6 +201,52 @@ def test_device_resize_is_bit_exact_with_pil(w, h, ow, oh):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("pad,flip", [(False, False), (True, False), (False, True), (True, True)])
+def test_batched_preprocess_equals_pil_per_image(pad, flip):
+    """visrep_preprocess_u8_batch: one descriptor per image, two launches per batch - images of different sizes (down- and upscaled, one
+    axis already at the target size, already square), optional expand2square canvas and mirror, resize + centre crop + normalise: equal to
+    PIL + the numpy expression per image, and to the per-image device route, bit for bit."""
+    from law_of_vision_representation_in_mllms_amd import device_preprocess as DP
+    from law_of_vision_representation_in_mllms_amd.llava.mm_utils import expand2square
+    rs = np.random.RandomState(3 + pad + 2 * flip)
+    shapes = [(640, 427), (333, 500), (224, 224), (100, 80), (224, 300), (300, 224), (17, 9), (768, 768), (501, 224)]
+    arrs = [rs.randint(0, 256, (h, w, 3), dtype=np.uint8) for w, h in shapes]
+    bg = (122, 116, 104)
+    mean, std = (0.481, 0.457, 0.408), (0.268, 0.261, 0.275)
+    S, crop = 224, 196
+    sizes, boxes, want = [], [], []
+    for a in arrs:
+        im = Image.fromarray(a)
+        if flip:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        if pad:
+            im = expand2square(im, bg)
+        w, h = im.size
+        ow, oh = (S, max(S, int(h * S / w))) if w <= h else (max(S, int(w * S / h)), S)      # shortest edge -> S
+        l, t = (ow - crop) // 2, (oh - crop) // 2
+        sizes.append((ow, oh))
+        boxes.append((l, t, crop, crop))
+        r = np.asarray(im.resize((ow, oh), Image.BICUBIC))[t: t + crop, l: l + crop].transpose(2, 0, 1).astype(np.float32)
+        want.append((r / np.float32(255.0) - np.array(mean, np.float32)[:, None, None]) / np.array(std, np.float32)[:, None, None])
+    dev = [torch.from_numpy(a).to(DEV) for a in arrs]
+    got = DP.preprocess_batch(dev, sizes, boxes, mean, std, torch.float32, bg if pad else None, flip)
+    assert got.shape == (len(arrs), 3, crop, crop)
+    for i, w_ in enumerate(want):
+        assert np.array_equal(got[i].cpu().numpy(), w_), (i, shapes[i])
+    # the per-image route (three launches per image) agrees
+    for i, d in enumerate(dev):
+        x = d.flip(1) if flip else d
+        if pad:
+            x = DP.expand2square_u8(x, bg)
+        assert torch.equal(DP.to_tensor(DP.resize_u8(x, sizes[i]), boxes[i], mean, std), got[i]), i
+    # bf16 output + caller-provided output tensor; an empty batch
+    out = torch.empty(len(arrs), 3, crop, crop, dtype=torch.bfloat16, device=DEV)
+    assert DP.preprocess_batch(dev, sizes, boxes, mean, std, pad_background=bg if pad else None, flip=flip, out=out) is out
+    assert torch.equal(out, got.to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        DP.preprocess_batch(dev[:2], sizes[:2], [boxes[0], (0, 0, crop, crop - 1)], mean, std)
+
+
 def test_device_preprocessor_equals_cpu_processors(tmp_path):
     """CLIP / DINOv2 / SigLIP processor geometry and arithmetic on the device: bit-identical fp32 pixel tensors; and the C-path
     loader of extract_feature."""

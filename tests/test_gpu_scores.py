@@ -69,6 +69,31 @@ def test_ascore_precomputed_row_scales(dtype):
             ascore_ops.max_cos_mean(od, rd.float(), so, None)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("n,Nt,Nr,D", [(3, 576, 576, 4096), (2, 577, 50, 256), (5, 729, 576, 1152), (2, 190, 193, 64), (40, 192, 384, 128), (300, 96, 200, 64)])
+def test_ascore_tile_variants(variant, n, Nt, Nr, D):
+    """Both bf16 Gram kernels (128 x 128 tiles; 192 x 192 persistent ping-pong) against the oracle on full, ragged and many-tile shapes
+    (n = 300: more tiles than CUs with an uneven persistent walk); the two agree bit for bit (same k order per accumulator)."""
+    from law_of_vision_representation_in_mllms_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n * 1000 + Nt + Nr)
+    shared = torch.randn(n, 1, D, generator=g)
+    o = (torch.randn(n, Nt, D, generator=g) + 0.7 * shared).to(torch.bfloat16)
+    r = (torch.randn(n, Nr, D, generator=g) + 0.7 * shared).to(torch.bfloat16)
+    od, rd = o.to(DEV), r.to(DEV)
+    old = lib.visrep_set_ascore_variant(variant)
+    try:
+        got = ascore_ops.max_cos_mean(od, rd).cpu()
+        lib.visrep_set_ascore_variant(3 - variant)
+        other = ascore_ops.max_cos_mean(od, rd).cpu()
+    finally:
+        lib.visrep_set_ascore_variant(old)
+    idx = list(range(n)) if n <= 5 else [0, 1, n // 2, n - 2, n - 1]
+    want = torch.tensor([OA.max_cos_mean(o[i], r[i]) for i in idx])
+    assert ((got[idx] - want).abs() / want.abs()).max().item() < 1e-4
+    assert torch.equal(got, other)
+
+
 def test_ascore_self_is_one():
     x = torch.randn(2, 300, 512)
     got = ascore_ops.max_cos_mean(x.to(DEV), x.to(DEV)).cpu()

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """End-to-end throughput of the C-feature extraction path: JPEG files -> decode -> resize -> normalise -> tower
 -> one .pt per image, for the host pipeline variants (serial decode like the reference, decode pool one batch ahead of the GPU,
-resize + normalise on the device).  Usage: python tools/pipeline_bench.py [n_images] [feature]"""
+resize + normalise on the device).  Usage: python tools/pipeline_bench.py [n_images] [feature] [bf16|fp32]
+(tower precision: the reference runs DINOv2 / CLIP in fp32 - C_score/extract_feature.configure's default - which makes every route
+tower-bound at ~630 images/s; bf16, the default HERE, shows the input pipeline)."""
 import json
 import os
 import shutil
@@ -18,6 +20,7 @@ from law_of_vision_representation_in_mllms_amd.C_score import extract_feature as
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 feature = sys.argv[2] if len(sys.argv) > 2 else "DINOv2"
+precision = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 root = tempfile.mkdtemp(prefix="visrep_pipe_")
 src = os.path.join(root, "JPEGImages", "cat")
 os.makedirs(src)
@@ -25,8 +28,8 @@ rs = np.random.RandomState(0)
 base = rs.randint(0, 255, (375, 500, 3), dtype=np.uint8)
 for i in range(n):
     Image.fromarray(np.roll(base, i, axis=1)).save(os.path.join(src, f"im{i:05d}.jpg"), quality=90)
-EF.configure(feature, img_size=224, synthetic_weights=True, batch=64)
-out = {"images": n, "feature": feature, "cores": os.cpu_count()}
+EF.configure(feature, img_size=224, synthetic_weights=True, batch=64, precision=precision)
+out = {"images": n, "feature": feature, "tower_precision": precision, "cores": os.cpu_count()}
 warm = os.path.join(root, "warm", "JPEGImages", "cat")                 # untimed first pass: module load, workspace, first-touch
 os.makedirs(warm)
 for i in range(64):
@@ -91,7 +94,7 @@ for tag, gen in (("input pipeline only: host Huffman x32 + device reconstruct/re
     torch.cuda.synchronize()
     out[tag] = {"images_per_s": round(cnt / (time.perf_counter() - t0), 1)}
 # tower alone on resident pixels, same batch size
-px = torch.randn(64, 3, 224, 224).to(torch.bfloat16).cuda()
+px = torch.randn(64, 3, 224, 224).cuda()
 f = EF._state.dift.forward
 f(px)
 torch.cuda.synchronize()
