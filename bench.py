@@ -43,6 +43,7 @@ MODEL = "openai/clip-vit-large-patch14-336"
 BATCH = 256
 N_LAYERS = 23                     # select_layer = -2: the 24th layer is never needed
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0             # HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per fc1 launch at batch 256 with the default (v2) GEMM, from rocprofv3 PMC passes of this kernel at this shape
 # (profiles/round2_final_kernel_stats.md, v2: round2_v2default_kernel_stats.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md "HBM"; round 1 calibrated both on layernorm_rows' known byte count).  Algorithmic bytes are 1.52e9.
@@ -117,8 +118,10 @@ def score_extras(dev, n_a=256, n_img=1800, n_pairs=12234):
         so = ascore_ops.row_scales(o)
         sec = ev_time(lambda: (ascore_ops.max_cos_mean(o, r336, so, s336), ascore_ops.max_cos_mean(o, r224, so, s224)))
         tf = 2.0 * Nt * 832 * 4096 * n_a / sec / 1e12
+        gbs = (2 * Nt + 832) * 4096 * 2.0 * n_a / sec / 1e9          # every operand row is read once per launch (no reuse across images)
         out[f"ascore_Nt{Nt}"] = {"ms": round(sec * 1e3, 3), "images": n_a, "images_per_s": round(n_a / sec, 1), "tflops": round(tf, 1),
-                                 "bound": "mfma (bf16)", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+                                 "bound": "mfma (bf16)", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "operand_GB_per_s": round(gbs, 1),
+                                 "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
         del o, so
     del r336, r224, s336, s224
     rs = np.random.RandomState(5)

@@ -220,8 +220,11 @@ def _process_images(input_dir, output_dir, workers):
     from concurrent.futures import ThreadPoolExecutor
 
     def save(m, out):
+        # the copy out of the batch tensor (torch.save of a view would pickle the whole batch's storage) is made HERE, on the writer thread:
+        # 64 one-megabyte clones on the calling thread each wake torch's intra-op pool and re-take the GIL against the writers - measured
+        # 37 ms per clone once the calling thread is no longer parked in pool futures (profiles/round3_pipeline.md)
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        torch.save(m, out)
+        torch.save(m.unsqueeze(0).clone(), out)
     # the 1-MB-per-image pickles are written by a small pool behind the GPU (they were most of the loop's wall-clock:
     # profiles/round1_pipeline.md); at most two batches of maps are in flight
     with ThreadPoolExecutor(max_workers=max(1, min(workers, 8))) as writers:
@@ -234,7 +237,7 @@ def _process_images(input_dir, output_dir, workers):
             stream = _prefetched(chunks, _load_pixels_worker if workers > 1 else _load_pixels, workers)
         for chunk, px in stream:
             maps = (_dift_maps(px) if _state.kind != "vit" else _to_maps(_state.dift.forward(px))).cpu()
-            batch = [writers.submit(save, m.unsqueeze(0).clone(), out) for (_, out), m in zip(chunk, maps)]
+            batch = [writers.submit(save, m, out) for (_, out), m in zip(chunk, maps)]
             for (_, out) in chunk:
                 print(f'Saved features to {out}')
             inflight.append(batch)

@@ -14,11 +14,13 @@
 //             bf16 inputs: v_mfma_f32_32x32x16_bf16 (products exact in fp32, fp32 accumulate)
 //             fp32 inputs: 4 x v_mfma_f32_32x32x2_f32 per 16-B load (exact fp32 FMA chain)
 //   pass 3  ascore_finalize  : score[img] = sum(partials) / Nt   (fixed order -> deterministic)
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
 #include "visrep_internal.h"
 
+int g_visrep_ascore_deep = getenv("VISREP_ASCORE_DEEP") ? atoi(getenv("VISREP_ASCORE_DEEP")) : 1;   // A/B knob (default on): six-slot ring for 192 x 192 tiles, 576 x 576 x 4096: 0.720 -> 0.651 ms
 int g_visrep_ascore_variant = 0;   // 0 = pick by launched tile area, 1 = 128 x 128 tiles, 2 = persistent ping-pong tiles (visrep_set_ascore_variant)
 
 namespace {
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void ascore_maxcos_tiled(const AScoreArgs p
 // hazard ledger is gemm_bf16_v5.hip's (OWN_ = false) with TM / 64 and TN / 64 LDS-DMA pieces per wave instead of four.
 // Epilogue: scale by c_ref, mask s >= Nr, row max over the wave's TN / 4 reference rows -> partial[img][t][4 nt + wn]; the finalize
 // kernel takes the max over the 4 * nnt parts.
-constexpr int P_TK = 64, P_SLOT = 256 * P_TK * 2, P_NSLOT = 5, P_LDS = P_NSLOT * P_SLOT;   // 32 KB x 5 = all of the CU's LDS
+constexpr int P_TK = 64;
 
 VR_DEV unsigned a_lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 // Fragment reads and their wait are asm: hipcc cannot tell an LDS read from the bytes an in-flight LDS-DMA will write and would put
@@ -325,14 +327,21 @@ VR_DEV void a_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 template <int N> VR_DEV void a_wait_vm() {
+    static_assert(N == 3 || N == 4 || N == 6, "pieces in flight");
     if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool DEEP>
 __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
     constexpr int TM = 32 * MI, TN = 64 * NJ;                  // 192 or 256 target rows x 192 or 256 reference rows per tile
     constexpr int PX = TM / 64, PW = TN / 64;                  // 8-row LDS-DMA pieces per wave and K-tile
+    // DEEP (192 x 192 only: 24-KB slots): a ring of SIX slots, the stream runs two whole K-tiles ahead (prologue X0 W0 X1 W1; L0(s) issues
+    // X(s+2), L1(s) issues W(s+2); the counted waits leave PX + PW pieces in flight).  X(s+2) / W(s+2) reuse the slots of X(s-1) / W(s-1), last
+    // read in L1(s-1): retired before barrier instance 4s, overwritten after it - the ledger of gemm_bf16_v5.hip with one more item in flight.
+    constexpr int SLOT = (TM > TN ? TM : TN) * P_TK * 2, NS = DEEP ? 6 : 5, INFL = DEEP ? PX + PW : PX;
+    static_assert(SLOT * NS <= 160 * 1024, "LDS ring");
     static_assert((MI == 6 || MI == 8) && (NJ == 3 || NJ == 4), "tile shapes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,14 +401,14 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
     cx.k = cw.k = 0; cx.ti = cw.ti = 0; cx.idx = cw.idx = 0;
     set_x(cx); set_w(cw);
     auto issue_x = [&]() {
-        char* dst = smem + ((2 * cx.idx) % P_NSLOT) * P_SLOT + wave * (1024 * PX);
+        char* dst = smem + ((2 * cx.idx) % NS) * SLOT + wave * (1024 * PX);
 #pragma unroll
         for (int j = 0; j < PX; ++j) glds16(cx.q[j] + cx.k, dst + j * 1024);
         ++cx.idx; cx.k += P_TK;
         if (cx.k == p.D) { cx.k = 0; ++cx.ti; set_x(cx); }
     };
     auto issue_w = [&]() {
-        char* dst = smem + ((2 * cw.idx + 1) % P_NSLOT) * P_SLOT + wave * (1024 * PW);
+        char* dst = smem + ((2 * cw.idx + 1) % NS) * SLOT + wave * (1024 * PW);
 #pragma unroll
         for (int j = 0; j < PW; ++j) glds16(cw.q[j] + cw.k, dst + j * 1024);
         ++cw.idx; cw.k += P_TK;
@@ -414,7 +423,8 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
 
     // ---- prologue: X0, W0 landed and visible, X1 in flight
     issue_x(); issue_w(); issue_x();
-    a_wait_vm<PX>();
+    if (DEEP) issue_w();
+    a_wait_vm<INFL>();
     a_barrier();
     const unsigned lds0 = a_lds_addr(smem);
     auto body = [&](auto G_) {
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
         int kt = 0, ti = 0;
         if (G == 1) a_barrier();                               // skew: group 1 runs one barrier interval behind
         for (int s = 0; s < S; ++s) {
-            const unsigned sx = lds0 + (unsigned)((2 * s) % P_NSLOT) * P_SLOT, sw = lds0 + (unsigned)((2 * s + 1) % P_NSLOT) * P_SLOT;
+            const unsigned sx = lds0 + (unsigned)((2 * s) % NS) * SLOT, sw = lds0 + (unsigned)((2 * s + 1) % NS) * SLOT;
             bf16x8 xf[MI], wf[NJ];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -435,8 +445,8 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
                 __builtin_amdgcn_s_setprio(1);
                 a_reads(wf, (sw + wbase) ^ (h << 6));           // W first: the MFMA segment starts with wf[0..] x xf[0]
                 a_reads(xf, (sx + xbase) ^ (h << 6));
-                if (h == 0) issue_w(); else issue_x();
-                if (h == 1 && G == 1) a_wait_vm<PX>();          // group 1's loads are needed by group 0 one barrier later
+                if ((h == 0) != DEEP) issue_w(); else issue_x();
+                if (h == 1 && G == 1) a_wait_vm<INFL>();        // group 1's loads are needed by group 0 one barrier later
                 a_pin(xf, true);
                 a_pin(wf, false);
                 __builtin_amdgcn_s_setprio(0);
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
                 if (h == 0) a_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);                  // keep the counted wait behind the segment's MFMAs
-            if (G == 0) a_wait_vm<PX>();
+            if (G == 0) a_wait_vm<INFL>();
             if (++kt == nk) {
                 kt = 0;
                 int img, m0, n0, nt; decode(ti, img, m0, n0, nt); ++ti;
@@ -491,20 +501,20 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the (unused) run-ahead loads before exit
 }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool DEEP>
 int launch_pp(const AScoreArgs& a, float* scores, hipStream_t s) {
-    constexpr int TM = 32 * MI, TN = 64 * NJ;
+    constexpr int TM = 32 * MI, TN = 64 * NJ, P_LDS = (TM > TN ? TM : TN) * P_TK * 2 * (DEEP ? 6 : 5);
     static bool attr = false;
     static int ncu = 256;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_pp<MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_pp<MI, NJ, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         attr = true;
     }
     const int nnt = (a.Nr + TN - 1) / TN, ntiles = a.n_img * ((a.Nt + TM - 1) / TM) * nnt;
-    hipLaunchKernelGGL((ascore_maxcos_pp<MI, NJ>), dim3(ntiles < ncu ? ntiles : ncu), dim3(512), P_LDS, s, a);
+    hipLaunchKernelGGL((ascore_maxcos_pp<MI, NJ, DEEP>), dim3(ntiles < ncu ? ntiles : ncu), dim3(512), P_LDS, s, a);
     return 4 * nnt;                                            // parts per target row in a.partial
 }
 
@@ -550,8 +560,9 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
     const long area128 = cover(Nt, 128) * cover(Nr, 128), area_pp = cover(Nt, tm) * cover(Nr, tn);
     const bool pp = g_visrep_ascore_variant == 2 || (g_visrep_ascore_variant == 0 && area_pp <= area128);
     if (tiled && pp) {
-        const int parts = tm == 192 ? (tn == 192 ? launch_pp<6, 3>(a, scores, s) : launch_pp<6, 4>(a, scores, s))
-                                    : (tn == 192 ? launch_pp<8, 3>(a, scores, s) : launch_pp<8, 4>(a, scores, s));
+        const int parts = tm == 192 ? (tn == 192 ? (g_visrep_ascore_deep ? launch_pp<6, 3, true>(a, scores, s) : launch_pp<6, 3, false>(a, scores, s))
+                                                 : launch_pp<6, 4, false>(a, scores, s))
+                                    : (tn == 192 ? launch_pp<8, 3, false>(a, scores, s) : launch_pp<8, 4, false>(a, scores, s));
         hipLaunchKernelGGL(ascore_finalize_tiles, dim3((n_img + 3) / 4), dim3(256), 0, s, partial, a.c_other, scores, n_img, Nt, parts);
         return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
     }

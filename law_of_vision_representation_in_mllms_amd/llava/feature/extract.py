@@ -114,15 +114,26 @@ def inference(model_args, data_args, training_args, model=None, workers=8, devic
             yield chunk, torch.stack([f.result() for f in pending])
             pending = nxt
 
-    with torch.no_grad(), ThreadPoolExecutor(max_workers=workers) as pool:
+    def save(feat, out_path):
+        # extract.py:211-214 `torch.save(feat.squeeze().cpu().clone(), path)`; the clone out of the batch tensor is made on the writer thread
+        os.makedirs(os.path.dirname(out_path), exist_ok=True)
+        torch.save(feat.squeeze().clone(), out_path)
+
+    # one download per batch, files written by a small pool behind the GPU (at most two batches of features in flight)
+    with torch.no_grad(), ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=max(1, min(workers, 8))) as writers:
         stream = _device_input_stream(chunks, processor, data_args.image_aspect_ratio, model.device) if device_decode else host_stream(pool)
+        inflight = []
         for chunk, images in stream:
             images = images.to(dtype=torch.bfloat16)
-            outputs = model(images)
-            for (_, out_path), feat in zip(chunk, torch.split(outputs, 1)):
-                os.makedirs(os.path.dirname(out_path), exist_ok=True)
-                torch.save(feat.squeeze().cpu().clone(), out_path)
-                written += 1
+            outputs = model(images).cpu()
+            inflight.append([writers.submit(save, feat, out_path) for (_, out_path), feat in zip(chunk, torch.split(outputs, 1))])
+            written += len(chunk)
+            if len(inflight) > 2:
+                for f in inflight.pop(0):
+                    f.result()
+        for batch in inflight:
+            for f in batch:
+                f.result()                                             # re-raises a failed write
     return written
 
 

@@ -31,7 +31,8 @@ def ev_time(fn, reps=10, warm=3):
     return best
 
 
-for Nt, Nr, D in ((576, 576, 4096), (576, 256, 4096), (256, 576, 4096), (256, 256, 4096), (196, 576, 4096), (196, 256, 4096), (729, 576, 4096), (576, 576, 1024)):
+only = int(os.environ.get("ASCORE_SHAPES", "0"))        # > 0: only the first shapes (PMC passes)
+for Nt, Nr, D in ((576, 576, 4096), (576, 256, 4096), (256, 576, 4096), (256, 256, 4096), (196, 576, 4096), (196, 256, 4096), (729, 576, 4096), (576, 576, 1024))[: only or None]:
     o = torch.randn(n, Nt, D, device=dev, generator=g).to(torch.bfloat16)
     r = torch.randn(n, Nr, D, device=dev, generator=g).to(torch.bfloat16)
     so, sr = ascore_ops.row_scales(o), ascore_ops.row_scales(r)
