@@ -168,6 +168,24 @@ int visrep_softmax_rows_f32(float* x, int ld, long rows, int cols, void* stream)
 size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B);
 int visrep_vit_forward_f32(const visrep_vit_config* cfg, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
                            void* workspace, void* stream);
+/* ---- fp32 on the bf16 matrix pipe ("split-bf16"): an fp32 value x is carried as three bf16 planes hi = bf16(x), mid = bf16(x - hi),
+ * lo = bf16(x - hi - mid) (24 significand bits); a product sum over the six plane pairs (hi,hi) (hi,mid) (hi,lo) (mid,hi) (mid,mid) (lo,hi),
+ * accumulated in fp32 by v_mfma_f32_16x16x32_bf16, differs from the exact fp32 result by ~1e-7 relative - below the rounding of an fp32
+ * FMA chain - at 16/6 of the exact-fp32 MFMA rate.  The reference-precision towers (C_score/extract_feature.py:36-45: CLIP / OpenCLIP /
+ * DINOv2 in fp32) run their projections this way; tests/test_gpu_f32.py holds the route to the same bars as the exact-fp32 one. */
+/* planes [rows, 3 K] bf16 = hi | mid | lo of x fp32 [rows, K] (ldx floats per row); K, ldx % 4 == 0 */
+int visrep_split_bf16x3(const float* x, int ldx, long rows, int K, void* planes, void* stream);
+/* C [M, N] fp32 (ldc; may be NULL) and / or out_planes [M, 3 N] (may be NULL) = epilogue(A W^T): v = act(A W^T + bias);
+ * v = resid + ls * v when resid != NULL (resid fp32 [M, ldc], may alias C; ls [N] or NULL = 1).  a_planes [M, 3 K], w_planes [N, 3 K]
+ * from visrep_split_bf16x3; N % 256 == 0, K % 64 == 0; act = VISREP_ACT_* evaluated with libm expf / erff / tanhf. */
+int visrep_gemm_f32_split(const void* a_planes, const void* w_planes, int M, int N, int K, const float* bias, int act, const float* resid,
+                          const float* ls, float* C, int ldc, void* out_planes, void* stream);
+/* 1 when visrep_vit_forward_f32_split takes this tower (d, mlp % 256 == 0, head width 64) */
+int visrep_vit_f32_split_supported(const visrep_vit_config* cfg);
+/* visrep_vit_forward_f32 with the projections as split-bf16 GEMMs.  w: the fp32 weights (vectors, patch matrix); wsplit: same struct whose
+ * wqkv / wo / w1 / w2 point to the plane triples [N, 3 K] of the fp32 matrices (other fields ignored).  Same workspace size. */
+int visrep_vit_forward_f32_split(const visrep_vit_config* cfg, const visrep_vit_weights* w, const visrep_vit_weights* wsplit, const float* pixels,
+                                 float* hidden, int B, int n_layers, void* workspace, void* stream);
 
 /* ---- fp32 convolution-block primitives of the supervised C-score post-processor (C_score/model_utils/projection_network.py:15-125
  * AggregationNetwork = detectron2-style BottleneckBlocks, model_utils/resnet.py:174-286: 1x1 / 3x3 / 1x1 bias-free convolutions, each

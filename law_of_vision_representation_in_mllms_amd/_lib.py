@@ -79,6 +79,10 @@ SIGNATURES = {
     "visrep_softmax_rows_f32": (_i, [_vp, _i, _l, _i, _vp]),
     "visrep_vit_f32_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
     "visrep_vit_forward_f32": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _vp]),
+    "visrep_split_bf16x3": (_i, [_vp, _i, C.c_long, _i, _vp, _vp]),
+    "visrep_gemm_f32_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "visrep_vit_f32_split_supported": (_i, [C.POINTER(VitConfig)]),
+    "visrep_vit_forward_f32_split": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _vp]),
     "visrep_im2col3x3_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "visrep_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -231,10 +231,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
 int g_visrep_f32_unfused_attention = 0;   // diagnostic: 1 = the three-launch attention (batched Q K^T -> softmax rows -> P V) for every head width
 namespace {
 
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the subtractions are exact in fp32, so the three planes
+// carry 24 significand bits - the operands of the split-bf16 GEMM (gemm_bf16_v5.hip EPI_F32X)
+VR_DEV void split3(const float (&v)[4], u32x2& hi, u32x2& mid, u32x2& lo) {
+    hi = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    const float r0 = v[0] - bf_lo(hi[0]), r1 = v[1] - bf_hi(hi[0]), r2 = v[2] - bf_lo(hi[1]), r3 = v[3] - bf_hi(hi[1]);
+    mid = u32x2{pack_bf16(r0, r1), pack_bf16(r2, r3)};
+    lo = u32x2{pack_bf16(r0 - bf_lo(mid[0]), r1 - bf_hi(mid[0])), pack_bf16(r2 - bf_lo(mid[1]), r3 - bf_hi(mid[1]))};
+}
+
+// fp32 [rows, K] (leading dimension ldx) -> bf16 planes [rows, 3 K] = hi | mid | lo; K % 4 == 0
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, int ldx, long rows, int K, bf16_t* __restrict__ planes) {
+    const long total = rows * (K / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / (K / 4);
+        const int c = (int)(i - r * (K / 4)) * 4;
+        const float4 f = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        u32x2 ph, pm, pl;
+        split3(v, ph, pm, pl);
+        bf16_t* dst = planes + r * 3 * K + c;
+        *reinterpret_cast<u32x2*>(dst) = ph;
+        *reinterpret_cast<u32x2*>(dst + K) = pm;
+        *reinterpret_cast<u32x2*>(dst + 2 * K) = pl;
+    }
+}
+
 struct AttnF32Args {
     const float* q; const float* k; const float* v; float* out;
     int B, T, H, ld, ldo;
     float sc;                                                 // scale * log2(e)
+    bf16_t* planes; int ldp, pd;                              // split-bf16 route: the context's three bf16 planes [M, 3 pd] instead of `out`
 };
 constexpr int AKT = 64, ALD = 65;
 
@@ -338,6 +365,22 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnF32Args p) {
     l_run += __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_run;
     // lane holds O[q][d = dt * 32 + (r & 3) + 8 (r >> 2) + 4 hi]
+    if (p.planes) {
+        bf16_t* prow = p.planes + (tok0 + qloc) * p.ldp + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float v[4] = {o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv};
+                u32x2 ph, pm, pl;
+                split3(v, ph, pm, pl);
+                bf16_t* dst = prow + dt * 32 + rg * 8 + hi * 4;
+                *reinterpret_cast<u32x2*>(dst) = ph;
+                *reinterpret_cast<u32x2*>(dst + p.pd) = pm;
+                *reinterpret_cast<u32x2*>(dst + 2 * p.pd) = pl;
+            }
+        return;
+    }
     float* orow = p.out + (tok0 + qloc) * p.ldo + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -363,6 +406,32 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
     float* yr = y + (size_t)row * ldy;
     for (int c = lane; c < d; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+}
+
+// the same LayerNorm writing the three bf16 planes of its output [rows, 3 d] (the split-bf16 GEMM's operand) instead of fp32; d % 4 == 0
+__global__ __launch_bounds__(256) void layernorm_f32_split_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                                  const float* __restrict__ b, bf16_t* __restrict__ planes, int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; q += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    bf16_t* pr = planes + (size_t)row * 3 * d;
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c), gv = *reinterpret_cast<const float4*>(g + c), bv = *reinterpret_cast<const float4*>(b + c);
+        const float v[4] = {(xv.x - mean) * rstd * gv.x + bv.x, (xv.y - mean) * rstd * gv.y + bv.y, (xv.z - mean) * rstd * gv.z + bv.z,
+                            (xv.w - mean) * rstd * gv.w + bv.w};
+        u32x2 ph, pm, pl;
+        split3(v, ph, pm, pl);
+        *reinterpret_cast<u32x2*>(pr + c) = ph;
+        *reinterpret_cast<u32x2*>(pr + d + c) = pm;
+        *reinterpret_cast<u32x2*>(pr + 2 * d + c) = pl;
+    }
 }
 
 // in-place softmax over `cols` of every row (max-subtracted, expf, one division per element) - one wave per row
@@ -488,9 +557,62 @@ WsF32 layout_f32(const visrep_vit_config* c, int B) {
     return w;
 }
 
+// split-bf16 route: planes of the LayerNorm / attention output [M, 3 d] bf16, fp32 Q | K | V [M, 3 d], planes of the MLP hidden [M, 3 mlp] bf16
+// (the embedding's im2col columns and patch rows alias it)
+struct WsF32X { size_t hp, qkv, mlpp, total; };
+WsF32X layout_f32x(const visrep_vit_config* c, int B) {
+    WsF32X w;
+    const size_t M = (size_t)B * c->tokens;
+    size_t off = 0;
+    w.hp = off;  off += up256(M * 3 * c->d * 2);
+    w.qkv = off; off += up256(M * 3 * c->d * 4);
+    const size_t mlp_b = M * 3 * c->mlp * 2;
+    const size_t P = (size_t)c->tokens - c->has_cls;
+    const size_t emb_b = up256((size_t)B * P * c->kpad * 4) + (size_t)B * P * c->d * 4;
+    w.mlpp = off; off += up256(mlp_b > emb_b ? mlp_b : emb_b);
+    w.total = off;
+    return w;
+}
+
+// fp32 GEMM on the bf16 matrix pipe: C = epilogue(A W^T) with A, W given as bf16 plane triples (see GemmArgs::ksplit)
+int launch_gemm_split(const bf16_t* Ap, const bf16_t* Wp, int M, int N, int K, const float* bias, int act, const float* resid, const float* ls, float* C,
+                      int ldc, bf16_t* planes, hipStream_t s) {
+    GemmArgs a{};
+    a.A = Ap; a.W = Wp; a.C = reinterpret_cast<bf16_t*>(C); a.bias = bias; a.ls = ls; a.resid32 = resid; a.planes = planes; a.ldp = 3 * N;
+    a.M = M; a.N = N; a.K = 6 * K; a.ksplit = K; a.lda = 3 * K; a.ldw = 3 * K; a.ldc = ldc; a.epi = EPI_F32X; a.act = act;
+    if (!visrep_gemm_v5_supports(a)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm_f32_split: N % 256 == 0 and K % 64 == 0");
+    return visrep_gemm_v5_dispatch(a, s);
+}
+
+bool split_route_supported(const visrep_vit_config* c) {
+    return c->d % 256 == 0 && c->mlp % 256 == 0 && c->d % 64 == 0 && c->mlp % 64 == 0 && (c->d / c->heads) == 64;
+}
+
 }  // namespace
 
 #define VR_TRY(x) do { const int rc_ = (x); if (rc_) return rc_; } while (0)
+
+extern "C" int visrep_split_bf16x3(const float* x, int ldx, long rows, int K, void* planes, void* stream) {
+    if (!x || !planes) return visrep_set_error(VISREP_ERR_ARG, "split_bf16x3: null pointer");
+    if (rows <= 0) return 0;
+    if (K <= 0 || (K & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)planes & 7))
+        return visrep_set_error(VISREP_ERR_SHAPE, "split_bf16x3: K and ldx must be multiples of 4, x 16-byte aligned");
+    const long total = rows * (K / 4);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, rows, K, (bf16_t*)planes);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "split_bf16x3: launch failed");
+}
+
+extern "C" int visrep_gemm_f32_split(const void* a_planes, const void* w_planes, int M, int N, int K, const float* bias, int act, const float* resid,
+                                     const float* ls, float* C, int ldc, void* out_planes, void* stream) {
+    if (!a_planes || !w_planes || (!C && !out_planes)) return visrep_set_error(VISREP_ERR_ARG, "gemm_f32_split: null pointer");
+    if (M <= 0) return 0;
+    if (C && (ldc < N || (ldc & 3))) return visrep_set_error(VISREP_ERR_SHAPE, "gemm_f32_split: ldc >= N, % 4 == 0");
+    return launch_gemm_split((const bf16_t*)a_planes, (const bf16_t*)w_planes, M, N, K, bias, act, resid, ls, C, C ? ldc : N, (bf16_t*)out_planes,
+                             (hipStream_t)stream);
+}
+
+extern "C" int visrep_vit_f32_split_supported(const visrep_vit_config* cfg) { return cfg && split_route_supported(cfg) ? 1 : 0; }
 
 extern "C" int visrep_gemm_f32(const float* A, int lda, const float* W, int ldw, int w_kn, const float* bias, float* C, int ldc, int M, int N, int K,
                                int epilogue, int act, const float* resid, const float* ls, float alpha, int nb1, int nb2, const long* strides6,
@@ -549,7 +671,8 @@ extern "C" int visrep_softmax_rows_f32(float* x, int ld, long rows, int cols, vo
 
 extern "C" size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B) {
     if (!cfg || B <= 0) return 0;
-    return layout_f32(cfg, B).total;
+    const size_t a = layout_f32(cfg, B).total, b = layout_f32x(cfg, B).total;     // one workspace serves both routes
+    return a > b ? a : b;
 }
 
 // The composed fp32 forward: same structure as visrep_vit_forward (HF CLIPVisionTransformer / Dinov2Model / SiglipVisionTransformer
@@ -623,6 +746,64 @@ extern "C" int visrep_vit_forward_f32(const visrep_vit_config* c, const visrep_v
         f.A = mlp; f.lda = c->mlp; f.K = c->mlp; f.W = (const float*)W.w2; f.ldw = c->mlp; f.N = d; f.C = x; f.ldc = d; f.bias = W.b2; f.epi = EPI_RESID; f.act = 0;
         f.resid = x; f.ls = W.ls2;
         VR_TRY(launch_gemm_f32(f, 1, s));
+    }
+    return 0;
+}
+
+
+// The same forward with every projection on the bf16 matrix pipe at fp32 accuracy (16x the exact-fp32 MFMA rate for 6x the products):
+// LayerNorm and the fused fp32 attention write the three bf16 planes of their outputs, the projections are EPI_F32X GEMMs over the six
+// significant plane pairs (error ~1e-7 relative per product sum, below the fp32 rounding of the native route), bias / activation /
+// LayerScale / residual stay fp32 in their epilogues, the MLP hidden only ever exists as planes.  wsplit: a visrep_vit_weights whose
+// wqkv / wo / w1 / w2 point to the bf16 plane triples [N, 3 K] of the fp32 matrices (visrep_split_bf16x3); its other fields are ignored.
+// Towers whose shapes the 256 x 256 kernel does not take (d or mlp not a multiple of 256, head width != 64:
+// visrep_vit_f32_split_supported) must use visrep_vit_forward_f32.
+extern "C" int visrep_vit_forward_f32_split(const visrep_vit_config* c, const visrep_vit_weights* w, const visrep_vit_weights* wsplit, const float* pixels,
+                                            float* hidden, int B, int n_layers, void* workspace, void* stream) {
+    if (!c || !w || !wsplit || !pixels || !hidden || !workspace) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32_split: null pointer");
+    if (B <= 0) return 0;
+    if (n_layers < 0 || n_layers > c->layers) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32_split: n_layers out of range");
+    if (!split_route_supported(c)) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward_f32_split: d and mlp must be multiples of 256, head width 64");
+    const int grid = c->image_size / c->patch;
+    if (grid * grid + (c->has_cls ? 1 : 0) != c->tokens) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward_f32_split: tokens != grid^2 + cls");
+    hipStream_t s = (hipStream_t)stream;
+    const WsF32X L = layout_f32x(c, B);
+    char* base = (char*)workspace;
+    float* x = hidden;
+    bf16_t* hp = (bf16_t*)(base + L.hp);
+    float* qkv = (float*)(base + L.qkv);
+    bf16_t* mlpp = (bf16_t*)(base + L.mlpp);
+    const int d = c->d, T = c->tokens, P = grid * grid, M = B * T, H = c->heads;
+
+    // ---- embeddings: exact-fp32 route (0.3 % of the FLOP)
+    float* cols = (float*)mlpp;
+    float* prow = (float*)((char*)mlpp + up256((size_t)B * P * c->kpad * 4));
+    hipLaunchKernelGGL(im2col_f32_kernel, dim3(2048), dim3(256), 0, s, pixels, cols, B, c->image_size, c->patch, c->kpad);
+    GemmF32Args g{};
+    g.A = cols; g.lda = c->kpad; g.W = (const float*)w->patch_w; g.ldw = c->kpad; g.C = prow; g.ldc = d; g.bias = w->patch_b;
+    g.M = B * P; g.N = d; g.K = c->kpad; g.epi = EPI_BIAS; g.alpha = 1.f; g.nb2 = 1;
+    VR_TRY(launch_gemm_f32(g, 1, s));
+    hipLaunchKernelGGL(embed_finish_f32_kernel, dim3(2048), dim3(256), 0, s, prow, w->cls, w->pos, x, B, T, P, d);
+    if (hipGetLastError() != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32_split: embedding launch failed");
+    if (c->pre_ln) VR_TRY(visrep_layernorm_f32(x, d, w->pre_ln_g, w->pre_ln_b, x, d, M, d, c->eps, stream));
+
+    const float scale = 1.0f / sqrtf(64.0f);
+    auto ln_split = [&](const float* gma, const float* bta) {
+        hipLaunchKernelGGL(layernorm_f32_split_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, d, gma, bta, hp, M, d, c->eps);
+        return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32_split: layernorm launch failed");
+    };
+    for (int l = 0; l < n_layers; ++l) {
+        const visrep_vit_layer& W = w->layers[l];
+        const visrep_vit_layer& S = wsplit->layers[l];
+        VR_TRY(ln_split(W.ln1_g, W.ln1_b));
+        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wqkv, M, 3 * d, d, W.bqkv, ACT_NONE, nullptr, nullptr, qkv, 3 * d, nullptr, s));
+        AttnF32Args at{qkv, qkv + d, qkv + 2 * d, nullptr, B, T, H, 3 * d, d, scale * 1.4426950408889634f, hp, 3 * d, d};
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
+        if (hipGetLastError() != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32_split: attention launch failed");
+        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wo, M, d, d, W.bo, ACT_NONE, x, W.ls1, x, d, nullptr, s));
+        VR_TRY(ln_split(W.ln2_g, W.ln2_b));
+        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.w1, M, c->mlp, d, W.b1, c->act, nullptr, nullptr, nullptr, c->mlp, mlpp, s));
+        VR_TRY(launch_gemm_split(mlpp, (const bf16_t*)S.w2, M, d, c->mlp, W.b2, ACT_NONE, x, W.ls2, x, d, nullptr, s));
     }
     return 0;
 }

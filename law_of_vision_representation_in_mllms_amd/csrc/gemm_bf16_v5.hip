@@ -150,8 +150,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 
     // ---- LDS-DMA source cursors.  Wave w covers rows [32w, 32w+32) of both operand tiles: 4 instructions of 8 rows x 128 B.
     //      lane -> (row = 8j + lane>>3, physical slot = lane&7); it fetches logical slot (lane&7) ^ ((row>>1)&7).
-    struct Cur { const bf16_t* p[4]; int k, ti, idx; };
+    // EPI_F32X: K = 6 ksplit walks six (A plane, W plane) pairs; the logical position k maps to column plane * ksplit + (k mod ksplit) of
+    // the operand's [rows, 3 ksplit] plane matrix: A planes 0 0 0 1 1 2, W planes 0 1 2 0 1 0 (two bits per segment in the constants below)
+    constexpr bool SPLIT = EPI == EPI_F32X;
+    struct Cur { const bf16_t* p[4]; int k, ti, idx, kin, seg; };
     Cur cx, cw;
+    auto col_of = [&](const Cur& c, unsigned tab) { return SPLIT ? (int)((tab >> (2 * c.seg)) & 3u) * p.ksplit + c.kin : c.k; };
+    auto advance = [&](Cur& c) {
+        ++c.idx; c.k += TK;
+        if (SPLIT) { c.kin += TK; if (c.kin == p.ksplit) { c.kin = 0; ++c.seg; } }
+    };
     auto set_x = [&](Cur& c) {
         int m0, n0; tw.decode(c.ti, m0, n0);
 #pragma unroll
@@ -173,28 +181,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         for (int j = 0; j < 4; ++j)
             c.p[j] = p.W + (size_t)(n0 + wave * 32 + j * 8 + (lane >> 3)) * p.ldw + (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 3);
     };
-    cx.k = cw.k = 0; cx.ti = cw.ti = 0; cx.idx = cw.idx = 0;
+    cx.k = cw.k = 0; cx.ti = cw.ti = 0; cx.idx = cw.idx = 0; cx.kin = cw.kin = 0; cx.seg = cw.seg = 0;
     set_x(cx); set_w(cw);
     auto issue_x = [&]() {
         char* dst = smem + ((2 * cx.idx) % NSLOT) * XW_BYTES + wave * 4096;
+        const int kc = col_of(cx, 0x940u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(cx.p[j] + cx.k, dst + j * 1024);
-        ++cx.idx; cx.k += TK;
-        if (cx.k == p.K) { cx.k = 0; ++cx.ti; set_x(cx); }
+        for (int j = 0; j < 4; ++j) glds16(cx.p[j] + kc, dst + j * 1024);
+        advance(cx);
+        if (cx.k == p.K) { cx.k = 0; cx.kin = 0; cx.seg = 0; ++cx.ti; set_x(cx); }
     };
     auto issue_w = [&]() {
+        const int kc = col_of(cw, 0x124u);
         if (V5_OWN) {                                         // group 0 only: eight pieces, rows 64 wn + 8 j + lane>>3
             char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wn * 8192;
             const size_t step = (size_t)16 * p.ldw;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) glds16(cw.p[j & 1] + (j >> 1) * step + cw.k, dst + j * 1024);
+            for (int j = 0; j < 8; ++j) glds16(cw.p[j & 1] + (j >> 1) * step + kc, dst + j * 1024);
         } else {
             char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wave * 4096;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(cw.p[j] + cw.k, dst + j * 1024);
+            for (int j = 0; j < 4; ++j) glds16(cw.p[j] + kc, dst + j * 1024);
         }
-        ++cw.idx; cw.k += TK;
-        if (cw.k == p.K) { cw.k = 0; ++cw.ti; set_w(cw); }
+        advance(cw);
+        if (cw.k == p.K) { cw.k = 0; cw.kin = 0; cw.seg = 0; ++cw.ti; set_w(cw); }
     };
 
     // ---- fragment read offsets (16x16x32 operands): row = base16 + (lane&15), logical slot = 4*h + (lane>>4),
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 kt = 0;
                 int m0, n0; tw.decode(ti, m0, n0); ++ti;
                 const int mb = m0 + grp * 128, nb = n0 + wn * 64;
-                if (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, hi);
+                if constexpr (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, hi);
+                else if constexpr (EPI == EPI_F32X) gemm_epilogue_f32x<8, 4>(p, acc, mb, nb, fr, hi);
                 else gemm_epilogue_rowmajor<EPI, 8, 4, true>(p, acc, mb, nb, fr, hi);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -297,7 +308,10 @@ int launch5(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool visrep_gemm_v5_supports(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0; }
+bool visrep_gemm_v5_supports(const GemmArgs& a) {
+    if (a.epi == EPI_F32X && (a.ksplit <= 0 || a.ksplit % TK || a.K != 6 * a.ksplit)) return false;
+    return a.N % TN == 0 && a.K % TK == 0;
+}
 
 int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
@@ -307,6 +321,7 @@ int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s) {
         case EPI_RESID: return launch5<EPI_RESID>(a, s);
         case EPI_VT: return launch5<EPI_VT>(a, s);
         case EPI_F32: return launch5<EPI_F32>(a, s);
+        case EPI_F32X: return launch5<EPI_F32X>(a, s);
     }
     return visrep_set_error(VISREP_ERR_ARG, "gemm: unknown epilogue");
 }

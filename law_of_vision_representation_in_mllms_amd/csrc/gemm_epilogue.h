@@ -317,3 +317,92 @@ VR_DEV void gemm_epilogue_vt(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb
     if (p.ln_rt) gemm_epilogue_vt_impl<NI, NJ, true>(p, acc, mb, nb, fr, hg);
     else gemm_epilogue_vt_impl<NI, NJ, false>(p, acc, mb, nb, fr, hg);
 }
+
+// ---- EPI_F32X: fp32 epilogue of the split-bf16 GEMM (16x16 accumulators): bias, EXACT activation (libm expf / erff / tanhf like the
+// fp32 tower path, f32ops.hip), LayerScale + fp32 residual, fp32 output and / or the output's own three bf16 planes (the next GEMM's operand)
+VR_DEV float act_exact_f32(float x, int act) {
+    switch (act) {
+        case ACT_QUICK_GELU: return x * (1.0f / (1.0f + expf(-1.702f * x)));          // x * sigmoid(1.702 x) (HF QuickGELUActivation)
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_GELU_TANH: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+        default: return x;
+    }
+}
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the subtractions are exact in fp32, 24 significand bits survive
+VR_DEV void split_bf16x3(const float (&v)[4], u32x2& hi, u32x2& mid, u32x2& lo) {
+    hi = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    const float r0 = v[0] - bf_lo(hi[0]), r1 = v[1] - bf_hi(hi[0]), r2 = v[2] - bf_lo(hi[1]), r3 = v[3] - bf_hi(hi[1]);
+    mid = u32x2{pack_bf16(r0, r1), pack_bf16(r2, r3)};
+    lo = u32x2{pack_bf16(r0 - bf_lo(mid[0]), r1 - bf_hi(mid[0])), pack_bf16(r2 - bf_lo(mid[1]), r3 - bf_hi(mid[1]))};
+}
+
+template <int NI, int NJ, int ACT>
+VR_DEV void gemm_epilogue_f32x_act(const GemmArgs& p, const f32x4 (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    float4 bv[NJ], lv[NJ];
+    auto col = [&](int j) { return nb + j * 16 + hg * 4; };
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { bv[j] = float4{0.f, 0.f, 0.f, 0.f}; lv[j] = float4{1.f, 1.f, 1.f, 1.f}; }
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + col(j));
+    }
+    if (p.ls) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) lv[j] = *reinterpret_cast<const float4*>(p.ls + col(j));
+    }
+    drain_visible_loads();
+    float* C32 = reinterpret_cast<float*>(p.C);
+    const float* R = p.resid32;
+    constexpr int RB = 1;                                     // rows whose residual loads are in flight together (2: 12 VGPR spills)
+#pragma unroll
+    for (int i0 = 0; i0 < NI; i0 += RB) {
+        float4 rv[RB][NJ];
+        bool ok[RB];
+        size_t row[RB];
+#pragma unroll
+        for (int ii = 0; ii < RB; ++ii) {
+            const int m = mb + (i0 + ii) * 16 + fr;
+            ok[ii] = m < p.M;
+            row[ii] = (size_t)(ok[ii] ? m : p.M - 1);
+            if (R) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) rv[ii][j] = *reinterpret_cast<const float4*>(R + row[ii] * p.ldc + col(j));
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < RB; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 a = acc[i0 + ii][j];
+                float v[4] = {a[0] + bv[j].x, a[1] + bv[j].y, a[2] + bv[j].z, a[3] + bv[j].w};
+                if (ACT != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_exact_f32(v[e], ACT);
+                }
+                if (R) {
+                    v[0] = rv[ii][j].x + lv[j].x * v[0]; v[1] = rv[ii][j].y + lv[j].y * v[1];
+                    v[2] = rv[ii][j].z + lv[j].z * v[2]; v[3] = rv[ii][j].w + lv[j].w * v[3];
+                }
+                if (!ok[ii]) continue;
+                if (C32) store_b128(C32 + row[ii] * p.ldc + col(j), f32x4{v[0], v[1], v[2], v[3]});
+                if (p.planes) {
+                    u32x2 hi, mid, lo;
+                    split_bf16x3(v, hi, mid, lo);
+                    bf16_t* pr = p.planes + row[ii] * p.ldp + col(j);
+                    store_b64(pr, hi);
+                    store_b64(pr + p.N, mid);
+                    store_b64(pr + 2 * p.N, lo);
+                }
+            }
+    }
+}
+
+template <int NI, int NJ>
+VR_DEV void gemm_epilogue_f32x(const GemmArgs& p, const f32x4 (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    switch (p.epi == EPI_F32X ? p.act : ACT_NONE) {
+        case ACT_QUICK_GELU: gemm_epilogue_f32x_act<NI, NJ, ACT_QUICK_GELU>(p, acc, mb, nb, fr, hg); break;
+        case ACT_GELU_ERF: gemm_epilogue_f32x_act<NI, NJ, ACT_GELU_ERF>(p, acc, mb, nb, fr, hg); break;
+        case ACT_GELU_TANH: gemm_epilogue_f32x_act<NI, NJ, ACT_GELU_TANH>(p, acc, mb, nb, fr, hg); break;
+        default: gemm_epilogue_f32x_act<NI, NJ, ACT_NONE>(p, acc, mb, nb, fr, hg); break;
+    }
+}

@@ -7,7 +7,7 @@
 
 typedef unsigned short bf16_t;
 
-enum { EPI_BIAS = 0, EPI_ACT = 1, EPI_RESID = 2, EPI_VT = 3, EPI_PATCH = 4, EPI_F32 = 5 };
+enum { EPI_BIAS = 0, EPI_ACT = 1, EPI_RESID = 2, EPI_VT = 3, EPI_PATCH = 4, EPI_F32 = 5, EPI_F32X = 6 };
 
 struct GemmArgs {
     const bf16_t* A;      // [M, K] row-major, leading dimension lda (elements)
@@ -36,6 +36,14 @@ struct GemmArgs {
     // implicit 3x3 convolution (v1 kernel, conv = 1): A is the channels-last activation [B, cH, cW, cC] and the A tile of
     // K-tile (tap, c0) is gathered on the fly: row m = (b, oy, ox) reads x[b, (oy*cstride+ky-cpad)>>cup, (ox*cstride+kx-cpad)>>cup, c0..]
     int conv, cH, cW, cC, cHo, cWo, cstride, cpad, cup;
+    // EPI_F32X (variant 5 only): an fp32 GEMM on the bf16 matrix pipe.  A and W hold the three bf16 planes (hi | mid | lo, x = hi + mid + lo
+    // to 24 bits) of fp32 matrices side by side: A [M, 3 ksplit], W [N, 3 ksplit]; K = 6 ksplit walks the six plane pairs whose product
+    // terms are >= 2^-24 of the result: (hi, hi) (hi, mid) (hi, lo) (mid, hi) (mid, mid) (lo, hi).  Epilogue in fp32:
+    // v = act(acc + bias); v = resid32 + ls * v (if resid32); C (fp32, may be null) and / or the three planes of v -> planes [M, 3 N].
+    int ksplit;
+    const float* resid32;
+    bf16_t* planes;
+    int ldp;
     unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };

@@ -163,7 +163,11 @@ class VitEngineF32:
     1/20 of the bf16 engine's throughput (exact-fp32 MFMA peak is 157 TFLOP/s), any head width that is a multiple of 4.
     forward() returns fp32 [B, tokens, d]; images are processed in chunks so that the fp32 score matrices stay below `max_ws_bytes`."""
 
-    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30):
+    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30, gemm: str = "auto"):
+        """gemm: 'split' = projections as split-bf16 GEMMs on the bf16 matrix pipe (fp32 values as three bf16 planes, six plane-pair
+        products, fp32 accumulation: ~1e-7 relative per product sum, visrep_vit_forward_f32_split); 'native' = exact-fp32 MFMA
+        (visrep_vit_forward_f32); 'auto' = split where the tower's shapes allow it (d, mlp % 256 == 0, head width 64), VISREP_F32_GEMM
+        in the environment overrides."""
         self.lib = _lib.require_gpu()
         self.spec = spec
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -206,6 +210,35 @@ class VitEngineF32:
                                    int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
         self._ws: Dict[int, torch.Tensor] = {}
         self._pinned = set()                 # batch sizes whose workspace a captured HIP graph refers to
+        import os
+        gemm = os.environ.get("VISREP_F32_GEMM", gemm)
+        if gemm not in ("auto", "split", "native"):
+            raise ValueError(f"gemm must be 'auto', 'split' or 'native', got {gemm!r}")
+        can = bool(self.lib.visrep_vit_f32_split_supported(C.byref(self._cfg)))
+        if gemm == "split" and not can:
+            raise ValueError("split-bf16 route needs d and mlp to be multiples of 256 and head width 64")
+        self.gemm = "split" if (gemm != "native" and can) else "native"
+        self._wsplit = None
+        if self.gemm == "split":
+            # the four projection matrices of every layer as bf16 plane triples [N, 3 K] (hi | mid | lo), split on the device once
+            self._split_layers = (_lib.VitLayer * max(n, 1))()
+            with torch.cuda.device(self.device):
+                for i in range(n):
+                    for k in ("wqkv", "wo", "w1", "w2"):
+                        wf = self._keep_by_ptr(getattr(self._layers[i], k))
+                        planes = torch.empty(wf.shape[0], 3 * wf.shape[1], dtype=torch.bfloat16, device=dev)
+                        _lib.check(self.lib.visrep_split_bf16x3(_lib.ptr(wf), wf.stride(0), wf.shape[0], wf.shape[1], _lib.ptr(planes), _lib.stream_ptr()),
+                                   "visrep_split_bf16x3")
+                        self._keep.append(planes)
+                        setattr(self._split_layers[i], k, planes.data_ptr())
+            self._wsplit = _lib.VitWeights()
+            self._wsplit.layers = C.cast(self._split_layers, C.POINTER(_lib.VitLayer))
+
+    def _keep_by_ptr(self, ptr: int) -> torch.Tensor:
+        for t in self._keep:
+            if t.data_ptr() == ptr:
+                return t
+        raise KeyError(ptr)
 
     def chunk(self) -> int:
         per = self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), 1)
@@ -239,8 +272,12 @@ class VitEngineF32:
             for b0 in range(0, B, step):
                 nb = min(step, B - b0)
                 ws = self.workspace(nb)
-                rc = self.lib.visrep_vit_forward_f32(C.byref(self._cfg), C.byref(self._w), _lib.ptr(px[b0:b0 + nb]), _lib.ptr(out[b0:b0 + nb]),
-                                                     nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
+                if self.gemm == "split":
+                    rc = self.lib.visrep_vit_forward_f32_split(C.byref(self._cfg), C.byref(self._w), C.byref(self._wsplit), _lib.ptr(px[b0:b0 + nb]),
+                                                               _lib.ptr(out[b0:b0 + nb]), nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
+                else:
+                    rc = self.lib.visrep_vit_forward_f32(C.byref(self._cfg), C.byref(self._w), _lib.ptr(px[b0:b0 + nb]), _lib.ptr(out[b0:b0 + nb]),
+                                                         nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
                 _lib.check(rc, "visrep_vit_forward_f32")
         return out
 
@@ -252,6 +289,34 @@ def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf1
     if precision in ("fp32", "float32", torch.float32):
         return VitEngineF32(spec, weights, device)
     raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+
+
+def split_bf16x3(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, K] -> bf16 planes [rows, 3 K] = hi | mid | lo (x = hi + mid + lo to 24 bits): the operand format of gemm_f32_split."""
+    lib = _lib.require_gpu()
+    rows, K = x.shape
+    planes = torch.empty(rows, 3 * K, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.visrep_split_bf16x3(_lib.ptr(x), x.stride(0), rows, K, _lib.ptr(planes), _lib.stream_ptr()), "visrep_split_bf16x3")
+    return planes
+
+
+def gemm_f32_split(a_planes: torch.Tensor, w_planes: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
+                   resid: Optional[torch.Tensor] = None, ls: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                   planes_out: bool = False):
+    """fp32 act(A W^T + bias) (+ LayerScale, residual) on the bf16 matrix pipe from bf16 plane triples; returns the fp32 result, or its own
+    plane triple [M, 3 N] when planes_out."""
+    lib = _lib.require_gpu()
+    M, K3 = a_planes.shape
+    N, K = w_planes.shape[0], K3 // 3
+    if w_planes.shape[1] != K3:
+        raise ValueError("gemm_f32_split: operand plane widths differ")
+    po = torch.empty(M, 3 * N, dtype=torch.bfloat16, device=a_planes.device) if planes_out else None
+    if out is None and not planes_out:
+        out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
+    rc = lib.visrep_gemm_f32_split(_lib.ptr(a_planes), _lib.ptr(w_planes), M, N, K, _lib.ptr(bias), _lib.ACT[act], _lib.ptr(resid), _lib.ptr(ls),
+                                   _lib.ptr(out), out.stride(0) if out is not None else N, _lib.ptr(po), _lib.stream_ptr())
+    _lib.check(rc, "visrep_gemm_f32_split")
+    return po if planes_out else out
 
 
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS, act: str = "none",

@@ -60,6 +60,79 @@ def test_gemm_f32_against_float64(M, N, K):
     assert rel(got, 0.125 * (want - bias.double())) < 2e-6
 
 
+def test_split_bf16x3_carries_24_bits():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(37, 256, generator=g) * torch.logspace(-6, 6, 256)[None]      # 12 decades of magnitudes
+    x[3, 5] = 0.0
+    p = engine.split_bf16x3(x.to(DEV)).cpu()
+    hi, mid, lo = p[:, :256].float(), p[:, 256:512].float(), p[:, 512:].float()
+    assert torch.equal(hi, x.to(torch.bfloat16).float())                          # round-to-nearest-even planes
+    assert torch.equal(mid, (x - hi).to(torch.bfloat16).float())
+    assert torch.equal(lo, (x - hi - mid).to(torch.bfloat16).float())
+    err = ((hi.double() + mid.double() + lo.double()) - x.double()).abs()
+    assert (err <= x.abs().double() * 2.0 ** -24).all()
+    # a strided source (views of a padded buffer) gives the same planes
+    buf = torch.zeros(37, 260)
+    buf[:, :256] = x
+    assert torch.equal(engine.split_bf16x3(buf.to(DEV)[:, :256]).cpu(), p)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 256, 64), (577 * 3, 768, 768), (1000, 1024, 1024), (300, 256, 4096), (256, 3072, 1024)])
+def test_gemm_f32_split_against_float64(M, N, K):
+    """fp32 GEMM on the bf16 matrix pipe (three planes per operand, six plane-pair products, fp32 accumulation) against float64: the
+    rounding noise of an fp32 accumulation over K, like the exact-fp32 MFMA chain (6e-8 at K = 64 ... 1.3e-6 at K = 4096); fp32 epilogues (bias, exact activations, LayerScale + in-place residual) and the plane-triple
+    output (= the split of the fp32 result, bit for bit)."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    want = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    ap, wp = engine.split_bf16x3(ad), engine.split_bf16x3(wd)
+    got = engine.gemm_f32_split(ap, wp, bd)
+    e_split, e_native = rel(got, want), rel(engine.gemm_f32(ad, wd, bd), want)
+    print(f"M={M} N={N} K={K}: split {e_split:.2e}  exact-fp32 MFMA chain {e_native:.2e}")
+    assert e_split < 2e-6 and e_split < 1.5 * e_native + 5e-8, (e_split, e_native)     # measured: 1.17x the exact chain's error at every K
+    for act, ref in (("quick_gelu", lambda x: x * torch.sigmoid(1.702 * x)), ("gelu", torch.nn.functional.gelu),
+                     ("gelu_tanh", lambda x: torch.nn.functional.gelu(x, approximate="tanh"))):
+        got_a = engine.gemm_f32_split(ap, wp, bd, act=act)
+        assert rel(got_a, ref(want)) < 2e-6, act
+        assert torch.equal(engine.gemm_f32_split(ap, wp, bd, act=act, planes_out=True), engine.split_bf16x3(got_a)), act
+    res = torch.randn(M, N, generator=g)
+    ls = torch.randn(N, generator=g)
+    out = res.clone().to(DEV)
+    engine.gemm_f32_split(ap, wp, bd, resid=out, ls=ls.to(DEV), out=out)
+    assert rel(out, res.double() + ls.double() * want) < 1e-6
+    out2 = res.clone().to(DEV)
+    engine.gemm_f32_split(ap, wp, None, resid=out2, out=out2)                     # no bias, no LayerScale
+    assert rel(out2, res.double() + (want - bias.double())) < 1e-6
+    with pytest.raises(RuntimeError, match="N % 256"):
+        engine.gemm_f32_split(ap, engine.split_bf16x3(torch.randn(100, K, device=DEV)), bd[:100].contiguous())      # N % 256 != 0
+
+
+@pytest.mark.parametrize("family,image,patch", [("clip", 70, 14), ("dinov2", 154, 14), ("siglip", 48, 16)])
+def test_f32_tower_split_route_equals_the_exact_route(family, image, patch):
+    """The reference-precision tower with its projections as split-bf16 GEMMs (the default where shapes allow) against the exact-fp32 MFMA
+    route and the fp32 oracle: same bar (the two routes differ by fp32 rounding noise only)."""
+    spec = VW.tiny_spec(family, image_size=image, patch=patch, d=256, heads=4, mlp=512, layers=4)           # head width 64, d % 256 == 0
+    w = VW.synthetic_weights(spec, seed=11)
+    px = torch.from_numpy(np.random.RandomState(3).standard_normal((5, 3, image, image)).astype(np.float32))
+    split = engine.VitEngineF32(spec, w, DEV)
+    native = engine.VitEngineF32(spec, w, DEV, gemm="native")
+    assert split.gemm == "split" and native.gemm == "native"
+    a, b = split.forward(px.to(DEV)), native.forward(px.to(DEV))
+    want = OV.tower_features(spec, w, px, select_layer=spec.layers, select_feature="cls_patch")
+    es, en = rel(a, want), rel(b, want)
+    assert es < 5e-6 and en < 5e-6 and rel(a, b) < 5e-6, (es, en)
+    for n_layers in (0, 1, 3):
+        assert rel(split.forward(px.to(DEV), n_layers=n_layers), native.forward(px.to(DEV), n_layers=n_layers)) < 5e-6
+    # shapes the 256 x 256 kernel does not take fall back to the exact route; asking for the split route there is an error
+    odd = VW.tiny_spec(family, image_size=image, patch=patch, d=128, heads=2, mlp=256, layers=2)
+    assert engine.VitEngineF32(odd, VW.synthetic_weights(odd, seed=1), DEV).gemm == "native"
+    with pytest.raises(ValueError):
+        engine.VitEngineF32(odd, VW.synthetic_weights(odd, seed=1), DEV, gemm="split")
+
+
 def test_gemm_f32_is_an_exact_fma_chain():
     """v_mfma_f32_32x32x2_f32 accumulates k in order with fused multiply-adds: small-integer operands give the exact integer result
     and the result does not depend on the row / column tile an element falls in."""
