@@ -146,6 +146,33 @@ def score_extras(dev, n_a=256, n_img=1800, n_pairs=12234):
     return out
 
 
+def fp32_tower_extra(dev, spec, weights, batch=64):
+    """The same tower in the reference's C-path precision (fp32: C_score/extract_feature.py:36-45), one batch of 64: the default route
+    (projections as split-bf16 GEMMs on the bf16 matrix pipe where the shapes allow) and the exact-fp32 MFMA route beside it."""
+    from law_of_vision_representation_in_mllms_amd import engine
+    px = torch.randn(batch, 3, spec.image_size, spec.image_size, device=dev)
+    T, d, m = spec.tokens, spec.d, spec.mlp
+    fl = N_LAYERS * (2 * T * d * 3 * d + 2 * T * d * d + 4 * T * T * d + 4 * T * d * m) * batch
+    out = {"batch": batch}
+    for route in ("auto", "native"):
+        eng = engine.VitEngineF32(spec, weights, dev, gemm=route)
+        for _ in range(2):
+            eng.forward(px, n_layers=N_LAYERS)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            eng.forward(px, n_layers=N_LAYERS)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        sec = e0.elapsed_time(e1) / 3 * 1e-3
+        out[eng.gemm] = {"ms": round(sec * 1e3, 1), "images_per_s": round(batch / sec, 1), "fp32_equivalent_tflops": round(fl / sec / 1e12, 1),
+                         "frac_of_exact_fp32_mfma_roof": round(fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 3)}
+        del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def aggregate_value(world, per_rank_units, steps, seconds):
     """Whole-job throughput: units of ALL ranks (weak scaling: every rank steps over its own batch) / max-over-ranks time."""
     return world * per_rank_units * steps / seconds
@@ -306,8 +333,9 @@ def main():
     if rank == 0 and not args.no_scores:
         try:
             scores = score_extras(dev)
+            scores["fp32_tower"] = fp32_tower_extra(dev, spec, weights)
         except Exception as e:                                              # never let the extra object take the bench down
-            scores = {"error": f"{type(e).__name__}: {e}"[:300]}
+            scores = {**(scores or {}), "error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- CPU baseline: the oracle on a bounded sample, host cores of this box (rank 0, N=1 only)
     cpu = None
