@@ -45,9 +45,9 @@ N_LAYERS = 23                     # select_layer = -2: the 24th layer is never n
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0             # HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per fc1 launch at batch 256 with the default (v2) GEMM, from rocprofv3 PMC passes of this kernel at this shape
-# (profiles/round2_final_kernel_stats.md, v2: round2_v2default_kernel_stats.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
+# (profiles/round3_final_kernel_stats.md, v2: round2_v2default_kernel_stats.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md "HBM"; round 1 calibrated both on layernorm_rows' known byte count).  Algorithmic bytes are 1.52e9.
-FC1_HBM_BYTES_PER_LAUNCH = {(5, 256): 2.969e9, (2, 256): 3.055e9}
+FC1_HBM_BYTES_PER_LAUNCH = {(5, 256): 2.962e9, (2, 256): 3.055e9}
 
 
 def flops_per_image(spec, n_layers):
@@ -320,7 +320,7 @@ def main():
             head = {"error": str(e)[:200]}
         roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p", 4: "gemm_bf16_v4", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
-                "traffic": FC1_HBM_BYTES_PER_LAUNCH.get((args.gemm_variant, B)), "traffic_unit": "HBM bytes per launch (PMC, profiles/round2_final_kernel_stats.md)",
+                "traffic": FC1_HBM_BYTES_PER_LAUNCH.get((args.gemm_variant, B)), "traffic_unit": "HBM bytes per launch (PMC, profiles/round3_final_kernel_stats.md)",
                 "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),
                 "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"], "dominant_kernel_only": head,
                 "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),

@@ -93,19 +93,20 @@ def test_gemm_f32_split_against_float64(M, N, K):
     e_split, e_native = rel(got, want), rel(engine.gemm_f32(ad, wd, bd), want)
     print(f"M={M} N={N} K={K}: split {e_split:.2e}  exact-fp32 MFMA chain {e_native:.2e}")
     assert e_split < 2e-6 and e_split < 1.5 * e_native + 5e-8, (e_split, e_native)     # measured: 1.17x the exact chain's error at every K
+    tol = 2.0 * e_native + 5e-7                                                        # epilogue cases: the same accumulation noise + libm
     for act, ref in (("quick_gelu", lambda x: x * torch.sigmoid(1.702 * x)), ("gelu", torch.nn.functional.gelu),
                      ("gelu_tanh", lambda x: torch.nn.functional.gelu(x, approximate="tanh"))):
         got_a = engine.gemm_f32_split(ap, wp, bd, act=act)
-        assert rel(got_a, ref(want)) < 2e-6, act
+        assert rel(got_a, ref(want)) < tol, act
         assert torch.equal(engine.gemm_f32_split(ap, wp, bd, act=act, planes_out=True), engine.split_bf16x3(got_a)), act
     res = torch.randn(M, N, generator=g)
     ls = torch.randn(N, generator=g)
     out = res.clone().to(DEV)
     engine.gemm_f32_split(ap, wp, bd, resid=out, ls=ls.to(DEV), out=out)
-    assert rel(out, res.double() + ls.double() * want) < 1e-6
+    assert rel(out, res.double() + ls.double() * want) < tol
     out2 = res.clone().to(DEV)
     engine.gemm_f32_split(ap, wp, None, resid=out2, out=out2)                     # no bias, no LayerScale
-    assert rel(out2, res.double() + (want - bias.double())) < 1e-6
+    assert rel(out2, res.double() + (want - bias.double())) < tol
     with pytest.raises(RuntimeError, match="N % 256"):
         engine.gemm_f32_split(ap, engine.split_bf16x3(torch.randn(100, K, device=DEV)), bd[:100].contiguous())      # N % 256 != 0
 
