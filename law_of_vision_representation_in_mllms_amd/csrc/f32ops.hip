@@ -11,6 +11,7 @@
 // QKV / out / MLP projections with fused bias / activation / LayerScale + residual, and, batched over (image, head), Q K^T and
 // P V - so the softmax sees fp32 scores exactly like HF's eager attention (modeling_clip.py eager_attention_forward).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "visrep_internal.h"
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
 //     buffered, staged through registers; running maximum / sum in fp32, exp2 of the scaled difference like the bf16 kernel.
 // Arithmetic is fp32 throughout; against HF's eager softmax the results differ by summation order only (~1e-6 relative).
 }  // namespace
+int g_visrep_f32_split_attention = getenv("VISREP_F32_SPLIT_ATTENTION") ? atoi(getenv("VISREP_F32_SPLIT_ATTENTION")) : 1;   // split route: attention on the bf16 pipe too (0: exact-fp32 MFMA)
 int g_visrep_f32_unfused_attention = 0;   // diagnostic: 1 = the three-launch attention (batched Q K^T -> softmax rows -> P V) for every head width
 namespace {
 
@@ -359,6 +361,203 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnF32Args p) {
                 }
         }
         if (t + 1 < ntile) stash(buf ^ 1);                      // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    if (idle || qloc >= p.T) return;
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_run;
+    // lane holds O[q][d = dt * 32 + (r & 3) + 8 (r >> 2) + 4 hi]
+    if (p.planes) {
+        bf16_t* prow = p.planes + (tok0 + qloc) * p.ldp + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float v[4] = {o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv};
+                u32x2 ph, pm, pl;
+                split3(v, ph, pm, pl);
+                bf16_t* dst = prow + dt * 32 + rg * 8 + hi * 4;
+                *reinterpret_cast<u32x2*>(dst) = ph;
+                *reinterpret_cast<u32x2*>(dst + p.pd) = pm;
+                *reinterpret_cast<u32x2*>(dst + 2 * p.pd) = pl;
+            }
+        return;
+    }
+    float* orow = p.out + (tok0 + qloc) * p.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 v4 = {o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv};
+            *reinterpret_cast<float4*>(orow + dt * 32 + rg * 8 + hi * 4) = v4;
+        }
+}
+
+// The same attention with both contractions on the bf16 matrix pipe at fp32 accuracy (split-bf16, see gemm_bf16_v5.hip EPI_F32X): fp32
+// Q | K | V in, fp32 context (or its three bf16 planes) out, fp32 softmax.
+//   * staging: K / V tiles of 64 keys are fetched as fp32 into registers one tile ahead (under the current tile's matrix work), split into
+//     hi | mid | lo bf16 planes and written to LDS after the tile's last read: K planes [64 keys][64 d], V planes TRANSPOSED [64 d][64 keys]
+//     (a thread fetches 16 consecutive keys of ONE d, lanes along d: coalesced rows, and writes 2 x 16 bytes per plane; the keys of a
+//     16-block are stored as 0-3, 8-11 | 4-7, 12-15 so that the 8 keys a lane needs for one MFMA k-slice are 16 contiguous bytes - the
+//     perm16 order of attention.hip); both are 128-byte rows with the 16-byte slot XOR-swizzled by (row >> 1) & 7, conflict-free for
+//     ds_read_b128;
+//   * S^T = sum over the six significant plane pairs of K_i Q_j^T (v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest terms first), Q planes
+//     in registers for the whole kernel; O^T += sum over the same pairs of V_i^T P_j^T with P split in registers after the fp32 softmax.
+//   96 MFMAs of 32 cycles per 64-key tile instead of 128 exact-fp32 MFMAs of 64 cycles.
+constexpr int XPL = 64 * 64 * 2;                               // one plane of one tile: 8 KB
+
+__global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Args p) {
+    __shared__ __attribute__((aligned(16))) char Kp[3 * XPL];
+    __shared__ __attribute__((aligned(16))) char Vp[3 * XPL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int nqt = (p.T + 127) >> 7;
+    int id = blockIdx.x;
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % p.H;
+    const int b = id / p.H;
+    const size_t tok0 = (size_t)b * p.T;
+    const int qloc = qt * 128 + wave * 32 + lq;
+    const bool idle = qt * 128 + wave * 32 >= p.T;             // wave-uniform: all 32 query rows past the sequence
+
+    // ---- Q planes (B operand of k-slice kk: q = lane & 31, d = 16 kk + 8 hi .. + 8), kept in registers
+    bf16x8 qf[3][4];
+    {
+        const float* qrow = p.q + (tok0 + (qloc < p.T ? qloc : p.T - 1)) * p.ld + h * 64 + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + kk * 16), c = *reinterpret_cast<const float4*>(qrow + kk * 16 + 4);
+            const float v0[4] = {a.x, a.y, a.z, a.w}, v1[4] = {c.x, c.y, c.z, c.w};
+            u32x2 h0, m0, l0, h1, m1, l1;
+            split3(v0, h0, m0, l0);
+            split3(v1, h1, m1, l1);
+            const u32x4 wh = {h0[0], h0[1], h1[0], h1[1]}, wm = {m0[0], m0[1], m1[0], m1[1]}, wl = {l0[0], l0[1], l1[0], l1[1]};
+            qf[0][kk] = __builtin_bit_cast(bf16x8, wh); qf[1][kk] = __builtin_bit_cast(bf16x8, wm); qf[2][kk] = __builtin_bit_cast(bf16x8, wl);
+        }
+    }
+    // ---- staging maps.  K: thread -> (key = tid >> 2, d = 16 (tid & 3) .. + 16): four float4.  V: thread -> (d = tid & 63, keys 16 (tid >> 6) .. + 16).
+    const int kkey = tid >> 2, kd = (tid & 3) * 16;
+    const int vd = tid & 63, vg = tid >> 6;
+    float4 rk[4];
+    float rv[16];
+    auto fetch = [&](int t) {
+        {
+            const int key = t * 64 + kkey;
+            const float* src = p.k + (tok0 + (key < p.T ? key : p.T - 1)) * p.ld + h * 64 + kd;     // keys past the image are masked below
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rk[j] = *reinterpret_cast<const float4*>(src + 4 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int key = t * 64 + vg * 16 + j;
+            rv[j] = p.v[(tok0 + (key < p.T ? key : p.T - 1)) * p.ld + h * 64 + vd];
+        }
+    };
+    auto stash = [&]() {
+        {   // K: 16 consecutive d of one key = slots 2 (tid & 3), + 1 of row `kkey`
+            u32x2 ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float v[4] = {rk[j].x, rk[j].y, rk[j].z, rk[j].w}; split3(v, ph[j], pm[j], pl[j]); }
+            const int sw = (kkey >> 1) & 7;
+            char* r0 = Kp + kkey * 128 + (((2 * (tid & 3)) ^ sw) << 4);
+            char* r1 = Kp + kkey * 128 + (((2 * (tid & 3) + 1) ^ sw) << 4);
+            *reinterpret_cast<u32x4*>(r0) = u32x4{ph[0][0], ph[0][1], ph[1][0], ph[1][1]};
+            *reinterpret_cast<u32x4*>(r1) = u32x4{ph[2][0], ph[2][1], ph[3][0], ph[3][1]};
+            *reinterpret_cast<u32x4*>(r0 + XPL) = u32x4{pm[0][0], pm[0][1], pm[1][0], pm[1][1]};
+            *reinterpret_cast<u32x4*>(r1 + XPL) = u32x4{pm[2][0], pm[2][1], pm[3][0], pm[3][1]};
+            *reinterpret_cast<u32x4*>(r0 + 2 * XPL) = u32x4{pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+            *reinterpret_cast<u32x4*>(r1 + 2 * XPL) = u32x4{pl[2][0], pl[2][1], pl[3][0], pl[3][1]};
+        }
+        {   // V^T: keys 16 vg .. + 16 of row d = vd -> slots 2 vg (keys 0-3, 8-11) and 2 vg + 1 (keys 4-7, 12-15)
+            u32x2 ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float v[4] = {rv[4 * j], rv[4 * j + 1], rv[4 * j + 2], rv[4 * j + 3]}; split3(v, ph[j], pm[j], pl[j]); }
+            const int sw = (vd >> 1) & 7;
+            char* r0 = Vp + vd * 128 + (((2 * vg) ^ sw) << 4);
+            char* r1 = Vp + vd * 128 + (((2 * vg + 1) ^ sw) << 4);
+            *reinterpret_cast<u32x4*>(r0) = u32x4{ph[0][0], ph[0][1], ph[2][0], ph[2][1]};
+            *reinterpret_cast<u32x4*>(r1) = u32x4{ph[1][0], ph[1][1], ph[3][0], ph[3][1]};
+            *reinterpret_cast<u32x4*>(r0 + XPL) = u32x4{pm[0][0], pm[0][1], pm[2][0], pm[2][1]};
+            *reinterpret_cast<u32x4*>(r1 + XPL) = u32x4{pm[1][0], pm[1][1], pm[3][0], pm[3][1]};
+            *reinterpret_cast<u32x4*>(r0 + 2 * XPL) = u32x4{pl[0][0], pl[0][1], pl[2][0], pl[2][1]};
+            *reinterpret_cast<u32x4*>(r1 + 2 * XPL) = u32x4{pl[1][0], pl[1][1], pl[3][0], pl[3][1]};
+        }
+    };
+    // plane pairs (operand from LDS, operand from registers), smallest product terms first
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    const int rsw = (lq >> 1) & 7, rbase = lq * 128;
+
+    f32x16 o[2];
+    o[0] = f32x16{}; o[1] = f32x16{};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntile = (p.T + 63) / 64;
+    fetch(0);
+    stash();
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) fetch(t + 1);                       // next tile's fp32 rows in flight under this tile's matrix work
+        if (!idle) {
+            f32x16 s[2];
+            s[0] = f32x16{}; s[1] = f32x16{};
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int kt2 = 0; kt2 < 2; ++kt2) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + PA[pr] * XPL + kt2 * 4096 + rbase + (((2 * kk + hi) ^ rsw) << 4));
+                        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[PB[pr]][kk], s[kt2], 0, 0, 0);
+                    }
+            if ((t + 1) * 64 > p.T) {                          // last tile: mask the keys past the image
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * 64 + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.T) s[kt2][r] = -INFINITY;
+            }
+            float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s[0][r], s[1][r]));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);               // finite: every tile holds at least one valid key
+            const float msc = m_new * p.sc;
+            const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, p.sc, -msc));
+            float psum = 0.f;
+            uint32_t pb[3][2][8];
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r + e], p.sc, -msc)); psum += v[e]; }
+                    u32x2 ph, pm, pl;
+                    split3(v, ph, pm, pl);
+                    pb[0][kt2][r >> 1] = ph[0]; pb[0][kt2][(r >> 1) + 1] = ph[1];
+                    pb[1][kt2][r >> 1] = pm[0]; pb[1][kt2][(r >> 1) + 1] = pm[1];
+                    pb[2][kt2][r >> 1] = pl[0]; pb[2][kt2][(r >> 1) + 1] = pl[1];
+                }
+            l_run = __builtin_fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            // O^T += V^T P^T: chunk c = 16 keys; the P operand of plane j = 4 packed words of pb[j][c >> 1], words 4 (c & 1) .. + 4
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32x4 w = {pb[PB[pr]][c >> 1][4 * (c & 1) + 0], pb[PB[pr]][c >> 1][4 * (c & 1) + 1], pb[PB[pr]][c >> 1][4 * (c & 1) + 2],
+                                     pb[PB[pr]][c >> 1][4 * (c & 1) + 3]};
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vp + PA[pr] * XPL + dt * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();                                        // every wave is done reading this tile's planes
+        if (t + 1 < ntile) stash();
         __syncthreads();
     }
     if (idle || qloc >= p.T) return;
@@ -798,7 +997,8 @@ extern "C" int visrep_vit_forward_f32_split(const visrep_vit_config* c, const vi
         VR_TRY(ln_split(W.ln1_g, W.ln1_b));
         VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wqkv, M, 3 * d, d, W.bqkv, ACT_NONE, nullptr, nullptr, qkv, 3 * d, nullptr, s));
         AttnF32Args at{qkv, qkv + d, qkv + 2 * d, nullptr, B, T, H, 3 * d, d, scale * 1.4426950408889634f, hp, 3 * d, d};
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
+        if (g_visrep_f32_split_attention) hipLaunchKernelGGL(attn_f32_split_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
+        else hipLaunchKernelGGL(attn_f32_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
         if (hipGetLastError() != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32_split: attention launch failed");
         VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wo, M, d, d, W.bo, ACT_NONE, x, W.ls1, x, d, nullptr, s));
         VR_TRY(ln_split(W.ln2_g, W.ln2_b));

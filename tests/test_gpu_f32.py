@@ -111,7 +111,7 @@ def test_gemm_f32_split_against_float64(M, N, K):
         engine.gemm_f32_split(ap, engine.split_bf16x3(torch.randn(100, K, device=DEV)), bd[:100].contiguous())      # N % 256 != 0
 
 
-@pytest.mark.parametrize("family,image,patch", [("clip", 70, 14), ("dinov2", 154, 14), ("siglip", 48, 16)])
+@pytest.mark.parametrize("family,image,patch", [("clip", 70, 14), ("dinov2", 154, 14), ("siglip", 48, 16), ("clip", 210, 14), ("dinov2", 266, 14)])
 def test_f32_tower_split_route_equals_the_exact_route(family, image, patch):
     """The reference-precision tower with its projections as split-bf16 GEMMs (the default where shapes allow) against the exact-fp32 MFMA
     route and the fp32 oracle: same bar (the two routes differ by fp32 rounding noise only)."""
