@@ -263,15 +263,16 @@ def _stack_weights(spec, seed, hidden, gen):
     return w, (p0, b0, p2, b2)
 
 
-def test_end_to_end_a_score_from_images_fp32():
+@pytest.mark.parametrize("d,route", [(128, "native"), (256, "split")])
+def test_end_to_end_a_score_from_images_fp32(d, route):
     """images -> tower (hidden_states[-2], CLS dropped) -> mlp2x_gelu projector -> A score, every step fp32 on the device, against the
-    same chain on the CPU oracle: 1e-4 relative (the north-star bar); the bf16 engine on the same images is reported beside it."""
+    same chain on the CPU oracle: 1e-4 relative (the north-star bar); the bf16 engine on the same images is reported beside it.
+    Width 128 runs the exact-fp32 MFMA projections, width 256 the split-bf16 ones (the engine's default where the shapes allow)."""
     gen = torch.Generator().manual_seed(11)
     hidden = 256
-    specs = {"clip336": VW.tiny_spec("clip", image_size=56, patch=14, d=128, heads=2, mlp=256, layers=3),
-             "clip224": VW.tiny_spec("clip", image_size=42, patch=14, d=128, heads=2, mlp=256, layers=3),
-             "dino": VW.tiny_spec("dinov2", image_size=42, patch=14, d=128, heads=2, mlp=256, layers=3),
-             "siglip": VW.tiny_spec("siglip", image_size=48, patch=16, d=128, heads=2, mlp=256, layers=3)}
+    kw = dict(d=d, heads=d // 64, mlp=2 * d, layers=3)
+    specs = {"clip336": VW.tiny_spec("clip", image_size=56, patch=14, **kw), "clip224": VW.tiny_spec("clip", image_size=42, patch=14, **kw),
+             "dino": VW.tiny_spec("dinov2", image_size=42, patch=14, **kw), "siglip": VW.tiny_spec("siglip", image_size=48, patch=16, **kw)}
     n_img = 6
     feats_dev, feats_bf16, feats_cpu = {}, {}, {}
     for i, (name, spec) in enumerate(specs.items()):
@@ -280,7 +281,9 @@ def test_end_to_end_a_score_from_images_fp32():
         sel = "cls_patch" if spec.family == "siglip" else "patch"
         f_cpu = OV.tower_features(spec, w, px, -2, sel)
         feats_cpu[name] = OP.mlp_gelu(f_cpu, [p0, p2], [b0, b2])
-        hid = engine.VitEngineF32(spec, w, DEV).forward(px.to(DEV), n_layers=spec.layers - 1)
+        eng32 = engine.VitEngineF32(spec, w, DEV)
+        assert eng32.gemm == route
+        hid = eng32.forward(px.to(DEV), n_layers=spec.layers - 1)
         f_dev = hid if spec.family == "siglip" else hid[:, 1:]
         h = engine.gemm_f32(f_dev.reshape(-1, spec.d).contiguous(), p0.to(DEV), b0.to(DEV), _lib.EPI_ACT, act="gelu")
         feats_dev[name] = engine.gemm_f32(h, p2.to(DEV), b2.to(DEV)).view(n_img, -1, hidden)
