@@ -29,18 +29,20 @@ def tower(name, side, seed):
     px = torch.randn(N, 3, side, side, generator=g).to(torch.bfloat16).float()
     f = {"oracle fp32": OV.tower_features(spec, w, px, 23, "patch"),
          "oracle bf16": OV.tower_features(spec, w, px, 23, "patch", dtype=torch.bfloat16).float(),
-         "HIP fp32": engine.VitEngineF32(spec, w, dev).forward(px.to(dev), n_layers=23)[:, 1:].float().cpu(),
+         "HIP fp32": engine.VitEngineF32(spec, w, dev).forward(px.to(dev), n_layers=23)[:, 1:].float().cpu(),                         # default: split-bf16 projections
+         "HIP fp32 exact": engine.VitEngineF32(spec, w, dev, gemm="native").forward(px.to(dev), n_layers=23)[:, 1:].float().cpu(),    # exact-fp32 MFMA
          "HIP bf16": engine.VitEngine(spec, w, dev).forward(px.to(dev), n_layers=23)[:, 1:].float().cpu()}
     return f
 
 
-print("# Tower precision vs scores - round 2 (`python tools/precision_report.py`, full-size random-init towers, %d images)\n" % N)
+print("# Tower precision vs scores (`python tools/precision_report.py`, full-size random-init towers, %d images).  `HIP fp32` = the default "
+      "reference-precision route (projections and attention as split-bf16 plane-pair products), `HIP fp32 exact` = exact-fp32 MFMA throughout\n" % N)
 clip224 = tower("openai/clip-vit-large-patch14", 224, 1)
 clip336 = tower("openai/clip-vit-large-patch14-336", 336, 2)
 dino = tower("facebook/dinov2-large", 224, 3)
-print("| tower features vs the fp32 oracle (rel. L2) | oracle bf16 | HIP fp32 | HIP bf16 |\n|---|---|---|---|")
+print("| tower features vs the fp32 oracle (rel. L2) | oracle bf16 | HIP fp32 | HIP fp32 exact | HIP bf16 |\n|---|---|---|---|---|")
 for nm, f in (("CLIP-L/14-224", clip224), ("CLIP-L/14-336", clip336), ("DINOv2-L @224", dino)):
-    print(f"| {nm} | {rel(f['oracle bf16'], f['oracle fp32']):.2e} | {rel(f['HIP fp32'], f['oracle fp32']):.2e} | {rel(f['HIP bf16'], f['oracle fp32']):.2e} |")
+    print(f"| {nm} | {rel(f['oracle bf16'], f['oracle fp32']):.2e} | {rel(f['HIP fp32'], f['oracle fp32']):.2e} | {rel(f['HIP fp32 exact'], f['oracle fp32']):.2e} | {rel(f['HIP bf16'], f['oracle fp32']):.2e} |")
 # A score on each variant (projector fp32 on the CPU for all: isolates the tower's precision)
 g = torch.Generator().manual_seed(7)
 p0, p2 = torch.randn(4096, 1024, generator=g) * 0.03, torch.randn(4096, 4096, generator=g) * 0.015
@@ -48,7 +50,7 @@ b0, b2 = torch.randn(4096, generator=g) * 0.02, torch.randn(4096, generator=g) *
 proj = lambda f: OP.mlp_gelu(f, [p0, p2], [b0, b2])
 print("\n| A score (DINOv2-L tokens vs the CLIP336 / CLIP224 stacks, %d images) | value | rel. diff to oracle fp32 |\n|---|---|---|" % N)
 base = None
-for var in ("oracle fp32", "oracle bf16", "HIP fp32", "HIP bf16"):
+for var in ("oracle fp32", "oracle bf16", "HIP fp32", "HIP fp32 exact", "HIP bf16"):
     a = OA.a_score(list(proj(dino[var])), list(proj(clip336[var])), list(proj(clip224[var])))[0]
     base = a if base is None else base
     print(f"| {var} | {a:.6f} | {abs(a - base) / abs(base):.2e} |")
@@ -76,7 +78,7 @@ for (i, j, k1, thr, noise) in cases:
     gts.append(k2)
 print("\n| C score hits (DINOv2-L 16x16 maps, 40 pairs x 20 key points, targets = the fp32 oracle's predictions + U(-40, 40) px) | hits @0.1 / 0.05 / 0.01 | key points | flips vs oracle fp32 | max prediction shift (px) |\n|---|---|---|---|---|")
 ref_hits = None
-for var in ("oracle fp32", "oracle bf16", "HIP fp32", "HIP bf16"):
+for var in ("oracle fp32", "oracle bf16", "HIP fp32", "HIP fp32 exact", "HIP bf16"):
     tot, nk, shift = np.zeros(3, np.int64), 0, 0.0
     per = []
     for (i, j, k1, thr, _), k2 in zip(cases, gts):
