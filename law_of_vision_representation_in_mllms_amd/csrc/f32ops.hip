@@ -5,11 +5,16 @@
 // MFMA engine perturbs features by ~1e-2 relative, which moves the A score by ~1e-3 and can flip PCK hits; this path keeps every
 // tensor and every accumulation in fp32 so that images -> tower -> scores can be compared with the fp32 reference chain at 1e-4.
 //
-// Arithmetic: v_mfma_f32_32x32x2_f32 - fp32 operands, fp32 accumulate, bitwise a chain of fmaf (MI355X_MICROARCH.md, "Matrix
-// cores"): 157 TFLOP/s peak, 1/16 of the bf16 rate.  A parity mode, not the throughput mode: one simple LDS-staged kernel
-// (128x128x16 tiles, 4 waves, register prefetch of the next K-step) serves every contraction of the forward - patch embedding,
-// QKV / out / MLP projections with fused bias / activation / LayerScale + residual, and, batched over (image, head), Q K^T and
-// P V - so the softmax sees fp32 scores exactly like HF's eager attention (modeling_clip.py eager_attention_forward).
+// Two routes (engine.VitEngineF32 picks; DESIGN.md section 6, profiles/round3_f32.md):
+//   exact  visrep_vit_forward_f32: v_mfma_f32_32x32x2_f32 - fp32 operands, fp32 accumulate, bitwise a chain of fmaf (MI355X_MICROARCH.md,
+//          "Matrix cores"; 157 TFLOP/s peak, 1/16 of the bf16 rate).  One LDS-staged kernel (128x128x16 tiles, 4 waves, register prefetch of
+//          the next K-step, asm-pipelined fragment reads) serves every contraction - patch embedding, QKV / out / MLP projections with fused
+//          bias / activation / LayerScale + residual, batched / gathered products for the C-score post-processors - and a flash-style
+//          attention keeps the fp32 scores in registers (head width 64; other widths: batched Q K^T -> softmax rows -> P V).  Any shape.
+//   split  visrep_vit_forward_f32_split: the projections and the attention on the bf16 matrix pipe at fp32 accuracy - an fp32 value as
+//          three bf16 planes (24 significand bits), six plane-pair products, fp32 accumulation and epilogues (gemm_bf16_v5.hip EPI_F32X,
+//          attn_f32_split_kernel below): ~1.6x the exact route end to end, the same error level against float64.  d, mlp % 256 == 0 and
+//          head width 64, i.e. every CLIP / OpenCLIP / DINOv2 tower of the paper.
 #include <math.h>
 #include <stdlib.h>
 

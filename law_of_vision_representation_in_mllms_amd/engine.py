@@ -160,7 +160,8 @@ class VitEngineF32:
 
     The reference's C-score CLIP / OpenCLIP / DINOv2 towers run in fp32 (C_score/extract_feature.py:36-45,49-50: no dtype cast,
     fp32 pixels); this engine is what makes images -> tower -> A / C score comparable with that chain at the 1e-4 bar.  About
-    1/20 of the bf16 engine's throughput (exact-fp32 MFMA peak is 157 TFLOP/s), any head width that is a multiple of 4.
+    1/6 of the bf16 engine's throughput on the split-bf16 route (1/10 on the exact-fp32 MFMA route, which takes any head width that is a
+    multiple of 4).
     forward() returns fp32 [B, tokens, d]; images are processed in chunks so that the fp32 score matrices stay below `max_ws_bytes`."""
 
     def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30, gemm: str = "auto"):
