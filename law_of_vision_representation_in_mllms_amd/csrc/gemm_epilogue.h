@@ -50,7 +50,7 @@ template <typename ACC> struct AccGeom { static constexpr int QN = sizeof(ACC) /
 // HAS_ST (EPI_RESID): also emit, per output row and per wave tile (NJ * RBLK columns = one "slot"), the sum and the sum of squares
 // of the bf16-ROUNDED outputs -> p.stat_partial[m * p.stat_slots + slot]; ln_stats_finalize turns the slots of a row into the
 // (rstd, -mean * rstd) the next LayerNorm-folded GEMM wants, so that LayerNorm never reads the residual stream again.
-template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, typename ACC>
+template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, bool RW, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK, NC = NJ * QN;   // NC column groups of 4 per lane
     float4 bv[NC], lv[(HAS_LS || HAS_LN) ? NC : 1];           // lv: LayerScale gamma, or the LN column sums s[n]
@@ -87,6 +87,13 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
         size_t orow[RB];
         u32x2 rv[RB][NC];
         float4 pv[RB][NC];
+        // RWIDE: residual rows are fetched the way the outputs are stored (see WIDE below) - one 16-byte load per PAIR of column blocks from
+        // the address this lane will store to, then the same v_permlane16_swap (an involution) hands each lane its own 4 + 4 columns: half the
+        // load instructions, 64 contiguous bytes per row and instruction instead of 32.
+        // RW is decided once per launch by the caller (ldc % 8 == 0 and a 16-byte aligned residual pointer).
+        constexpr bool RWIDE = RW && EPI == EPI_RESID && QN == 1 && (NC % 2) == 0;
+        constexpr bool rwide = RWIDE;
+        u32x4 rq[RB][RWIDE ? NC / 2 : 1];
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
             const int m = mb + (i0 + ii) * RBLK + fr;
@@ -100,8 +107,14 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
                 posrow = p.pos + (size_t)(p.cls_off + pi) * p.N;
             }
             if (EPI == EPI_RESID) {
+                if (RWIDE && rwide) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) rv[ii][c] = *reinterpret_cast<const u32x2*>(p.resid + orow[ii] * p.ldc + col(c));
+                    for (int c0 = 0; c0 < NC; c0 += 2)
+                        rq[ii][c0 / 2] = *reinterpret_cast<const u32x4*>(p.resid + orow[ii] * p.ldc + ((hg & 1) ? col(c0 + 1) - 4 : col(c0)));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) rv[ii][c] = *reinterpret_cast<const u32x2*>(p.resid + orow[ii] * p.ldc + col(c));
+                }
             }
             if (EPI == EPI_PATCH) {
 #pragma unroll
@@ -123,6 +136,13 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
 #pragma unroll
             for (int c0 = 0; c0 < NC; c0 += (WIDE ? 2 : 1)) {
                 u32x2 o2[WIDE ? 2 : 1];
+                if (RWIDE && rwide) {                         // even lanes loaded (own j, partner's j), odd lanes (partner's j + 1, own j + 1)
+                    const u32x4 q4 = rq[ii][c0 / 2];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(q4[0], q4[2], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(q4[1], q4[3], false, false);
+                    rv[ii][c0] = u32x2{(unsigned)s0[0], (unsigned)s1[0]};
+                    rv[ii][c0 + (RWIDE ? 1 : 0)] = u32x2{(unsigned)s0[1], (unsigned)s1[1]};
+                }
 #pragma unroll
                 for (int cc = 0; cc < (WIDE ? 2 : 1); ++cc) {
                     const int c = c0 + cc;
@@ -185,27 +205,36 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
     }
 }
 
-template <int EPI, int NI, int NJ, int ACT, bool STATS, typename ACC>
-VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+template <int EPI, int NI, int NJ, int ACT, bool STATS, bool RW, typename ACC>
+VR_DEV void gemm_epilogue_rowmajor_rw(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     const bool interior = mb + NI * AccGeom<ACC>::RBLK <= p.M;
     if (STATS && EPI == EPI_RESID && p.stat_partial) {       // residual GEMM that also emits the next LayerNorm's row statistics
         if (p.ls) {
-            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, true>(p, acc, mb, nb, fr, hg);
-            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, true>(p, acc, mb, nb, fr, hg);
+            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, true, RW>(p, acc, mb, nb, fr, hg);
+            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, true, RW>(p, acc, mb, nb, fr, hg);
         } else {
-            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, true>(p, acc, mb, nb, fr, hg);
-            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, true>(p, acc, mb, nb, fr, hg);
+            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, true, RW>(p, acc, mb, nb, fr, hg);
+            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, true, RW>(p, acc, mb, nb, fr, hg);
         }
     } else if (EPI == EPI_RESID && p.ls) {                   // LayerScale towers (DINOv2): its own path keeps the others lean
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, false>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, false>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, false, RW>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, false, RW>(p, acc, mb, nb, fr, hg);
     } else if ((EPI == EPI_BIAS || EPI == EPI_ACT) && p.ln_rt) {   // LayerNorm folded into this GEMM
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true, false>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true, false>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true, false, RW>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true, false, RW>(p, acc, mb, nb, fr, hg);
     } else {
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, false>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, false>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, false, RW>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, false, RW>(p, acc, mb, nb, fr, hg);
     }
+}
+
+template <int EPI, int NI, int NJ, int ACT, bool STATS, typename ACC>
+VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    // wide residual loads (see RWIDE in the implementation): 16-byte aligned residual rows, 16x16 accumulators, an even number of column blocks
+    if (EPI == EPI_RESID && AccGeom<ACC>::QN == 1 && (NJ % 2) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0)
+        gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, EPI == EPI_RESID>(p, acc, mb, nb, fr, hg);
+    else
+        gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, false>(p, acc, mb, nb, fr, hg);
 }
 
 // STATS: only the kernel the dispatcher routes statistics-emitting residual GEMMs to (v2) compiles that epilogue
