@@ -35,6 +35,9 @@
 #ifndef VISREP_ATTN_ABLATE
 #define VISREP_ATTN_ABLATE 0
 #endif
+#ifndef VISREP_ATTN_V1_THR
+#define VISREP_ATTN_V1_THR 8             // 0: update the running maximum on every tile
+#endif
 
 namespace {
 
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
             const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             mloc = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
         }
-#ifdef VISREP_ATTN_V1_THR                                   // diagnostic build: keep the old maximum while no row's maximum grew by more than THR (exp2 units)
+#if VISREP_ATTN_V1_THR > 0                                  // deferred maximum: keep the old one while no row's maximum grew by more than THR (exp2 units):
+        // p <= 2^THR then (bf16 keeps its relative precision, sums are fp32) and most tiles skip the rescale branch below; -2.4 % (round 3)
         const float m_new = __any((mloc - m_run) * p.sc > (float)VISREP_ATTN_V1_THR) ? fmaxf(m_run, mloc) : m_run;
 #else
         const float m_new = fmaxf(m_run, mloc);             // finite: every image's first tile holds >= 1 valid key
