@@ -214,7 +214,25 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
     }
     u32x2 o = {pack_bf16(acc.x, acc.y), pack_bf16(acc.z, acc.w)};
     *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
+    if (p.stat_rt && p.N == 1024) {
+        // N = 4 * blockDim: this block IS row m, so the row's LayerNorm statistics (of the bf16-ROUNDED outputs, the formula of
+        // ln_stats_finalize_rows) come out of the reduction itself instead of a read-back pass over the rows (splitk_reduce_emits_stats)
+        __shared__ float red[2][4];
+        const float r0 = bf_lo(o[0]), r1 = bf_hi(o[0]), r2 = bf_lo(o[1]), r3 = bf_hi(o[1]);
+        const float s1 = wave_sum((r0 + r1) + (r2 + r3));
+        const float s2 = wave_sum(__builtin_fmaf(r0, r0, __builtin_fmaf(r1, r1, __builtin_fmaf(r2, r2, r3 * r3))));
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), t2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+            const float mean = t1 * (1.0f / 1024.0f);
+            const float var = fmaxf(t2 * (1.0f / 1024.0f) - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + p.stat_eps);
+            p.stat_rt[m] = float2{rstd, -mean * rstd};
+        }
+    }
 }
+bool splitk_reduce_emits_stats(const GemmArgs& a) { return a.stat_rt && a.epi == EPI_RESID && a.N == 1024; }
 
 }  // namespace
 
@@ -337,6 +355,7 @@ int run_one(const GemmArgs& a, hipStream_t s, int variant) {
 int run_split_k(const GemmArgs& a, hipStream_t s) {              // 1 = handled, 0 = not eligible, < 0 = error
     const int sk = try_split_k(a, s);
     if (sk <= 0) return sk;
+    if (splitk_reduce_emits_stats(a)) return 1;                  // the reduction wrote stat_rt for its rows
     const int rc = finish_stats(a, false, s);
     return rc ? rc : 1;
 }
