@@ -7,7 +7,8 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is enqueued
  *     asynchronously on it; nothing here synchronises, allocates or frees device memory
  *   - return value 0 = ok, negative = error (VISREP_ERR_*); visrep_last_error() gives the message; no C++
- *     exception crosses the boundary; no global mutable state besides the thread-local error string
+ *     exception crosses the boundary; no process-global mutable state: the error string and the A/B variant knobs are thread-local,
+ *     caller-owned scratch is keyed by (device, stream), per-kernel LDS opt-ins and CU counts are cached per device
  *   - bf16 tensors are raw uint16 storage (torch.bfloat16), row-major, leading dimensions in ELEMENTS
  */
 #ifndef VISREP_H
@@ -19,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 200
+#define VISREP_VERSION 400   /* round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures) */
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
@@ -38,22 +39,22 @@ int visrep_version(void);
 /* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
 size_t visrep_last_error(char* buf, size_t n);
 
-/* Tuning knob (process-global, for A/B measurements): selects the GEMM kernel family used by every entry point below.
- * 1 = 128x128 tiles / one barrier per K-tile; 2 = 256x256 persistent ping-pong kernel (16x16x32 MFMA, 4 barriers per K-tile);
- * 3 = 128-byte LDS rows (BK = 64), 32x32x16 MFMA, 2 barriers per 32-deep k-step; 4 = experimental 4-wave 256x256 kernel, one 128x128
- * quadrant per wave with AGPR accumulators (profiles/round2_gemm_v4.md); 5 (default) = 3's data path with 2's 16x16x32 MFMAs and epilogues
- * (profiles/round2_gemm_v5.md).  2-5 need N % 256 == 0 (3, 5: K % 64 == 0, else 2 runs); everything else runs 1.
- * Returns the previous value.  Results are identical up to fp32 summation order. */
+/* Kernel-variant knobs for A/B measurements.  They are PER-THREAD state (the calling thread's later launches only): there is no
+ * process-global mutable state behind this ABI, and the defaults need no call at all.  Each returns the previous value.
+ *
+ * GEMM family used by every entry point below: 1 = 128x128 tiles, one barrier per K-tile (also: N % 256 != 0 shapes, tail rows, split-K,
+ * implicit 3x3 convolution); 2 = 256x256 persistent ping-pong kernel, 64-byte LDS rows (runs when K % 64 != 0); 5 (default) = the same
+ * structure with 128-byte LDS rows, a five-slot LDS-DMA ring and half the barriers (profiles/round2_gemm_v5.md).  2 and 5 need
+ * N % 256 == 0.  Results are identical up to fp32 summation order.  (Variants 3 and 4 - measured dead ends, profiles/round2_gemm_v4.md -
+ * exist only in the tools-only VISREP_EXPERIMENTS build.) */
 int visrep_set_gemm_variant(int variant);
-/* Same kind of knob for the attention forward at head width 64 (the ViT towers' MHSA): 1 (default) = the four-wave kernel that also
- * serves head widths 128 / 192; 2 = attn_fwd_ab, two 32-row query blocks per wave whose matrix work and softmax are interleaved MFMA
- * by MFMA (csrc/attention_ab.hip; measured equal-to-slower, profiles/round3_attention.md).  Returns the previous value.  Results
- * agree to the bf16 rounding of P. */
+/* Attention forward at head width 64: 1 (default) = attn_fwd, the four-wave kernel that also serves head widths 128 / 192.  2 = attn_fwd_ab
+ * (two 32-row query blocks per wave; measured equal-to-slower, profiles/round3_attention.md) exists only in the VISREP_EXPERIMENTS build;
+ * the production library refuses it. */
 int visrep_set_attn_variant(int variant);
 /* Tile shape of the bf16 A-score Gram (visrep_ascore_maxcos*): 0 (default) = whichever launches the smaller tile area for (Nt, Nr);
  * 1 = one 128 x 128 tile per workgroup; 2 = persistent ping-pong tiles of 192 or 256 rows per operand (the GEMM default's structure;
- * 576 = 3 x 192, 256 = 1 x 256).
- * Returns the previous value.  Results are identical up to fp32 summation order (none: both sum k in the same order per MFMA chain). */
+ * 576 = 3 x 192, 256 = 1 x 256).  Results are identical up to fp32 summation order (none: both sum k in the same order per MFMA chain). */
 int visrep_set_ascore_variant(int variant);
 /* Timing-only ablation of GEMM variant 2 (bit 0: skip MFMAs, bit 1: skip the LDS-DMA loads, bit 2: skip the fragment reads):
  * results are WRONG for mask != 0; used by tools/gemm_ablate.py to attribute cycles.  Returns the previous mask. */
@@ -65,9 +66,12 @@ int visrep_debug_gemm_timing_buffer(void* dev_u64x16);
 /* ---- optional device scratch owned by the caller (e.g. one torch tensor kept alive for the process).  With it,
  * visrep_gemm_bf16 splits the K loop of problems that have few output tiles but a deep reduction (the diffusion towers'
  * 3x3 convolutions at 12x12 / 24x24 resolution) across CUs and reduces the fp32 partial planes in slice order, i.e.
- * deterministically.  The registration is per DEVICE (the current one at the call; a process driving several GPUs registers one
- * buffer on each); the planes are not keyed by stream: at most one stream per device runs GEMMs at a time.  (NULL, 0) detaches. */
+ * deterministically.  Registrations are keyed by (device, stream): visrep_set_scratch registers the buffer every stream of the CURRENT
+ * device falls back to (enough when one stream per device runs GEMMs at a time); visrep_set_stream_scratch registers a buffer for ONE
+ * stream of the current device and wins over the device-wide one - a caller that runs split-K GEMMs on several streams of a device
+ * concurrently gives each stream its own (up to 8 per device).  (NULL, 0) detaches.  Both are thread-safe. */
 int visrep_set_scratch(void* ptr, size_t bytes);
+int visrep_set_stream_scratch(void* stream, void* ptr, size_t bytes);
 
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
  * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from
@@ -168,24 +172,33 @@ int visrep_softmax_rows_f32(float* x, int ld, long rows, int cols, void* stream)
 size_t visrep_vit_f32_workspace_bytes(const visrep_vit_config* cfg, int B);
 int visrep_vit_forward_f32(const visrep_vit_config* cfg, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
                            void* workspace, void* stream);
-/* ---- fp32 on the bf16 matrix pipe ("split-bf16"): an fp32 value x is carried as three bf16 planes hi = bf16(x), mid = bf16(x - hi),
- * lo = bf16(x - hi - mid) (24 significand bits); a product sum over the six plane pairs (hi,hi) (hi,mid) (hi,lo) (mid,hi) (mid,mid) (lo,hi),
- * accumulated in fp32 by v_mfma_f32_16x16x32_bf16, differs from the exact fp32 result by ~1e-7 relative - below the rounding of an fp32
- * FMA chain - at 16/6 of the exact-fp32 MFMA rate.  The reference-precision towers (C_score/extract_feature.py:36-45: CLIP / OpenCLIP /
- * DINOv2 in fp32) run their projections this way; tests/test_gpu_f32.py holds the route to the same bars as the exact-fp32 one. */
-/* planes [rows, 3 K] bf16 = hi | mid | lo of x fp32 [rows, K] (ldx floats per row); K, ldx % 4 == 0 */
-int visrep_split_bf16x3(const float* x, int ldx, long rows, int K, void* planes, void* stream);
-/* C [M, N] fp32 (ldc; may be NULL) and / or out_planes [M, 3 N] (may be NULL) = epilogue(A W^T): v = act(A W^T + bias);
- * v = resid + ls * v when resid != NULL (resid fp32 [M, ldc], may alias C; ls [N] or NULL = 1).  a_planes [M, 3 K], w_planes [N, 3 K]
- * from visrep_split_bf16x3; N % 256 == 0, K % 64 == 0; act = VISREP_ACT_* evaluated with libm expf / erff / tanhf. */
-int visrep_gemm_f32_split(const void* a_planes, const void* w_planes, int M, int N, int K, const float* bias, int act, const float* resid,
-                          const float* ls, float* C, int ldc, void* out_planes, void* stream);
+/* ---- fp32 on the bf16 matrix pipe ("split-bf16"): an fp32 value x is carried as bf16 planes hi = bf16(x), mid = bf16(x - hi),
+ * lo = bf16(x - hi - mid) (the subtractions are exact; two planes hold 16 significand bits, three hold 24) and a product sum runs over
+ * `products` plane pairs, accumulated in fp32 by v_mfma_f32_16x16x32_bf16:
+ *   6 = (hi,hi) (hi,mid) (hi,lo) (mid,hi) (mid,mid) (lo,hi): every term >= 2^-24 of the result; differs from the exact fp32 result by ~1e-7
+ *       relative - below the rounding of an fp32 FMA chain - at 16/6 of the exact-fp32 MFMA rate;
+ *   4 = the full product of two-plane operands; 3 = (hi,hi) (hi,mid) (mid,hi): terms below 2^-16 dropped, ~4e-6 relative per product sum
+ *       (between TF32 and fp32), at 16/3 of the exact-fp32 rate; accuracy against A / PCK in profiles/round4_precision.md.
+ * The reference-precision towers (C_score/extract_feature.py:36-45: CLIP / OpenCLIP / DINOv2 in fp32) run their projections this way;
+ * tests/test_gpu_f32.py holds the route to the same bars as the exact-fp32 one. */
+/* planes [rows, nplanes K] bf16 = hi | mid [| lo] of x fp32 [rows, K] (ldx floats per row); nplanes 2 | 3; K, ldx % 4 == 0 */
+int visrep_split_bf16_planes(const float* x, int ldx, long rows, int K, int nplanes, void* planes, void* stream);
+/* C [M, N] fp32 (ldc; may be NULL) and / or out_planes [M, npl N] (may be NULL) = epilogue(A W^T): v = act(A W^T + bias);
+ * v = resid + ls * v when resid != NULL (resid fp32 [M, ldc], may alias C; ls [N] or NULL = 1).  products 3 | 4 | 6; npl = 3 for 6 products,
+ * else 2; a_planes [M, npl K], w_planes [N, npl K] from visrep_split_bf16_planes; N % 256 == 0, K % 64 == 0; act = VISREP_ACT_* evaluated
+ * with libm expf / erff / tanhf. */
+int visrep_gemm_f32_split(const void* a_planes, const void* w_planes, int M, int N, int K, int products, const float* bias, int act,
+                          const float* resid, const float* ls, float* C, int ldc, void* out_planes, void* stream);
 /* 1 when visrep_vit_forward_f32_split takes this tower (d, mlp % 256 == 0, head width 64) */
 int visrep_vit_f32_split_supported(const visrep_vit_config* cfg);
-/* visrep_vit_forward_f32 with the projections as split-bf16 GEMMs.  w: the fp32 weights (vectors, patch matrix); wsplit: same struct whose
- * wqkv / wo / w1 / w2 point to the plane triples [N, 3 K] of the fp32 matrices (other fields ignored).  Same workspace size. */
-int visrep_vit_forward_f32_split(const visrep_vit_config* cfg, const visrep_vit_weights* w, const visrep_vit_weights* wsplit, const float* pixels,
-                                 float* hidden, int B, int n_layers, void* workspace, void* stream);
+/* visrep_vit_forward_f32 with the projections and the attention as split-bf16 products.  w: the fp32 weights (vectors, patch matrix); wsplit:
+ * same struct whose wqkv / wo / w1 / w2 point to the planes [N, npl K] of the fp32 matrices (other fields ignored); products as above.
+ * Same workspace size. */
+int visrep_vit_forward_f32_split(const visrep_vit_config* cfg, const visrep_vit_weights* w, const visrep_vit_weights* wsplit, int products,
+                                 const float* pixels, float* hidden, int B, int n_layers, void* workspace, void* stream);
+/* Per-thread diagnostic of the fp32 towers' attention (tests only): bit 0 = three-launch attention (batched Q K^T -> softmax rows -> P V
+ * through HBM) on the exact route; bit 1 = exact-fp32 MFMA attention inside the split route.  Returns the previous mask. */
+int visrep_debug_f32_attention(int mask);
 
 /* ---- fp32 convolution-block primitives of the supervised C-score post-processor (C_score/model_utils/projection_network.py:15-125
  * AggregationNetwork = detectron2-style BottleneckBlocks, model_utils/resnet.py:174-286: 1x1 / 3x3 / 1x1 bias-free convolutions, each

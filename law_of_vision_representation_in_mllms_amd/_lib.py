@@ -11,6 +11,7 @@ import threading
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VISREP_LIB") or os.path.join(_PKG, "libvisrep_hip.so")   # VISREP_LIB: diagnostic builds only
 
+ABI_VERSION = 400                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
 BF16, F32 = 0, 1
 EPI_BIAS, EPI_ACT, EPI_RESID, EPI_VT, EPI_PATCH, EPI_F32 = range(6)
 ACT = {"none": 0, "quick_gelu": 1, "gelu": 2, "gelu_erf": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3}
@@ -52,6 +53,7 @@ SIGNATURES = {
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "visrep_set_scratch": (_i, [_vp, _sz]),
+    "visrep_set_stream_scratch": (_i, [_vp, _vp, _sz]),
     "visrep_layernorm_stats": (_i, [_vp, _i, _vp, _i, _i, _f, _vp]),
     "visrep_gemm_bf16_ln": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_gemm_bf16_resid_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
@@ -79,10 +81,11 @@ SIGNATURES = {
     "visrep_softmax_rows_f32": (_i, [_vp, _i, _l, _i, _vp]),
     "visrep_vit_f32_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
     "visrep_vit_forward_f32": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _vp]),
-    "visrep_split_bf16x3": (_i, [_vp, _i, C.c_long, _i, _vp, _vp]),
-    "visrep_gemm_f32_split": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "visrep_split_bf16_planes": (_i, [_vp, _i, C.c_long, _i, _i, _vp, _vp]),
+    "visrep_gemm_f32_split": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "visrep_vit_f32_split_supported": (_i, [C.POINTER(VitConfig)]),
-    "visrep_vit_forward_f32_split": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(VitWeights), _vp, _vp, _i, _i, _vp, _vp]),
+    "visrep_vit_forward_f32_split": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(VitWeights), _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "visrep_debug_f32_attention": (_i, [_i]),
     "visrep_im2col3x3_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "visrep_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -123,6 +126,11 @@ def load(build_if_missing: bool = True):
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        lib.visrep_version.restype = C.c_int
+        got = lib.visrep_version()
+        if got != ABI_VERSION:                                  # a stale library (VISREP_LIB, a leftover build) would misread the arguments
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                               "(`python -m law_of_vision_representation_in_mllms_amd.build --force`)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -22,8 +22,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "gemm_bf16_v5.hip", "attention.hip", "attention_ab.hip", "rowops.hip", "convnet.hip", "ascore.hip",
+# the product library: GEMM v1 (128x128: tails, split-K, N % 256 != 0, implicit convolution), v2 (K % 64 != 0), v5 (default), attn_fwd
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v5.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip",
            "cscore.hip", "f32ops.hip", "jpeg_decode.hip", "visrep_abi.hip"]
+# measured dead ends kept for the record (GEMM v3 / v4, attn_fwd_ab): compiled only into the tools-only library
+# libvisrep_hip_exp.so (build_experiments_lib, -DVISREP_EXPERIMENTS), never into what ships
+EXPERIMENT_SOURCES = ["gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "attention_ab.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
@@ -57,19 +61,19 @@ def have_sources() -> bool:
     return all(os.path.exists(os.path.join(CSRC, f)) for f in SOURCES + HEADERS)
 
 
-def source_hash(defines=()) -> str:
-    return _digest(SOURCES + HEADERS, defines)
+def source_hash(defines=(), sources=None) -> str:
+    return _digest(list(sources or SOURCES) + HEADERS, defines)
 
 
 def _hash_file(out: str) -> str:
     return os.path.splitext(out)[0] + ".srchash"
 
 
-def _stale(out: str = LIB, defines=()) -> bool:
+def _stale(out: str = LIB, defines=(), sources=None) -> bool:
     if not os.path.exists(out) or not os.path.exists(_hash_file(out)):
         return True
     with open(_hash_file(out)) as fh:
-        return fh.read().strip() != source_hash(defines)
+        return fh.read().strip() != source_hash(defines, sources)
 
 
 def _compile(src: str, objdir: str, defines, verbose: bool) -> str:
@@ -95,8 +99,10 @@ def _compile(src: str, objdir: str, defines, verbose: bool) -> str:
     return obj
 
 
-def _build(out: str, defines=(), tag: str = "", verbose: bool = False, only=None) -> str:
-    """only: the translation units the extra defines apply to (diagnostic builds); every other unit is the default build's object."""
+def _build(out: str, defines=(), tag: str = "", verbose: bool = False, only=None, sources=None) -> str:
+    """only: the translation units the extra defines apply to (diagnostic builds); every other unit is the default build's object.
+    sources: the translation units to link (default: the product library's)."""
+    sources = list(sources or SOURCES)
     objdir = os.path.join(OBJ, tag) if tag else OBJ
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
@@ -107,9 +113,9 @@ def _build(out: str, defines=(), tag: str = "", verbose: bool = False, only=None
                 if only is not None and src not in only:
                     return _compile(src, OBJ, (), verbose)
                 return _compile(src, objdir, defines, verbose)
-            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
-                objs = list(pool.map(one, SOURCES))
-            if not _stale(out, defines):
+            with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(one, sources))
+            if not _stale(out, defines, sources):
                 return out                                # another process linked it while this one waited for the lock
             tmp = f"{out}.{os.getpid()}.tmp"
             cmd = [_hipcc()] + LDFLAGS + objs + ["-o", tmp]
@@ -121,7 +127,7 @@ def _build(out: str, defines=(), tag: str = "", verbose: bool = False, only=None
                 raise RuntimeError(f"hipcc failed linking {os.path.basename(out)}")
             os.replace(tmp, out)
             with open(f"{_hash_file(out)}.{os.getpid()}.tmp", "w") as fh:
-                fh.write(source_hash(defines))
+                fh.write(source_hash(defines, sources))
             os.replace(f"{_hash_file(out)}.{os.getpid()}.tmp", _hash_file(out))
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
@@ -138,9 +144,17 @@ def build_attn_ablation_lib(mask: int) -> str:
     return _build(os.path.join(PKG, f"libvisrep_hip_attn{mask}.so"), [f"-DVISREP_ATTN_ABLATE={mask}"], f"attn{mask}")
 
 
-def build_variant_lib(name: str, defines, only=None) -> str:
+def build_variant_lib(name: str, defines, only=None, experiments: bool = False) -> str:
     """Diagnostic build with extra -D flags (tools/ only): libvisrep_hip_<name>.so, loaded through VISREP_LIB."""
+    if experiments:
+        return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), ["-DVISREP_EXPERIMENTS"] + list(defines), name, sources=SOURCES + EXPERIMENT_SOURCES)
     return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), list(defines), name, only=only)
+
+
+def build_experiments_lib() -> str:
+    """libvisrep_hip_exp.so = the product sources + GEMM v3 / v4 + attn_fwd_ab with -DVISREP_EXPERIMENTS (tools/ only, loaded through
+    VISREP_LIB): the variants the round-2 / round-3 profiles measured and rejected stay reproducible without shipping."""
+    return _build(os.path.join(PKG, "libvisrep_hip_exp.so"), ["-DVISREP_EXPERIMENTS"], "exp", sources=SOURCES + EXPERIMENT_SOURCES)
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:

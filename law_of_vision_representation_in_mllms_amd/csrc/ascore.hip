@@ -20,8 +20,8 @@
 #include "common.h"
 #include "visrep_internal.h"
 
-int g_visrep_ascore_deep = getenv("VISREP_ASCORE_DEEP") ? atoi(getenv("VISREP_ASCORE_DEEP")) : 1;   // A/B knob (default on): six-slot ring for 192 x 192 tiles, 576 x 576 x 4096: 0.720 -> 0.651 ms
-int g_visrep_ascore_variant = 0;   // 0 = pick by launched tile area, 1 = 128 x 128 tiles, 2 = persistent ping-pong tiles (visrep_set_ascore_variant)
+constexpr int ASCORE_DEEP = 1;     // six-slot ring for 192 x 192 tiles (576 x 576 x 4096: 0.720 -> 0.651 ms with it, profiles/round3_scores_kernel_stats.md)
+thread_local int t_visrep_ascore_variant = 0;   // 0 = pick by launched tile area, 1 = 128 x 128 tiles, 2 = persistent ping-pong tiles (visrep_set_ascore_variant)
 
 namespace {
 
@@ -504,15 +504,9 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
 template <int MI, int NJ, bool DEEP>
 int launch_pp(const AScoreArgs& a, float* scores, hipStream_t s) {
     constexpr int TM = 32 * MI, TN = 64 * NJ, P_LDS = (TM > TN ? TM : TN) * P_TK * 2 * (DEEP ? 6 : 5);
-    static bool attr = false;
-    static int ncu = 256;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_pp<MI, NJ, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        attr = true;
-    }
+    static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device)
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(ascore_maxcos_pp<MI, NJ, DEEP>), P_LDS);
+    const int ncu = visrep_cu_count();
     const int nnt = (a.Nr + TN - 1) / TN, ntiles = a.n_img * ((a.Nt + TM - 1) / TM) * nnt;
     hipLaunchKernelGGL((ascore_maxcos_pp<MI, NJ, DEEP>), dim3(ntiles < ncu ? ntiles : ncu), dim3(512), P_LDS, s, a);
     return 4 * nnt;                                            // parts per target row in a.partial
@@ -558,9 +552,9 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
     auto cover = [](int n, int t) { return (long)((n + t - 1) / t) * t; };
     const int tm = cover(Nt, 256) <= cover(Nt, 192) ? 256 : 192, tn = cover(Nr, 256) <= cover(Nr, 192) ? 256 : 192;
     const long area128 = cover(Nt, 128) * cover(Nr, 128), area_pp = cover(Nt, tm) * cover(Nr, tn);
-    const bool pp = g_visrep_ascore_variant == 2 || (g_visrep_ascore_variant == 0 && area_pp <= area128);
+    const bool pp = t_visrep_ascore_variant == 2 || (t_visrep_ascore_variant == 0 && area_pp <= area128);
     if (tiled && pp) {
-        const int parts = tm == 192 ? (tn == 192 ? (g_visrep_ascore_deep ? launch_pp<6, 3, true>(a, scores, s) : launch_pp<6, 3, false>(a, scores, s))
+        const int parts = tm == 192 ? (tn == 192 ? launch_pp<6, 3, ASCORE_DEEP != 0>(a, scores, s)
                                                  : launch_pp<6, 4, false>(a, scores, s))
                                     : (tn == 192 ? launch_pp<8, 3, false>(a, scores, s) : launch_pp<8, 4, false>(a, scores, s));
         hipLaunchKernelGGL(ascore_finalize_tiles, dim3((n_img + 3) / 4), dim3(256), 0, s, partial, a.c_other, scores, n_img, Nt, parts);
@@ -569,8 +563,8 @@ int run(const void* other, const void* ref, const float* c_other_in, const float
     if (tiled) {                                               // LDS-tiled MFMA kernel, one 128 x 128 tile per workgroup
         ntt = (Nt + A_BM - 1) / A_BM;
         const int nnt = (Nr + A_BN - 1) / A_BN;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ascore_maxcos_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS); attr = true; }
+        static VisrepLdsOptIn opt;
+        visrep_lds_opt_in(opt, reinterpret_cast<const void*>(ascore_maxcos_tiled), A_LDS);
         hipLaunchKernelGGL(ascore_maxcos_tiled, dim3((unsigned)((size_t)n_img * ntt * nnt)), dim3(256), A_LDS, s, a);
         hipLaunchKernelGGL(ascore_finalize_tiles, dim3((n_img + 3) / 4), dim3(256), 0, s, partial, a.c_other, scores, n_img, Nt, nnt);
         return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
@@ -592,8 +586,8 @@ extern "C" size_t visrep_ascore_workspace_bytes(int n_img, int Nt, int Nr) {
 
 extern "C" int visrep_set_ascore_variant(int v) {
     if (v < 0 || v > 2) return visrep_set_error(VISREP_ERR_SHAPE, "ascore variant: 0 (by tile area), 1 (128 x 128 tiles) or 2 (persistent ping-pong tiles)");
-    const int old = g_visrep_ascore_variant;
-    g_visrep_ascore_variant = v;
+    const int old = t_visrep_ascore_variant;                   // per-thread state
+    t_visrep_ascore_variant = v;
     return old;
 }
 

@@ -248,12 +248,17 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 
 }  // namespace
 
-int g_visrep_attn_variant = 1;   // 1 = attn_fwd<ND> for every head width (default); 2 = attn_fwd_ab (attention_ab.hip) for head width 64
+thread_local int t_visrep_attn_variant = 1;   // 1 = attn_fwd<ND> for every head width (default); 2 = attn_fwd_ab (attention_ab.hip, VISREP_EXPERIMENTS builds) for head width 64
 
-extern "C" int visrep_set_attn_variant(int variant) {
-    if (variant != 1 && variant != 2) return visrep_set_error(VISREP_ERR_SHAPE, "attention variant must be 1 or 2");
-    const int old = g_visrep_attn_variant;
-    g_visrep_attn_variant = variant;
+extern "C" int visrep_set_attn_variant(int variant) {          // per-thread; returns the previous value
+#ifdef VISREP_EXPERIMENTS
+    const bool ok = variant == 1 || variant == 2;
+#else
+    const bool ok = variant == 1;
+#endif
+    if (!ok) return visrep_set_error(VISREP_ERR_SHAPE, "attention variant must be 1 (2 = attn_fwd_ab: VISREP_EXPERIMENTS builds only)");
+    const int old = t_visrep_attn_variant;
+    t_visrep_attn_variant = variant;
     return old;
 }
 
@@ -265,8 +270,10 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     if ((ldq % 8) || (ldk % 8) || (ldvt % 64) || (ldo % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "attention: bad leading dimension");
     const long Mk = kv_shared ? Tk : (long)B * Tk;
     if (ldvt < ((Mk + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "attention: ldvt must cover round_up(key rows, 64)");
-    if (head_dim == 64 && g_visrep_attn_variant == 2)
+#ifdef VISREP_EXPERIMENTS
+    if (head_dim == 64 && t_visrep_attn_variant == 2)
         return visrep_attention_ab_launch(q, ldq, k, ldk, vt, ldvt, out, ldo, B, Tq, Tk, H, kv_shared, causal, scale, (hipStream_t)stream);
+#endif
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.Mk = (int)Mk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.kv_shared = kv_shared; a.causal = causal;
@@ -274,17 +281,22 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     const int nqt = (Tq + 127) / 128, nd = head_dim / 64;
     const dim3 grid(nqt * H * B), block(256);
     size_t lds = (size_t)nd * 4 * TILE_B;                   // double-buffered K + V^T tiles
-    if (const char* e = getenv("VISREP_ATTN_EXTRA_LDS")) {  // diagnostic: unused LDS to lower the number of resident workgroups per CU
-        lds += (size_t)atoi(e);
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)attn_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+#ifdef VISREP_EXPERIMENTS
+    {   // diagnostic (tools-only build): unused LDS to lower the number of resident workgroups per CU; the knob is read once
+        static const int extra = getenv("VISREP_ATTN_EXTRA_LDS") ? atoi(getenv("VISREP_ATTN_EXTRA_LDS")) : 0;
+        if (extra > 0 && nd == 1) {
+            lds += (size_t)extra;
+            static VisrepLdsOptIn opt1;
+            visrep_lds_opt_in(opt1, (const void*)attn_fwd<1>, 160 * 1024);
+        }
     }
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (nd == 1) hipLaunchKernelGGL(attn_fwd<1>, grid, block, lds, st, a);
     else if (nd == 2) hipLaunchKernelGGL(attn_fwd<2>, grid, block, lds, st, a);
     else {
-        static bool attr = false;                           // 96 KB of dynamic LDS needs the opt-in once
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        static VisrepLdsOptIn opt3;                         // 96 KB of dynamic LDS needs the opt-in once per device
+        visrep_lds_opt_in(opt3, (const void*)attn_fwd<3>, (int)lds);
         hipLaunchKernelGGL(attn_fwd<3>, grid, block, lds, st, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "attention: launch failed");

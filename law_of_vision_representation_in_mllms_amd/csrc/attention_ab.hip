@@ -498,8 +498,8 @@ int visrep_attention_ab_launch(const void* q, int ldq, const void* k, int ldk, c
     a.nwg = a.nfull + ((a.nqb & 7) ? ((a.nqb & 7) > 4 ? 2 : 1) : 0);
     const dim3 grid(a.nwg * H * B), block(256);
     const size_t lds = (size_t)2 * NSLOT * TILE_B + 8 * 4096;   // K ring + V^T ring + 8 Q tiles = 80 KB: two workgroups per CU
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_ab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static VisrepLdsOptIn opt;
+    visrep_lds_opt_in(opt, (const void*)attn_fwd_ab, (int)lds);
     static int told = 0;
     if (!told && getenv("VISREP_DEBUG")) {
         int nb = 0;

@@ -339,11 +339,8 @@ extern "C" int visrep_row_rnorm_f32(const float* x, long rows, int C, float eps,
 template <int KC>
 static void launch_mutual_nn(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float eps, float* out, hipStream_t st) {
     const size_t lds = (size_t)10 * PP * sizeof(float);
-    static size_t lds_set = 0;
-    if (lds > lds_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mutual_nn_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device): the largest size opted in so far
+    if (lds > 48 * 1024) visrep_lds_opt_in(opt, reinterpret_cast<const void*>(mutual_nn_kernel<KC>), (int)lds);
     hipLaunchKernelGGL(mutual_nn_kernel<KC>, dim3(n_pairs), dim3(256), lds, st, gram, r1, r2, PP, eps, out);
 }
 
@@ -369,12 +366,9 @@ extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const
     if (split < 0 || split >= C || (split & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: split must be even and in [0, C)");
     CArgs a{feats, img1, img2, patch_idx, nkp, lin, xy, n_pairs, kmax, P, C, split, window, soft_eval, beta, anno_stride, anno_half};
     const size_t lds = sizeof(float) * ((size_t)32 * P * P);
-    static size_t lds_set[2] = {0, 0};
-    if (lds > lds_set[layout]) {
-        if (layout) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cscore_transfer<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set[layout] = lds;
-    }
+    static VisrepLdsOptIn opt[2];                                // per (layout, device)
+    if (layout) visrep_lds_opt_in(opt[1], reinterpret_cast<const void*>(cscore_transfer<true>), (int)lds);
+    else visrep_lds_opt_in(opt[0], reinterpret_cast<const void*>(cscore_transfer<false>), (int)lds);
     if (layout) hipLaunchKernelGGL(cscore_transfer<true>, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(cscore_transfer<false>, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "cscore_transfer: launch failed");

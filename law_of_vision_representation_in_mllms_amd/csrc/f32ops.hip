@@ -234,8 +234,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args p) {
 //     buffered, staged through registers; running maximum / sum in fp32, exp2 of the scaled difference like the bf16 kernel.
 // Arithmetic is fp32 throughout; against HF's eager softmax the results differ by summation order only (~1e-6 relative).
 }  // namespace
-int g_visrep_f32_split_attention = getenv("VISREP_F32_SPLIT_ATTENTION") ? atoi(getenv("VISREP_F32_SPLIT_ATTENTION")) : 1;   // split route: attention on the bf16 pipe too (0: exact-fp32 MFMA)
-int g_visrep_f32_unfused_attention = 0;   // diagnostic: 1 = the three-launch attention (batched Q K^T -> softmax rows -> P V) for every head width
+// diagnostics, per-thread (no process-global mutable state): bit 0 = the three-launch attention (batched Q K^T -> softmax rows -> P V) for
+// every head width on the exact route; bit 1 = exact-fp32 MFMA attention inside the split route (visrep_debug_f32_attention)
+thread_local int t_visrep_f32_attention_dbg = 0;
 namespace {
 
 // x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the subtractions are exact in fp32, so the three planes
@@ -247,8 +248,9 @@ VR_DEV void split3(const float (&v)[4], u32x2& hi, u32x2& mid, u32x2& lo) {
     lo = u32x2{pack_bf16(r0 - bf_lo(mid[0]), r1 - bf_hi(mid[0])), pack_bf16(r2 - bf_lo(mid[1]), r3 - bf_hi(mid[1]))};
 }
 
-// fp32 [rows, K] (leading dimension ldx) -> bf16 planes [rows, 3 K] = hi | mid | lo; K % 4 == 0
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, int ldx, long rows, int K, bf16_t* __restrict__ planes) {
+// fp32 [rows, K] (leading dimension ldx) -> bf16 planes [rows, NPL K] = hi | mid [| lo]; K % 4 == 0
+template <int NPL>
+__global__ __launch_bounds__(256) void split_bf16_planes_kernel(const float* __restrict__ x, int ldx, long rows, int K, bf16_t* __restrict__ planes) {
     const long total = rows * (K / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / (K / 4);
@@ -257,10 +259,10 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
         const float v[4] = {f.x, f.y, f.z, f.w};
         u32x2 ph, pm, pl;
         split3(v, ph, pm, pl);
-        bf16_t* dst = planes + r * 3 * K + c;
+        bf16_t* dst = planes + r * NPL * K + c;
         *reinterpret_cast<u32x2*>(dst) = ph;
         *reinterpret_cast<u32x2*>(dst + K) = pm;
-        *reinterpret_cast<u32x2*>(dst + 2 * K) = pl;
+        if (NPL == 3) *reinterpret_cast<u32x2*>(dst + 2 * K) = pl;
     }
 }
 
@@ -268,7 +270,7 @@ struct AttnF32Args {
     const float* q; const float* k; const float* v; float* out;
     int B, T, H, ld, ldo;
     float sc;                                                 // scale * log2(e)
-    bf16_t* planes; int ldp, pd;                              // split-bf16 route: the context's three bf16 planes [M, 3 pd] instead of `out`
+    bf16_t* planes; int ldp, pd, npl;                         // split-bf16 route: the context's npl (2 | 3) bf16 planes [M, npl pd] instead of `out`
 };
 constexpr int AKT = 64, ALD = 65;
 
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnF32Args p) {
                 bf16_t* dst = prow + dt * 32 + rg * 8 + hi * 4;
                 *reinterpret_cast<u32x2*>(dst) = ph;
                 *reinterpret_cast<u32x2*>(dst + p.pd) = pm;
-                *reinterpret_cast<u32x2*>(dst + 2 * p.pd) = pl;
+                if (p.npl == 3) *reinterpret_cast<u32x2*>(dst + 2 * p.pd) = pl;
             }
         return;
     }
@@ -406,14 +408,21 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnF32Args p) {
 //     16-block are stored as 0-3, 8-11 | 4-7, 12-15 so that the 8 keys a lane needs for one MFMA k-slice are 16 contiguous bytes - the
 //     perm16 order of attention.hip); both are 128-byte rows with the 16-byte slot XOR-swizzled by (row >> 1) & 7, conflict-free for
 //     ds_read_b128;
-//   * S^T = sum over the six significant plane pairs of K_i Q_j^T (v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest terms first), Q planes
+//   * S^T = sum over the NP significant plane pairs of K_i Q_j^T (v_mfma_f32_32x32x16_bf16, fp32 accumulate, smallest terms first), Q planes
 //     in registers for the whole kernel; O^T += sum over the same pairs of V_i^T P_j^T with P split in registers after the fp32 softmax.
-//   96 MFMAs of 32 cycles per 64-key tile instead of 128 exact-fp32 MFMAs of 64 cycles.
+//   NP = 6 (three planes, fp32-equivalent): 96 MFMAs of 32 cycles per 64-key tile instead of 128 exact-fp32 MFMAs of 64 cycles;
+//   NP = 3 / 4 (two planes = 16 significand bits per operand): 48 / 64 MFMAs, two thirds of the split work and of the LDS.
 constexpr int XPL = 64 * 64 * 2;                               // one plane of one tile: 8 KB
+template <int NP> struct SplitPairs;                          // (plane of the LDS operand, plane of the register operand), smallest terms first
+template <> struct SplitPairs<6> { static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct SplitPairs<4> { static constexpr int A[4] = {1, 1, 0, 0}, B[4] = {1, 0, 1, 0}; };
+template <> struct SplitPairs<3> { static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
 
+template <int NP>
 __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Args p) {
-    __shared__ __attribute__((aligned(16))) char Kp[3 * XPL];
-    __shared__ __attribute__((aligned(16))) char Vp[3 * XPL];
+    constexpr int NPL = NP == 6 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) char Kp[NPL * XPL];
+    __shared__ __attribute__((aligned(16))) char Vp[NPL * XPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hi = lane >> 5;
     const int nqt = (p.T + 127) >> 7;
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
     const bool idle = qt * 128 + wave * 32 >= p.T;             // wave-uniform: all 32 query rows past the sequence
 
     // ---- Q planes (B operand of k-slice kk: q = lane & 31, d = 16 kk + 8 hi .. + 8), kept in registers
-    bf16x8 qf[3][4];
+    bf16x8 qf[NPL][4];
     {
         const float* qrow = p.q + (tok0 + (qloc < p.T ? qloc : p.T - 1)) * p.ld + h * 64 + hi * 8;
 #pragma unroll
@@ -437,7 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
             split3(v0, h0, m0, l0);
             split3(v1, h1, m1, l1);
             const u32x4 wh = {h0[0], h0[1], h1[0], h1[1]}, wm = {m0[0], m0[1], m1[0], m1[1]}, wl = {l0[0], l0[1], l1[0], l1[1]};
-            qf[0][kk] = __builtin_bit_cast(bf16x8, wh); qf[1][kk] = __builtin_bit_cast(bf16x8, wm); qf[2][kk] = __builtin_bit_cast(bf16x8, wl);
+            qf[0][kk] = __builtin_bit_cast(bf16x8, wh); qf[1][kk] = __builtin_bit_cast(bf16x8, wm);
+            if (NPL == 3) qf[NPL - 1][kk] = __builtin_bit_cast(bf16x8, wl);
         }
     }
     // ---- staging maps.  K: thread -> (key = tid >> 2, d = 16 (tid & 3) .. + 16): four float4.  V: thread -> (d = tid & 63, keys 16 (tid >> 6) .. + 16).
@@ -470,8 +480,10 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
             *reinterpret_cast<u32x4*>(r1) = u32x4{ph[2][0], ph[2][1], ph[3][0], ph[3][1]};
             *reinterpret_cast<u32x4*>(r0 + XPL) = u32x4{pm[0][0], pm[0][1], pm[1][0], pm[1][1]};
             *reinterpret_cast<u32x4*>(r1 + XPL) = u32x4{pm[2][0], pm[2][1], pm[3][0], pm[3][1]};
-            *reinterpret_cast<u32x4*>(r0 + 2 * XPL) = u32x4{pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
-            *reinterpret_cast<u32x4*>(r1 + 2 * XPL) = u32x4{pl[2][0], pl[2][1], pl[3][0], pl[3][1]};
+            if (NPL == 3) {
+                *reinterpret_cast<u32x4*>(r0 + 2 * XPL) = u32x4{pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+                *reinterpret_cast<u32x4*>(r1 + 2 * XPL) = u32x4{pl[2][0], pl[2][1], pl[3][0], pl[3][1]};
+            }
         }
         {   // V^T: keys 16 vg .. + 16 of row d = vd -> slots 2 vg (keys 0-3, 8-11) and 2 vg + 1 (keys 4-7, 12-15)
             u32x2 ph[4], pm[4], pl[4];
@@ -484,12 +496,14 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
             *reinterpret_cast<u32x4*>(r1) = u32x4{ph[1][0], ph[1][1], ph[3][0], ph[3][1]};
             *reinterpret_cast<u32x4*>(r0 + XPL) = u32x4{pm[0][0], pm[0][1], pm[2][0], pm[2][1]};
             *reinterpret_cast<u32x4*>(r1 + XPL) = u32x4{pm[1][0], pm[1][1], pm[3][0], pm[3][1]};
-            *reinterpret_cast<u32x4*>(r0 + 2 * XPL) = u32x4{pl[0][0], pl[0][1], pl[2][0], pl[2][1]};
-            *reinterpret_cast<u32x4*>(r1 + 2 * XPL) = u32x4{pl[1][0], pl[1][1], pl[3][0], pl[3][1]};
+            if (NPL == 3) {
+                *reinterpret_cast<u32x4*>(r0 + 2 * XPL) = u32x4{pl[0][0], pl[0][1], pl[2][0], pl[2][1]};
+                *reinterpret_cast<u32x4*>(r1 + 2 * XPL) = u32x4{pl[1][0], pl[1][1], pl[3][0], pl[3][1]};
+            }
         }
     };
     // plane pairs (operand from LDS, operand from registers), smallest product terms first
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    using PR = SplitPairs<NP>;
     const int rsw = (lq >> 1) & 7, rbase = lq * 128;
 
     f32x16 o[2];
@@ -505,13 +519,13 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
             f32x16 s[2];
             s[0] = f32x16{}; s[1] = f32x16{};
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int kt2 = 0; kt2 < 2; ++kt2) {
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + PA[pr] * XPL + kt2 * 4096 + rbase + (((2 * kk + hi) ^ rsw) << 4));
-                        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[PB[pr]][kk], s[kt2], 0, 0, 0);
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + PR::A[pr] * XPL + kt2 * 4096 + rbase + (((2 * kk + hi) ^ rsw) << 4));
+                        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[PR::B[pr]][kk], s[kt2], 0, 0, 0);
                     }
             if ((t + 1) * 64 > p.T) {                          // last tile: mask the keys past the image
 #pragma unroll
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
             const float msc = m_new * p.sc;
             const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, p.sc, -msc));
             float psum = 0.f;
-            uint32_t pb[3][2][8];
+            uint32_t pb[NPL][2][8];
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
                     split3(v, ph, pm, pl);
                     pb[0][kt2][r >> 1] = ph[0]; pb[0][kt2][(r >> 1) + 1] = ph[1];
                     pb[1][kt2][r >> 1] = pm[0]; pb[1][kt2][(r >> 1) + 1] = pm[1];
-                    pb[2][kt2][r >> 1] = pl[0]; pb[2][kt2][(r >> 1) + 1] = pl[1];
+                    if (NPL == 3) { pb[NPL - 1][kt2][r >> 1] = pl[0]; pb[NPL - 1][kt2][(r >> 1) + 1] = pl[1]; }
                 }
             l_run = __builtin_fmaf(l_run, alpha, psum);
             m_run = m_new;
@@ -548,15 +562,15 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
             // O^T += V^T P^T: chunk c = 16 keys; the P operand of plane j = 4 packed words of pb[j][c >> 1], words 4 (c & 1) .. + 4
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const u32x4 w = {pb[PB[pr]][c >> 1][4 * (c & 1) + 0], pb[PB[pr]][c >> 1][4 * (c & 1) + 1], pb[PB[pr]][c >> 1][4 * (c & 1) + 2],
-                                     pb[PB[pr]][c >> 1][4 * (c & 1) + 3]};
+                    const u32x4 w = {pb[PR::B[pr]][c >> 1][4 * (c & 1) + 0], pb[PR::B[pr]][c >> 1][4 * (c & 1) + 1], pb[PR::B[pr]][c >> 1][4 * (c & 1) + 2],
+                                     pb[PR::B[pr]][c >> 1][4 * (c & 1) + 3]};
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vp + PA[pr] * XPL + dt * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vp + PR::A[pr] * XPL + dt * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                     }
                 }
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_split_kernel(const AttnF32Arg
                 bf16_t* dst = prow + dt * 32 + rg * 8 + hi * 4;
                 *reinterpret_cast<u32x2*>(dst) = ph;
                 *reinterpret_cast<u32x2*>(dst + p.pd) = pm;
-                *reinterpret_cast<u32x2*>(dst + 2 * p.pd) = pl;
+                if (NPL == 3) *reinterpret_cast<u32x2*>(dst + 2 * p.pd) = pl;
             }
         return;
     }
@@ -612,7 +626,8 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     for (int c = lane; c < d; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
 }
 
-// the same LayerNorm writing the three bf16 planes of its output [rows, 3 d] (the split-bf16 GEMM's operand) instead of fp32; d % 4 == 0
+// the same LayerNorm writing the NPL bf16 planes of its output [rows, NPL d] (the split-bf16 GEMM's operand) instead of fp32; d % 4 == 0
+template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_f32_split_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                                   const float* __restrict__ b, bf16_t* __restrict__ planes, int rows, int d, float eps) {
     const int lane = threadIdx.x & 63;
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_split_kernel(const float* _
     float q = 0.f;
     for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; q += t * t; }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
-    bf16_t* pr = planes + (size_t)row * 3 * d;
+    bf16_t* pr = planes + (size_t)row * NPL * d;
     for (int c = lane * 4; c < d; c += 256) {
         const float4 xv = *reinterpret_cast<const float4*>(xr + c), gv = *reinterpret_cast<const float4*>(g + c), bv = *reinterpret_cast<const float4*>(b + c);
         const float v[4] = {(xv.x - mean) * rstd * gv.x + bv.x, (xv.y - mean) * rstd * gv.y + bv.y, (xv.z - mean) * rstd * gv.z + bv.z,
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_split_kernel(const float* _
         split3(v, ph, pm, pl);
         *reinterpret_cast<u32x2*>(pr + c) = ph;
         *reinterpret_cast<u32x2*>(pr + d + c) = pm;
-        *reinterpret_cast<u32x2*>(pr + 2 * d + c) = pl;
+        if (NPL == 3) *reinterpret_cast<u32x2*>(pr + 2 * d + c) = pl;
     }
 }
 
@@ -778,12 +793,14 @@ WsF32X layout_f32x(const visrep_vit_config* c, int B) {
     return w;
 }
 
-// fp32 GEMM on the bf16 matrix pipe: C = epilogue(A W^T) with A, W given as bf16 plane triples (see GemmArgs::ksplit)
-int launch_gemm_split(const bf16_t* Ap, const bf16_t* Wp, int M, int N, int K, const float* bias, int act, const float* resid, const float* ls, float* C,
-                      int ldc, bf16_t* planes, hipStream_t s) {
+// fp32 GEMM on the bf16 matrix pipe: C = epilogue(A W^T) with A, W given as bf16 planes [rows, npl K] (see GemmArgs::ksplit); products in {3, 4, 6}
+int launch_gemm_split(const bf16_t* Ap, const bf16_t* Wp, int M, int N, int K, int products, const float* bias, int act, const float* resid, const float* ls,
+                      float* C, int ldc, bf16_t* planes, hipStream_t s) {
     GemmArgs a{};
-    a.A = Ap; a.W = Wp; a.C = reinterpret_cast<bf16_t*>(C); a.bias = bias; a.ls = ls; a.resid32 = resid; a.planes = planes; a.ldp = 3 * N;
-    a.M = M; a.N = N; a.K = 6 * K; a.ksplit = K; a.lda = 3 * K; a.ldw = 3 * K; a.ldc = ldc; a.epi = EPI_F32X; a.act = act;
+    if (!visrep_split_tables(products, a.tab_a, a.tab_w)) return visrep_set_error(VISREP_ERR_ARG, "gemm_f32_split: products must be 3, 4 or 6");
+    const int npl = visrep_split_planes(products);
+    a.A = Ap; a.W = Wp; a.C = reinterpret_cast<bf16_t*>(C); a.bias = bias; a.ls = ls; a.resid32 = resid; a.planes = planes; a.ldp = npl * N; a.out_planes = npl;
+    a.M = M; a.N = N; a.K = products * K; a.ksplit = K; a.lda = npl * K; a.ldw = npl * K; a.ldc = ldc; a.epi = EPI_F32X; a.act = act;
     if (!visrep_gemm_v5_supports(a)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm_f32_split: N % 256 == 0 and K % 64 == 0");
     return visrep_gemm_v5_dispatch(a, s);
 }
@@ -796,24 +813,32 @@ bool split_route_supported(const visrep_vit_config* c) {
 
 #define VR_TRY(x) do { const int rc_ = (x); if (rc_) return rc_; } while (0)
 
-extern "C" int visrep_split_bf16x3(const float* x, int ldx, long rows, int K, void* planes, void* stream) {
-    if (!x || !planes) return visrep_set_error(VISREP_ERR_ARG, "split_bf16x3: null pointer");
+extern "C" int visrep_split_bf16_planes(const float* x, int ldx, long rows, int K, int nplanes, void* planes, void* stream) {
+    if (!x || !planes) return visrep_set_error(VISREP_ERR_ARG, "split_bf16_planes: null pointer");
+    if (nplanes != 2 && nplanes != 3) return visrep_set_error(VISREP_ERR_ARG, "split_bf16_planes: nplanes must be 2 or 3");
     if (rows <= 0) return 0;
     if (K <= 0 || (K & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)planes & 7))
-        return visrep_set_error(VISREP_ERR_SHAPE, "split_bf16x3: K and ldx must be multiples of 4, x 16-byte aligned");
+        return visrep_set_error(VISREP_ERR_SHAPE, "split_bf16_planes: K and ldx must be multiples of 4, x 16-byte aligned");
     const long total = rows * (K / 4);
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16)), dim3(256), 0,
-                       (hipStream_t)stream, x, ldx, rows, K, (bf16_t*)planes);
-    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "split_bf16x3: launch failed");
+    const dim3 grid((unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16));
+    if (nplanes == 3) hipLaunchKernelGGL(split_bf16_planes_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, rows, K, (bf16_t*)planes);
+    else hipLaunchKernelGGL(split_bf16_planes_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, rows, K, (bf16_t*)planes);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "split_bf16_planes: launch failed");
 }
 
-extern "C" int visrep_gemm_f32_split(const void* a_planes, const void* w_planes, int M, int N, int K, const float* bias, int act, const float* resid,
-                                     const float* ls, float* C, int ldc, void* out_planes, void* stream) {
+extern "C" int visrep_gemm_f32_split(const void* a_planes, const void* w_planes, int M, int N, int K, int products, const float* bias, int act,
+                                     const float* resid, const float* ls, float* C, int ldc, void* out_planes, void* stream) {
     if (!a_planes || !w_planes || (!C && !out_planes)) return visrep_set_error(VISREP_ERR_ARG, "gemm_f32_split: null pointer");
     if (M <= 0) return 0;
     if (C && (ldc < N || (ldc & 3))) return visrep_set_error(VISREP_ERR_SHAPE, "gemm_f32_split: ldc >= N, % 4 == 0");
-    return launch_gemm_split((const bf16_t*)a_planes, (const bf16_t*)w_planes, M, N, K, bias, act, resid, ls, C, C ? ldc : N, (bf16_t*)out_planes,
-                             (hipStream_t)stream);
+    return launch_gemm_split((const bf16_t*)a_planes, (const bf16_t*)w_planes, M, N, K, products, bias, act, resid, ls, C, C ? ldc : N,
+                             (bf16_t*)out_planes, (hipStream_t)stream);
+}
+
+extern "C" int visrep_debug_f32_attention(int mask) {          // per-thread diagnostic, see t_visrep_f32_attention_dbg; returns the previous mask
+    const int old = t_visrep_f32_attention_dbg;
+    t_visrep_f32_attention_dbg = mask;
+    return old;
 }
 
 extern "C" int visrep_vit_f32_split_supported(const visrep_vit_config* cfg) { return cfg && split_route_supported(cfg) ? 1 : 0; }
@@ -921,7 +946,7 @@ extern "C" int visrep_vit_forward_f32(const visrep_vit_config* c, const visrep_v
         a.alpha = 1.f; a.nb2 = 1;
         a.A = h; a.lda = d; a.K = d; a.M = M; a.W = (const float*)W.wqkv; a.ldw = d; a.N = 3 * d; a.C = qkv; a.ldc = 3 * d; a.bias = W.bqkv; a.epi = EPI_BIAS;
         VR_TRY(launch_gemm_f32(a, 1, s));
-        if (dh == 64 && !g_visrep_f32_unfused_attention) {
+        if (dh == 64 && !(t_visrep_f32_attention_dbg & 1)) {
             // fused flash-style fp32 attention: scores stay in registers (attn_f32_kernel)
             AttnF32Args at{qkv, qkv + d, qkv + 2 * d, h, B, T, H, 3 * d, d, scale * 1.4426950408889634f};
             hipLaunchKernelGGL(attn_f32_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
@@ -962,9 +987,11 @@ extern "C" int visrep_vit_forward_f32(const visrep_vit_config* c, const visrep_v
 // wqkv / wo / w1 / w2 point to the bf16 plane triples [N, 3 K] of the fp32 matrices (visrep_split_bf16x3); its other fields are ignored.
 // Towers whose shapes the 256 x 256 kernel does not take (d or mlp not a multiple of 256, head width != 64:
 // visrep_vit_f32_split_supported) must use visrep_vit_forward_f32.
-extern "C" int visrep_vit_forward_f32_split(const visrep_vit_config* c, const visrep_vit_weights* w, const visrep_vit_weights* wsplit, const float* pixels,
-                                            float* hidden, int B, int n_layers, void* workspace, void* stream) {
+extern "C" int visrep_vit_forward_f32_split(const visrep_vit_config* c, const visrep_vit_weights* w, const visrep_vit_weights* wsplit, int products,
+                                            const float* pixels, float* hidden, int B, int n_layers, void* workspace, void* stream) {
     if (!c || !w || !wsplit || !pixels || !hidden || !workspace) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32_split: null pointer");
+    if (products != 3 && products != 4 && products != 6) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32_split: products must be 3, 4 or 6");
+    const int npl = visrep_split_planes(products);
     if (B <= 0) return 0;
     if (n_layers < 0 || n_layers > c->layers) return visrep_set_error(VISREP_ERR_ARG, "vit_forward_f32_split: n_layers out of range");
     if (!split_route_supported(c)) return visrep_set_error(VISREP_ERR_SHAPE, "vit_forward_f32_split: d and mlp must be multiples of 256, head width 64");
@@ -993,22 +1020,26 @@ extern "C" int visrep_vit_forward_f32_split(const visrep_vit_config* c, const vi
 
     const float scale = 1.0f / sqrtf(64.0f);
     auto ln_split = [&](const float* gma, const float* bta) {
-        hipLaunchKernelGGL(layernorm_f32_split_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, d, gma, bta, hp, M, d, c->eps);
+        if (npl == 3) hipLaunchKernelGGL(layernorm_f32_split_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, x, d, gma, bta, hp, M, d, c->eps);
+        else hipLaunchKernelGGL(layernorm_f32_split_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, x, d, gma, bta, hp, M, d, c->eps);
         return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32_split: layernorm launch failed");
     };
     for (int l = 0; l < n_layers; ++l) {
         const visrep_vit_layer& W = w->layers[l];
         const visrep_vit_layer& S = wsplit->layers[l];
         VR_TRY(ln_split(W.ln1_g, W.ln1_b));
-        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wqkv, M, 3 * d, d, W.bqkv, ACT_NONE, nullptr, nullptr, qkv, 3 * d, nullptr, s));
-        AttnF32Args at{qkv, qkv + d, qkv + 2 * d, nullptr, B, T, H, 3 * d, d, scale * 1.4426950408889634f, hp, 3 * d, d};
-        if (g_visrep_f32_split_attention) hipLaunchKernelGGL(attn_f32_split_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
-        else hipLaunchKernelGGL(attn_f32_kernel, dim3(((T + 127) / 128) * H * B), dim3(256), 0, s, at);
+        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wqkv, M, 3 * d, d, products, W.bqkv, ACT_NONE, nullptr, nullptr, qkv, 3 * d, nullptr, s));
+        AttnF32Args at{qkv, qkv + d, qkv + 2 * d, nullptr, B, T, H, 3 * d, d, scale * 1.4426950408889634f, hp, npl * d, d, npl};
+        const dim3 agrid(((T + 127) / 128) * H * B);
+        if (t_visrep_f32_attention_dbg & 2) hipLaunchKernelGGL(attn_f32_kernel, agrid, dim3(256), 0, s, at);
+        else if (products == 6) hipLaunchKernelGGL(attn_f32_split_kernel<6>, agrid, dim3(256), 0, s, at);
+        else if (products == 4) hipLaunchKernelGGL(attn_f32_split_kernel<4>, agrid, dim3(256), 0, s, at);
+        else hipLaunchKernelGGL(attn_f32_split_kernel<3>, agrid, dim3(256), 0, s, at);
         if (hipGetLastError() != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward_f32_split: attention launch failed");
-        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wo, M, d, d, W.bo, ACT_NONE, x, W.ls1, x, d, nullptr, s));
+        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.wo, M, d, d, products, W.bo, ACT_NONE, x, W.ls1, x, d, nullptr, s));
         VR_TRY(ln_split(W.ln2_g, W.ln2_b));
-        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.w1, M, c->mlp, d, W.b1, c->act, nullptr, nullptr, nullptr, c->mlp, mlpp, s));
-        VR_TRY(launch_gemm_split(mlpp, (const bf16_t*)S.w2, M, d, c->mlp, W.b2, ACT_NONE, x, W.ls2, x, d, nullptr, s));
+        VR_TRY(launch_gemm_split(hp, (const bf16_t*)S.w1, M, c->mlp, d, products, W.b1, c->act, nullptr, nullptr, nullptr, c->mlp, mlpp, s));
+        VR_TRY(launch_gemm_split(mlpp, (const bf16_t*)S.w2, M, d, c->mlp, products, W.b2, ACT_NONE, x, W.ls2, x, d, nullptr, s));
     }
     return 0;
 }

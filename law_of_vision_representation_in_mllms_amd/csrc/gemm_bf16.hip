@@ -14,6 +14,8 @@
 //                four consecutive n  -> one 8-byte bf16x4 store per fragment into row-major C.
 //   SWAP = false (V^T epilogue): a = X fragment, b = W fragment -> lane holds C[m = 4g+r][n = l&15]:
 //                four consecutive m -> one 8-byte store into the token-contiguous V^T layout.
+#include <mutex>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "visrep_internal.h"
@@ -168,11 +170,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_vt(const float* __restrict_
 template <int EPI, bool CONV = false>
 int launch(const GemmArgs& a, hipStream_t s) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128<EPI, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    static VisrepLdsOptIn opt;                                      // per (kernel instantiation, device)
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_128<EPI, CONV>), LDS_BYTES);
     hipLaunchKernelGGL((gemm_bf16_128<EPI, CONV>), dim3(ntm * ntn, a.kslice ? a.K / a.kslice : 1), dim3(256), LDS_BYTES, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
@@ -236,14 +235,64 @@ bool splitk_reduce_emits_stats(const GemmArgs& a) { return a.stat_rt && a.epi ==
 
 }  // namespace
 
-int g_visrep_gemm_variant = 5;
-// split-K scratch, one registration PER DEVICE (a process that drives several GPUs registers one buffer on each; a GEMM only ever
-// uses the buffer of the device it is launched on).  One stream per device at a time may run split-K GEMMs: the planes are not keyed
-// by stream (documented in include/visrep.h).
-void* g_visrep_scratch[VISREP_MAX_DEVICES] = {};
-size_t g_visrep_scratch_bytes[VISREP_MAX_DEVICES] = {};
+thread_local int t_visrep_gemm_variant = 5;
 int g_visrep_gemm_dbg = 0;
 unsigned long long* g_visrep_gemm_dbg_buf = nullptr;
+
+// ---- per-device state -------------------------------------------------------------------------------------------------------------
+int visrep_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < VISREP_MAX_DEVICES ? dev : VISREP_MAX_DEVICES - 1;
+}
+int visrep_cu_count() {
+    static std::atomic<int> n[VISREP_MAX_DEVICES];
+    const int dev = visrep_device();
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (!v) {
+        hipDeviceProp_t prop;
+        v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        n[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// split-K scratch registry: (device, stream) -> caller-owned buffer.  A handful of entries per device, searched under a mutex (a launch-path
+// lookup is a few loads; registration happens once per engine).
+namespace {
+struct ScratchEntry { bool used, any; hipStream_t stream; void* ptr; size_t bytes; };
+constexpr int SCRATCH_SLOTS = 9;                                 // 1 device-wide + 8 stream-keyed registrations per device
+ScratchEntry g_scratch[VISREP_MAX_DEVICES][SCRATCH_SLOTS] = {};
+std::mutex g_scratch_mu;
+}  // namespace
+VisrepScratch visrep_scratch_for(hipStream_t s) {
+    const int dev = visrep_device();
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    VisrepScratch any{nullptr, 0};
+    for (const ScratchEntry& e : g_scratch[dev]) {
+        if (!e.used) continue;
+        if (!e.any && e.stream == s) return VisrepScratch{e.ptr, e.bytes};
+        if (e.any) any = VisrepScratch{e.ptr, e.bytes};
+    }
+    return any;
+}
+int visrep_scratch_register(bool any_stream, hipStream_t s, void* ptr, size_t bytes) {
+    const int dev = visrep_device();
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchEntry* slot = nullptr;
+    for (ScratchEntry& e : g_scratch[dev])
+        if (e.used && e.any == any_stream && (any_stream || e.stream == s)) slot = &e;
+    if (!ptr) {                                                   // unregister
+        if (slot) slot->used = false;
+        return 0;
+    }
+    if (!slot)
+        for (ScratchEntry& e : g_scratch[dev])
+            if (!e.used) { slot = &e; break; }
+    if (!slot) return visrep_set_error(VISREP_ERR_ARG, "set_stream_scratch: at most 8 stream-keyed registrations per device");
+    *slot = ScratchEntry{true, any_stream, s, ptr, bytes};
+    return 0;
+}
 
 namespace {
 int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
@@ -255,17 +304,21 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
         }
         return visrep_set_error(VISREP_ERR_ARG, "conv3x3: epilogue must be BIAS, RESID or F32");
     }
+#ifdef VISREP_EXPERIMENTS                                         // v3 / v4: documented dead ends, tools-only library (build.build_experiments_lib)
     if (variant == 4 && visrep_gemm_v4_supports(a)) return visrep_gemm_v4_dispatch(a, s);
+#endif
     if (variant == 5 && visrep_gemm_v5_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
         return visrep_gemm_v5_dispatch(b, s);
     }
+#ifdef VISREP_EXPERIMENTS
     if (variant == 3 && visrep_gemm_v3_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
         return visrep_gemm_v3_dispatch(b, s);
     }
+#endif
     if (variant >= 2 && visrep_gemm_v2_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
@@ -283,16 +336,7 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
     return visrep_set_error(VISREP_ERR_ARG, "gemm: unknown epilogue");
 }
 
-int cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
+int cu_count() { return visrep_cu_count(); }
 }  // namespace
 
 namespace {
@@ -302,10 +346,9 @@ namespace {
 // fused.  Returns 1 when the problem was handled this way, 0 when it was not eligible, < 0 on error.
 int try_split_k(const GemmArgs& a, hipStream_t s) {
     if (!(a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VISREP_MAX_DEVICES) return 0;
-    void* const scratch = g_visrep_scratch[dev];
-    const size_t scratch_bytes = g_visrep_scratch_bytes[dev];
+    const VisrepScratch reg = visrep_scratch_for(s);               // the buffer of (this device, this stream), else the device-wide one
+    void* const scratch = reg.ptr;
+    const size_t scratch_bytes = reg.bytes;
     if (!scratch) return 0;
     const int ncu = cu_count();
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
@@ -366,7 +409,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
     if (a.stat_rt && a.epi != EPI_RESID) return visrep_set_error(VISREP_ERR_ARG, "gemm: row statistics are an EPI_RESID feature");
-    const int variant = g_visrep_gemm_variant;
+    const int variant = t_visrep_gemm_variant;
     {
         const int sk = run_split_k(a, s);
         if (sk) return sk < 0 ? sk : 0;

@@ -228,16 +228,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256p(const GemmArgs p) {
 
 template <int EPI>
 int launch3(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256p<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device)
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256p<EPI>), LDS2);
+    const int ncu = visrep_cu_count();
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
     hipLaunchKernelGGL(gemm_bf16_256p<EPI>, dim3(grid), dim3(512), LDS2, s, a);

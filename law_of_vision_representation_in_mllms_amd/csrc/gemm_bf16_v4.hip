@@ -292,16 +292,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_256q(const GemmArgs p) {
 
 template <int EPI>
 int launch4(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256q<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device)
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256q<EPI>), LDS4);
+    const int ncu = visrep_cu_count();
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
     hipLaunchKernelGGL(gemm_bf16_256q<EPI>, dim3(grid), dim3(256), LDS4, s, a);

@@ -150,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 
     // ---- LDS-DMA source cursors.  Wave w covers rows [32w, 32w+32) of both operand tiles: 4 instructions of 8 rows x 128 B.
     //      lane -> (row = 8j + lane>>3, physical slot = lane&7); it fetches logical slot (lane&7) ^ ((row>>1)&7).
-    // EPI_F32X: K = 6 ksplit walks six (A plane, W plane) pairs; the logical position k maps to column plane * ksplit + (k mod ksplit) of
-    // the operand's [rows, 3 ksplit] plane matrix: A planes 0 0 0 1 1 2, W planes 0 1 2 0 1 0 (two bits per segment in the constants below)
+    // EPI_F32X: K = nprod * ksplit walks the (A plane, W plane) pairs of p.tab_a / p.tab_w (two bits per segment); the logical position k maps
+    // to column plane * ksplit + (k mod ksplit) of the operand's [rows, nplanes * ksplit] plane matrix
     constexpr bool SPLIT = EPI == EPI_F32X;
     struct Cur { const bf16_t* p[4]; int k, ti, idx, kin, seg; };
     Cur cx, cw;
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     set_x(cx); set_w(cw);
     auto issue_x = [&]() {
         char* dst = smem + ((2 * cx.idx) % NSLOT) * XW_BYTES + wave * 4096;
-        const int kc = col_of(cx, 0x940u);
+        const int kc = col_of(cx, p.tab_a);
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(cx.p[j] + kc, dst + j * 1024);
         advance(cx);
         if (cx.k == p.K) { cx.k = 0; cx.kin = 0; cx.seg = 0; ++cx.ti; set_x(cx); }
     };
     auto issue_w = [&]() {
-        const int kc = col_of(cw, 0x124u);
+        const int kc = col_of(cw, p.tab_w);
         if (V5_OWN) {                                         // group 0 only: eight pieces, rows 64 wn + 8 j + lane>>3
             char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wn * 8192;
             const size_t step = (size_t)16 * p.ldw;
@@ -285,16 +285,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 
 template <int EPI, bool OWN_>
 int launch5o(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device)
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_>), LDS2);
+    const int ncu = visrep_cu_count();
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
     hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_>), dim3(grid), dim3(512), LDS2, s, a);
@@ -309,7 +302,7 @@ int launch5(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 bool visrep_gemm_v5_supports(const GemmArgs& a) {
-    if (a.epi == EPI_F32X && (a.ksplit <= 0 || a.ksplit % TK || a.K != 6 * a.ksplit)) return false;
+    if (a.epi == EPI_F32X && (a.ksplit <= 0 || a.ksplit % TK || a.K % a.ksplit || a.K / a.ksplit < 1 || a.K / a.ksplit > 8)) return false;
     return a.N % TN == 0 && a.K % TK == 0;
 }
 

@@ -420,7 +420,7 @@ VR_DEV void gemm_epilogue_f32x_act(const GemmArgs& p, const f32x4 (&acc)[NI][NJ]
                     bf16_t* pr = p.planes + row[ii] * p.ldp + col(j);
                     store_b64(pr, hi);
                     store_b64(pr + p.N, mid);
-                    store_b64(pr + 2 * p.N, lo);
+                    if (p.out_planes == 3) store_b64(pr + 2 * p.N, lo);      // uniform: two-plane consumers (3 / 4 products) never read lo
                 }
             }
     }

@@ -14,10 +14,15 @@ int visrep_set_error(int code, const char* msg) {
 
 extern "C" int visrep_version(void) { return VISREP_VERSION; }
 
-extern "C" int visrep_set_gemm_variant(int variant) {
-    if (variant < 1 || variant > 5) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1 .. 5");
-    const int old = g_visrep_gemm_variant;
-    g_visrep_gemm_variant = variant;
+extern "C" int visrep_set_gemm_variant(int variant) {            // per-thread (see visrep_internal.h); returns the previous value
+#ifdef VISREP_EXPERIMENTS
+    const bool ok = variant >= 1 && variant <= 5;
+#else
+    const bool ok = variant == 1 || variant == 2 || variant == 5;
+#endif
+    if (!ok) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1, 2 or 5 (3 / 4: VISREP_EXPERIMENTS builds only)");
+    const int old = t_visrep_gemm_variant;
+    t_visrep_gemm_variant = variant;
     return old;
 }
 
@@ -45,11 +50,13 @@ extern "C" size_t visrep_last_error(char* buf, size_t n) {
 extern "C" int visrep_set_scratch(void* ptr, size_t bytes) {
     if ((ptr == nullptr) != (bytes == 0)) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pass (ptr, bytes) or (NULL, 0)");
     if ((size_t)ptr & 15) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pointer must be 16-byte aligned");
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VISREP_MAX_DEVICES) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: no current device");
-    g_visrep_scratch[dev] = ptr;              // registration of the CURRENT device only
-    g_visrep_scratch_bytes[dev] = bytes;
-    return 0;
+    return visrep_scratch_register(true, nullptr, ptr, bytes);   // device-wide registration of the CURRENT device
+}
+
+extern "C" int visrep_set_stream_scratch(void* stream, void* ptr, size_t bytes) {
+    if ((ptr == nullptr) != (bytes == 0)) return visrep_set_error(VISREP_ERR_ARG, "set_stream_scratch: pass (ptr, bytes) or (NULL, 0)");
+    if ((size_t)ptr & 15) return visrep_set_error(VISREP_ERR_ARG, "set_stream_scratch: pointer must be 16-byte aligned");
+    return visrep_scratch_register(false, (hipStream_t)stream, ptr, bytes);   // keyed by (current device, stream)
 }
 
 extern "C" int visrep_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/visrep.h"
 
 typedef unsigned short bf16_t;
@@ -36,14 +38,18 @@ struct GemmArgs {
     // implicit 3x3 convolution (v1 kernel, conv = 1): A is the channels-last activation [B, cH, cW, cC] and the A tile of
     // K-tile (tap, c0) is gathered on the fly: row m = (b, oy, ox) reads x[b, (oy*cstride+ky-cpad)>>cup, (ox*cstride+kx-cpad)>>cup, c0..]
     int conv, cH, cW, cC, cHo, cWo, cstride, cpad, cup;
-    // EPI_F32X (variant 5 only): an fp32 GEMM on the bf16 matrix pipe.  A and W hold the three bf16 planes (hi | mid | lo, x = hi + mid + lo
-    // to 24 bits) of fp32 matrices side by side: A [M, 3 ksplit], W [N, 3 ksplit]; K = 6 ksplit walks the six plane pairs whose product
-    // terms are >= 2^-24 of the result: (hi, hi) (hi, mid) (hi, lo) (mid, hi) (mid, mid) (lo, hi).  Epilogue in fp32:
-    // v = act(acc + bias); v = resid32 + ls * v (if resid32); C (fp32, may be null) and / or the three planes of v -> planes [M, 3 N].
+    // EPI_F32X (variant 5 only): an fp32 GEMM on the bf16 matrix pipe.  A and W hold the bf16 PLANES of fp32 matrices side by side
+    // (hi | mid [| lo]: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); two planes carry 16 significand bits, three carry 24):
+    // A [M, nplanes * ksplit], W [N, nplanes * ksplit].  K = nprod * ksplit walks nprod (A plane, W plane) pairs, two bits per pair in
+    // tab_a / tab_w (split_tables()):  6 products = every pair whose terms are >= 2^-24 of the result - (hi,hi) (hi,mid) (hi,lo) (mid,hi)
+    // (mid,mid) (lo,hi), fp32-equivalent;  4 = the full product of two-plane operands;  3 = (hi,hi) (hi,mid) (mid,hi), terms < 2^-16 dropped.
+    // Epilogue in fp32: v = act(acc + bias); v = resid32 + ls * v (if resid32); C (fp32, may be null) and / or the planes of v ->
+    // planes [M, out_planes * N] (leading dimension ldp).
     int ksplit;
+    unsigned tab_a, tab_w;
     const float* resid32;
     bf16_t* planes;
-    int ldp;
+    int ldp, out_planes;
     unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };
@@ -60,11 +66,39 @@ bool visrep_gemm_v3_supports(const GemmArgs& a);
 int visrep_gemm_v3_dispatch(const GemmArgs& a, hipStream_t s);
 extern int g_visrep_gemm_dbg;
 extern unsigned long long* g_visrep_gemm_dbg_buf;
-extern int g_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 3 / 5 = 256x256 persistent ping-pong kernels (when N % 256 == 0), 4 = 4-wave stream; default 5
+// Kernel-variant selection is PER-THREAD state (visrep_set_*_variant changes the calling thread's choice only): two threads - or two
+// engines on two GPUs driven from two threads - never see each other's diagnostic setting, and the defaults need no setter at all.
+extern thread_local int t_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 5 = 256x256 persistent ping-pong kernels (when N % 256 == 0); 3 / 4: VISREP_EXPERIMENTS builds; default 5
 int visrep_attention_ab_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
                                int B, int Tq, int Tk, int H, int kv_shared, int causal, float scale, hipStream_t st);
-extern int g_visrep_attn_variant;
+extern thread_local int t_visrep_attn_variant;
 int visrep_set_error(int code, const char* msg);
+// split-bf16 product sets (GemmArgs::tab_a / tab_w, attn_f32_split_kernel): products in {3, 4, 6}; planes needed = 2, 2, 3
+inline int visrep_split_planes(int products) { return products == 6 ? 3 : 2; }
+inline bool visrep_split_tables(int products, unsigned& tab_a, unsigned& tab_w) {
+    switch (products) {
+        case 3: tab_a = 0x010u; tab_w = 0x004u; return true;      // A planes 0 0 1,       W planes 0 1 0
+        case 4: tab_a = 0x050u; tab_w = 0x044u; return true;      // A planes 0 0 1 1,     W planes 0 1 0 1
+        case 6: tab_a = 0x940u; tab_w = 0x124u; return true;      // A planes 0 0 0 1 1 2, W planes 0 1 2 0 1 0
+    }
+    return false;
+}
 constexpr int VISREP_MAX_DEVICES = 16;
-extern void* g_visrep_scratch[VISREP_MAX_DEVICES];       // caller-owned device scratch (visrep_set_scratch), per device: split-K partial sums
-extern size_t g_visrep_scratch_bytes[VISREP_MAX_DEVICES];
+
+// ---- per-DEVICE one-shot state: a process may drive several GPUs, and both the multiprocessor count and the function attribute
+// hipFuncAttributeMaxDynamicSharedMemorySize belong to a device, not to the process
+int visrep_device();      // current device index, clamped to [0, VISREP_MAX_DEVICES)
+int visrep_cu_count();    // multiprocessors of the current device (cached per device)
+struct VisrepLdsOptIn { std::atomic<int> bytes[VISREP_MAX_DEVICES]; };   // largest dynamic-LDS size opted in so far, per device (static storage: zeros)
+inline void visrep_lds_opt_in(VisrepLdsOptIn& st, const void* kernel, int bytes) {
+    const int dev = visrep_device();
+    if (st.bytes[dev].load(std::memory_order_acquire) >= bytes) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);   // idempotent: a race between two threads sets it twice
+    st.bytes[dev].store(bytes, std::memory_order_release);
+}
+// Caller-owned split-K scratch (visrep_set_scratch / visrep_set_stream_scratch): keyed by (device, stream).  A stream-keyed registration wins;
+// the device-wide registration (stream key = "any") serves every other stream of that device - callers that run split-K GEMMs on several
+// streams of one device concurrently register one buffer per stream.
+struct VisrepScratch { void* ptr; size_t bytes; };
+VisrepScratch visrep_scratch_for(hipStream_t s);
+int visrep_scratch_register(bool any_stream, hipStream_t s, void* ptr, size_t bytes);

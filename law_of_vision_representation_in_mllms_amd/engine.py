@@ -164,11 +164,15 @@ class VitEngineF32:
     multiple of 4).
     forward() returns fp32 [B, tokens, d]; images are processed in chunks so that the fp32 score matrices stay below `max_ws_bytes`."""
 
-    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30, gemm: str = "auto"):
-        """gemm: 'split' = projections as split-bf16 GEMMs on the bf16 matrix pipe (fp32 values as three bf16 planes, six plane-pair
-        products, fp32 accumulation: ~1e-7 relative per product sum, visrep_vit_forward_f32_split); 'native' = exact-fp32 MFMA
-        (visrep_vit_forward_f32); 'auto' = split where the tower's shapes allow it (d, mlp % 256 == 0, head width 64), VISREP_F32_GEMM
-        in the environment overrides."""
+    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30, gemm: str = "auto",
+                 products: Optional[int] = None):
+        """gemm: 'split' = projections and attention as split-bf16 products on the bf16 matrix pipe (fp32 values as bf16 planes, fp32
+        accumulation, visrep_vit_forward_f32_split); 'native' = exact-fp32 MFMA (visrep_vit_forward_f32); 'auto' = split where the tower's
+        shapes allow it (d, mlp % 256 == 0, head width 64), VISREP_F32_GEMM in the environment overrides.
+        products (split route): 6 = three planes, every plane pair >= 2^-24 of the result (fp32-equivalent, ~1e-7 per product sum);
+        4 / 3 = two planes (16 significand bits), all four pairs / without (mid, mid): ~4e-6 per product sum at half the matrix work.
+        None = DEFAULT_SPLIT_PRODUCTS (the cheapest setting that holds A <= 1e-4 and exact PCK hits on the full-size towers,
+        profiles/round4_precision.md); VISREP_F32_PRODUCTS in the environment overrides."""
         self.lib = _lib.require_gpu()
         self.spec = spec
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -219,17 +223,22 @@ class VitEngineF32:
         if gemm == "split" and not can:
             raise ValueError("split-bf16 route needs d and mlp to be multiples of 256 and head width 64")
         self.gemm = "split" if (gemm != "native" and can) else "native"
+        products = int(os.environ.get("VISREP_F32_PRODUCTS", products if products is not None else DEFAULT_SPLIT_PRODUCTS))
+        if products not in (3, 4, 6):
+            raise ValueError(f"products must be 3, 4 or 6, got {products}")
+        self.products = products if self.gemm == "split" else None
         self._wsplit = None
         if self.gemm == "split":
-            # the four projection matrices of every layer as bf16 plane triples [N, 3 K] (hi | mid | lo), split on the device once
+            npl = split_planes(products)
+            # the four projection matrices of every layer as bf16 planes [N, npl K] (hi | mid [| lo]), split on the device once
             self._split_layers = (_lib.VitLayer * max(n, 1))()
             with torch.cuda.device(self.device):
                 for i in range(n):
                     for k in ("wqkv", "wo", "w1", "w2"):
                         wf = self._keep_by_ptr(getattr(self._layers[i], k))
-                        planes = torch.empty(wf.shape[0], 3 * wf.shape[1], dtype=torch.bfloat16, device=dev)
-                        _lib.check(self.lib.visrep_split_bf16x3(_lib.ptr(wf), wf.stride(0), wf.shape[0], wf.shape[1], _lib.ptr(planes), _lib.stream_ptr()),
-                                   "visrep_split_bf16x3")
+                        planes = torch.empty(wf.shape[0], npl * wf.shape[1], dtype=torch.bfloat16, device=dev)
+                        _lib.check(self.lib.visrep_split_bf16_planes(_lib.ptr(wf), wf.stride(0), wf.shape[0], wf.shape[1], npl, _lib.ptr(planes),
+                                                                     _lib.stream_ptr()), "visrep_split_bf16_planes")
                         self._keep.append(planes)
                         setattr(self._split_layers[i], k, planes.data_ptr())
             self._wsplit = _lib.VitWeights()
@@ -274,8 +283,9 @@ class VitEngineF32:
                 nb = min(step, B - b0)
                 ws = self.workspace(nb)
                 if self.gemm == "split":
-                    rc = self.lib.visrep_vit_forward_f32_split(C.byref(self._cfg), C.byref(self._w), C.byref(self._wsplit), _lib.ptr(px[b0:b0 + nb]),
-                                                               _lib.ptr(out[b0:b0 + nb]), nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
+                    rc = self.lib.visrep_vit_forward_f32_split(C.byref(self._cfg), C.byref(self._w), C.byref(self._wsplit), self.products,
+                                                               _lib.ptr(px[b0:b0 + nb]), _lib.ptr(out[b0:b0 + nb]), nb, n_layers, _lib.ptr(ws),
+                                                               _lib.stream_ptr())
                 else:
                     rc = self.lib.visrep_vit_forward_f32(C.byref(self._cfg), C.byref(self._w), _lib.ptr(px[b0:b0 + nb]), _lib.ptr(out[b0:b0 + nb]),
                                                          nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
@@ -292,30 +302,44 @@ def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf1
     raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
 
 
-def split_bf16x3(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [rows, K] -> bf16 planes [rows, 3 K] = hi | mid | lo (x = hi + mid + lo to 24 bits): the operand format of gemm_f32_split."""
+DEFAULT_SPLIT_PRODUCTS = 6           # plane-pair products of the split-bf16 route (VitEngineF32 / gemm_f32_split); see VitEngineF32.__init__
+
+
+def split_planes(products: int) -> int:
+    """bf16 planes per fp32 value a product set reads: three for the six-product (fp32-equivalent) set, two for 3 / 4 products."""
+    return 3 if products == 6 else 2
+
+
+def split_bf16_planes(x: torch.Tensor, nplanes: int = 3) -> torch.Tensor:
+    """fp32 [rows, K] -> bf16 planes [rows, nplanes K] = hi | mid [| lo] (x = hi + mid + lo to 24 bits; hi + mid to 16): the operand format
+    of gemm_f32_split."""
     lib = _lib.require_gpu()
     rows, K = x.shape
-    planes = torch.empty(rows, 3 * K, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.visrep_split_bf16x3(_lib.ptr(x), x.stride(0), rows, K, _lib.ptr(planes), _lib.stream_ptr()), "visrep_split_bf16x3")
+    planes = torch.empty(rows, nplanes * K, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.visrep_split_bf16_planes(_lib.ptr(x), x.stride(0), rows, K, nplanes, _lib.ptr(planes), _lib.stream_ptr()), "visrep_split_bf16_planes")
     return planes
+
+
+def split_bf16x3(x: torch.Tensor) -> torch.Tensor:
+    return split_bf16_planes(x, 3)
 
 
 def gemm_f32_split(a_planes: torch.Tensor, w_planes: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
                    resid: Optional[torch.Tensor] = None, ls: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                   planes_out: bool = False):
-    """fp32 act(A W^T + bias) (+ LayerScale, residual) on the bf16 matrix pipe from bf16 plane triples; returns the fp32 result, or its own
-    plane triple [M, 3 N] when planes_out."""
+                   planes_out: bool = False, products: int = 6):
+    """fp32 act(A W^T + bias) (+ LayerScale, residual) on the bf16 matrix pipe from bf16 planes (split_bf16_planes with
+    split_planes(products) planes); returns the fp32 result, or its own planes [M, npl N] when planes_out."""
     lib = _lib.require_gpu()
-    M, K3 = a_planes.shape
-    N, K = w_planes.shape[0], K3 // 3
-    if w_planes.shape[1] != K3:
+    npl = split_planes(products)
+    M, Kp = a_planes.shape
+    N, K = w_planes.shape[0], Kp // npl
+    if w_planes.shape[1] != Kp or Kp % npl:
         raise ValueError("gemm_f32_split: operand plane widths differ")
-    po = torch.empty(M, 3 * N, dtype=torch.bfloat16, device=a_planes.device) if planes_out else None
+    po = torch.empty(M, npl * N, dtype=torch.bfloat16, device=a_planes.device) if planes_out else None
     if out is None and not planes_out:
         out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
-    rc = lib.visrep_gemm_f32_split(_lib.ptr(a_planes), _lib.ptr(w_planes), M, N, K, _lib.ptr(bias), _lib.ACT[act], _lib.ptr(resid), _lib.ptr(ls),
-                                   _lib.ptr(out), out.stride(0) if out is not None else N, _lib.ptr(po), _lib.stream_ptr())
+    rc = lib.visrep_gemm_f32_split(_lib.ptr(a_planes), _lib.ptr(w_planes), M, N, K, products, _lib.ptr(bias), _lib.ACT[act], _lib.ptr(resid),
+                                   _lib.ptr(ls), _lib.ptr(out), out.stride(0) if out is not None else N, _lib.ptr(po), _lib.stream_ptr())
     _lib.check(rc, "visrep_gemm_f32_split")
     return po if planes_out else out
 

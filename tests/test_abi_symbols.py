@@ -27,7 +27,32 @@ def test_library_builds_loads_and_exports_everything():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(lib, s), s
-    assert _lib.load().visrep_version() == 200
+    hdr = int(re.search(r"#define VISREP_VERSION (\d+)", open(os.path.join(ROOT, "include", "visrep.h")).read()).group(1))
+    assert _lib.load().visrep_version() == hdr == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A library built against another ABI version (VISREP_LIB pointing at a leftover build) would take arguments at the wrong positions:
+    the binding compares visrep_version() with the version it was written against before binding anything."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.load(build_if_missing=False)
+
+
+def test_variant_knobs_are_per_thread_and_experiments_are_not_in_the_product_library():
+    import threading
+    lib = _lib.load()
+    assert lib.visrep_set_gemm_variant(2) == 5                       # returns the previous (default) value
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.visrep_set_gemm_variant(1)))
+    t.start(); t.join()
+    assert seen == [5]                                               # another thread still sees the default
+    assert lib.visrep_set_gemm_variant(5) == 2
+    for v in (3, 4):                                                 # dead ends live in the tools-only VISREP_EXPERIMENTS build
+        assert lib.visrep_set_gemm_variant(v) == -1 and "EXPERIMENTS" in _lib.last_error()
+    assert lib.visrep_set_attn_variant(2) < 0 and lib.visrep_set_attn_variant(1) == 1
+    assert not hasattr(ctypes.CDLL(_lib.LIB_PATH), "visrep_attention_ab_launch")
 
 
 def test_error_reporting_without_gpu_work():

@@ -18,18 +18,20 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v3_256", "gemm_v4_256q", "gemm_v5_256k64"])
+@pytest.fixture(params=[1, 2, 5], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v5_256k64"])
 def gemm_variant(request):
-    """Run a test under both GEMM kernel families (v2 falls back to v1 when N % 256 != 0)."""
+    """Run a test under every GEMM kernel family of the product library (v2 / v5 fall back to v1 when N % 256 != 0; the measured dead
+    ends v3 / v4 live in the tools-only VISREP_EXPERIMENTS build)."""
     lib = _lib.load()
     old = lib.visrep_set_gemm_variant(request.param)
     yield request.param
     lib.visrep_set_gemm_variant(old)
 
 
-@pytest.fixture(params=[1, 2], ids=["attn_v1", "attn_ab"])
+@pytest.fixture(params=[1], ids=["attn_v1"])
 def attn_variant(request):
-    """Head-width-64 attention under both kernels: the four-wave attn_fwd<1> (default) and the two-blocks-per-wave attn_fwd_ab."""
+    """Attention kernel of the product library: the four-wave attn_fwd<ND> (attn_fwd_ab, round 3's measured-slower rewrite, is in the
+    tools-only VISREP_EXPERIMENTS build)."""
     lib = _lib.load()
     old = lib.visrep_set_attn_variant(request.param)
     yield request.param
@@ -273,22 +275,16 @@ def test_attention_head64_cross_and_causal(B, Tq, Tk, H, shared, causal, attn_va
     assert rel_err(out, want) < 1e-2
 
 
-def test_attention_variants_agree_at_the_headline_shape_sample():
-    """ViT-L/14-336 geometry (16 heads x 577 tokens), 4 images: the two head-width-64 kernels agree to the bf16 rounding of P."""
+def test_attention_at_the_headline_shape_sample():
+    """ViT-L/14-336 geometry (16 heads x 577 tokens), 4 images against the fp32 torch reference of the same op."""
     B, T, H, d = 4, 577, 16, 1024
     g = torch.Generator().manual_seed(3)
     qk = bf(torch.randn(B * T, 2 * d, generator=g)).to(DEV)
     v = bf(torch.randn(B * T, d, generator=g)).to(DEV)
     vt = engine.linear_vt(v, bf(torch.eye(d)).to(DEV), None)
-    lib = _lib.load()
-    outs = []
-    for variant in (1, 2):
-        old = lib.visrep_set_attn_variant(variant)
-        outs.append(engine.mhsa(qk, vt, B, T, H, 0.125))
-        lib.visrep_set_attn_variant(old)
-    assert rel_err(outs[1], outs[0]) < 6e-3
+    out = engine.mhsa(qk, vt, B, T, H, 0.125)
     want = ref_attention(qk[:, :d], qk[:, d:], v, B, T, H)
-    assert rel_err(outs[1], want) < 1e-2 and max_err(outs[1], want) < 1.5e-2
+    assert rel_err(out, want) < 1e-2 and max_err(out, want) < 1.5e-2
 
 
 # ------------------------------------------------------------------------------------------------ towers

@@ -25,27 +25,30 @@ for name, a, N, K, epi, act in (("fc1", x, m, d, _lib.EPI_ACT, "quick_gelu"), ("
     o = torch.empty(M, N, device=dev)
     sec = ev(lambda: engine.gemm_f32(a, w, b, epi, act, out=o))
     print(f"gemm_f32 {name}: M={M} N={N} K={K}: {sec * 1e3:.3f} ms  {2.0 * M * N * K / sec / 1e12:.1f} TFLOP/s  ({2.0 * M * N * K / sec / 157.3e12:.3f} of the fp32 MFMA roof)", flush=True)
-    # the same product on the bf16 matrix pipe: three planes per operand, six plane-pair products (6x the bf16 FLOP)
-    ap, wp = engine.split_bf16x3(a), engine.split_bf16x3(w)
-    sec_sp = ev(lambda: engine.split_bf16x3(a))
+    # the same product on the bf16 matrix pipe: three planes / six plane-pair products (6x the bf16 FLOP), two planes / four and three products
     act_s = act if epi == _lib.EPI_ACT else "none"
-    sec = ev(lambda: engine.gemm_f32_split(ap, wp, b, act=act_s, out=o))
     ref = engine.gemm_f32(a[:4096], w, b, epi, act)
-    got = engine.gemm_f32_split(ap[:4096], wp, b, act=act_s)
-    print(f"   split-bf16 {name}: {sec * 1e3:.3f} ms  {2.0 * M * N * K / sec / 1e12:.1f} fp32-equivalent TFLOP/s = {12.0 * M * N * K / sec / 1e12:.0f} bf16 TFLOP/s "
-          f"({12.0 * M * N * K / sec / 2500e12:.3f} of the bf16 roof); split pass of A alone {sec_sp * 1e3:.3f} ms; |split - exact| / |exact| = "
-          f"{((got - ref).double().norm() / ref.double().norm()).item():.2e}", flush=True)
-    del ap, wp
+    for products in (6, 4, 3):
+        npl = engine.split_planes(products)
+        ap, wp = engine.split_bf16_planes(a, npl), engine.split_bf16_planes(w, npl)
+        sec_sp = ev(lambda: engine.split_bf16_planes(a, npl))
+        sec = ev(lambda: engine.gemm_f32_split(ap, wp, b, act=act_s, out=o, products=products))
+        got = engine.gemm_f32_split(ap[:4096], wp, b, act=act_s, products=products)
+        print(f"   split-bf16 x{products} {name}: {sec * 1e3:.3f} ms  {2.0 * M * N * K / sec / 1e12:.1f} fp32-equivalent TFLOP/s = {2.0 * products * M * N * K / sec / 1e12:.0f} bf16 TFLOP/s "
+              f"({2.0 * products * M * N * K / sec / 2500e12:.3f} of the bf16 roof); split pass of A alone {sec_sp * 1e3:.3f} ms; |split - exact| / |exact| = "
+              f"{((got - ref).double().norm() / ref.double().norm()).item():.2e}", flush=True)
+        del ap, wp
 spec = VW.SPECS["openai/clip-vit-large-patch14-336"]
 wts = VW.synthetic_weights(spec, seed=1, n_layers=23)
 px = torch.randn(B, 3, 336, 336, device=dev, generator=g)
 fl = 23 * (2 * T * d * 3 * d + 2 * T * d * d + 4 * T * T * d + 4 * T * d * m) * B
 outs = {}
-for route in ("native", "split"):
-    eng = engine.VitEngineF32(spec, wts, dev, gemm=route)
+for route in ("native", "split6", "split4", "split3"):
+    eng = engine.VitEngineF32(spec, wts, dev, gemm=route[:5] if route != "native" else route, products=int(route[5:]) if route != "native" else None)
     sec = ev(lambda: eng.forward(px, n_layers=23), reps=2)
     outs[route] = eng.forward(px[:4], n_layers=23)
     print(f"fp32 tower ({route} GEMMs) batch {B}: {sec * 1e3:.1f} ms = {B / sec:.1f} images/s = {fl / sec / 1e12:.1f} fp32-equivalent TFLOP/s "
           f"({fl / sec / 157.3e12:.3f} of the exact-fp32 MFMA roof)", flush=True)
     del eng
-print(f"split vs native features: rel L2 {((outs['split'] - outs['native']).double().norm() / outs['native'].double().norm()).item():.2e}")
+for r in ("split6", "split4", "split3"):
+    print(f"{r} vs native features: rel L2 {((outs[r] - outs['native']).double().norm() / outs['native'].double().norm()).item():.2e}")
