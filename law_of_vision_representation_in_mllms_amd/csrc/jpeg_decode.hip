@@ -150,6 +150,7 @@ int parse(const uint8_t* d, size_t n, Parsed& P, const char*& why) {
             if (sl >= 12 && !memcmp(s, "Adobe", 5)) adobe_transform = s[11];
         } else if (m == 0xDA) {                                    // SOS
             if (!sof) { why = "scan before frame header"; return VISREP_ERR_ARG; }
+            if (sl < 1) { why = "bad SOS"; return VISREP_ERR_ARG; }
             const int ns = s[0];
             if (sl < 1 + 2 * ns + 3) { why = "bad SOS"; return VISREP_ERR_ARG; }
             if (ns != I.ncomp) { why = "non-interleaved (multi-scan) file"; I.unsupported = 1; }
@@ -199,11 +200,17 @@ int parse(const uint8_t* d, size_t n, Parsed& P, const char*& why) {
 // ---- bit reader over the entropy-coded segment (byte stuffing, restart markers)
 struct Bits {
     const uint8_t* d; size_t n, pos;
-    uint64_t acc; int cnt;                 // `cnt` valid bits at the TOP of the low 32 bits... kept simple: acc holds cnt bits, msb first
+    uint64_t acc; int cnt;                 // acc holds cnt valid bits, msb first
     bool hit_marker;
+    int fake;                              // zero bytes fed past a marker / the end of the data (the newest `fake` bytes of acc)
+    // True once the decoder has CONSUMED bits that were not in the file: the entropy-coded segment ended (a marker, or the data itself)
+    // before the MCUs it should hold.  libjpeg pads such a scan with zeros and warns; PIL raises "image file is truncated" when the data
+    // ends - either way the reference does not silently produce these blocks, so the caller falls back to PIL (which raises like the reference).
+    inline bool overran() const { return cnt < 8 * fake; }
     void fill() {
         while (cnt <= 48) {
             int b = 0;
+            const bool was = hit_marker;
             if (!hit_marker && pos < n) {
                 b = d[pos];
                 if (b == 0xFF) {
@@ -216,6 +223,7 @@ struct Bits {
             } else if (pos >= n) {
                 hit_marker = true;
             }
+            if (hit_marker || was) ++fake;
             acc = (acc << 8) | (uint64_t)b;
             cnt += 8;
         }
@@ -274,16 +282,18 @@ extern "C" int visrep_jpeg_entropy_decode(const void* data, size_t n, int16_t* c
     long plane[3];
     plane[0] = 0;
     for (int c = 1; c < I.ncomp; ++c) plane[c] = plane[c - 1] + (long)I.blocks_w[c - 1] * I.blocks_h[c - 1] * 64;
-    Bits b{(const uint8_t*)data, n, P.scan_off, 0, 0, false};
+    Bits b{(const uint8_t*)data, n, P.scan_off, 0, 0, false, 0};
     int pred[3] = {0, 0, 0};
     const long nmcu = (long)I.mcus_w * I.mcus_h;
     int to_restart = I.restart_interval;
     for (long m = 0; m < nmcu; ++m) {
         if (I.restart_interval && to_restart == 0) {
             // byte-align, expect RSTn, reset the predictors (jdhuff.c process_restart)
-            b.acc = 0; b.cnt = 0; b.hit_marker = false;
+            if (b.overran()) return visrep_set_error(VISREP_ERR_ARG, "jpeg: entropy-coded data ends before its restart interval (truncated or corrupt)");
+            b.acc = 0; b.cnt = 0; b.hit_marker = false; b.fake = 0;
             while (b.pos + 1 < n && !(b.d[b.pos] == 0xFF && b.d[b.pos + 1] >= 0xD0 && b.d[b.pos + 1] <= 0xD7)) ++b.pos;   // skip to the marker
-            if (b.pos + 1 < n) b.pos += 2;
+            if (b.pos + 1 >= n) return visrep_set_error(VISREP_ERR_ARG, "jpeg: restart marker missing (truncated or corrupt)");
+            b.pos += 2;
             pred[0] = pred[1] = pred[2] = 0;
             to_restart = I.restart_interval;
         }
@@ -318,6 +328,7 @@ extern "C" int visrep_jpeg_entropy_decode(const void* data, size_t n, int16_t* c
         }
         if (I.restart_interval) --to_restart;
     }
+    if (b.overran()) return visrep_set_error(VISREP_ERR_ARG, "jpeg: entropy-coded data ends before the last MCU (truncated or corrupt)");
     return 0;
 }
 

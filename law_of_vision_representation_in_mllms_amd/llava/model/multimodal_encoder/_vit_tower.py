@@ -146,6 +146,9 @@ class HipViTTower(nn.Module):
         if path is not None:
             from transformers import AutoConfig
             return AutoConfig.from_pretrained(path)
+        if self.vision_tower_name not in VW.SPECS:           # like from_pretrained on a name that is neither a directory nor cached
+            raise OSError(f"{self.vision_tower_name} is not a local checkpoint directory, is not in the offline HF cache and has no built-in "
+                          "architecture")
         spec = VW.SPECS[self.vision_tower_name]
         return SimpleNamespace(hidden_size=spec.d, image_size=spec.image_size, patch_size=spec.patch,
                                num_hidden_layers=spec.layers, num_attention_heads=spec.heads, intermediate_size=spec.mlp)

@@ -431,3 +431,75 @@ def test_aggregation_network_on_device_matches_reference(tag):
     torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
     again = net(x)                                                              # CPU tensor in: moved to the device, cached packing reused
     assert torch.equal(again, got)
+
+
+# ------------------------------------------------------------------------------------------------ towers built from checkpoint DIRECTORIES
+@pytest.mark.parametrize("fmt", ["safetensors", "bin2"])
+@pytest.mark.parametrize("kind", ["clip_full", "dinov2", "siglip"])
+def test_tower_built_from_a_checkpoint_directory_equals_the_hf_model(tmp_path, kind, fmt):
+    """The reference's `from_pretrained(path)` route end to end (clip_encoder.py:22-27): a tiny HF model saved with save_pretrained
+    (safetensors, and a two-shard .bin) -> tower class pointed at the DIRECTORY -> features equal HF's own forward of that model (the
+    arithmetic the reference runs) and the oracle on the packed weights.  tests/test_host_checkpoints.py pins the loader itself."""
+    from test_host_checkpoints import tiny_hf_model, write_checkpoint
+    model, Tower, family = tiny_hf_model(kind)
+    path = str(tmp_path / kind)
+    write_checkpoint(model, path, fmt, {"height": 42, "width": 42} if kind == "dinov2" else None)
+    sel = "cls_patch" if family == "siglip" else "patch"
+    tower = Tower(path, SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature=sel, device=DEV))
+    assert tower.is_loaded and tower.vision_tower_name == path
+    side = tower.spec.image_size
+    px = torch.randn(3, 3, side, side, generator=torch.Generator().manual_seed(2))
+    got = tower(px)
+    with torch.no_grad():
+        vm = model.vision_model if kind == "clip_full" else model
+        kw = {"interpolate_pos_encoding": True} if kind == "dinov2" and "interpolate_pos_encoding" in vm.forward.__code__.co_varnames else {}
+        hs = vm(pixel_values=px, output_hidden_states=True, **kw).hidden_states[-2]
+    want_hf = hs if family == "siglip" else hs[:, 1:]
+    spec, w = tower._spec_and_weights()
+    want = OV.tower_features(spec, w, px, -2, sel)
+    assert rel(want, want_hf) < 1e-5                         # the oracle on the weights read from disk IS the saved HF model
+    assert got.shape == want.shape and rel(got, want) < 2e-2 and rel(got, want_hf) < 2e-2      # bf16 engine vs fp32
+    t32 = Tower(path, SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature=sel, device=DEV, tower_precision="fp32"))
+    assert rel(t32(px), want_hf) < 2e-5                      # the reference-precision engine reproduces HF's fp32 forward
+
+
+def test_sd_featurizer_built_from_a_diffusers_directory(tmp_path):
+    """SDFeaturizer(sd_id = a local diffusers-layout directory) - unet/ vae/ scheduler/ text_encoder/ tokenizer/ read from disk
+    (dift_sd.py:226-243) - gives bit-identical features to engines built from the same weights in memory and fed the same token ids."""
+    import json
+    from test_host_checkpoints import write_diffusers_dir
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM.src.models import dift_sd as DS
+    from law_of_vision_representation_in_mllms_amd.sd_engine import SdEngine
+    from law_of_vision_representation_in_mllms_amd.text_engine import ClipTextEngine
+    spec = SW.tiny_sd_spec()
+    # a byte-level CLIP BPE vocabulary (256 byte symbols, their word-final forms, <bos>, <eos>; no merges): a real CLIPTokenizer offline
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {t: i for i, t in enumerate(chars + [c + "</w>" for c in chars] + ["<|startoftext|>", "<|endoftext|>"])}
+    ts = SW.TextSpec(vocab=len(vocab), d=128, mlp=256, layers=2, heads=2, max_pos=16, act="quick_gelu")
+    wu, wv, wt = SW.synthetic_unet(spec.unet, 21, n_up_blocks=len(spec.unet.block_out)), SW.synthetic_vae(spec.vae, 22), SW.synthetic_text(ts, 23)
+    root = str(tmp_path / "tiny-sd")
+    write_diffusers_dir(root, spec, ts, wu, wv, wt)
+    os.makedirs(os.path.join(root, "tokenizer"))
+    json.dump(vocab, open(os.path.join(root, "tokenizer", "vocab.json"), "w"))
+    open(os.path.join(root, "tokenizer", "merges.txt"), "w").write("#version: 0.2\n")
+    json.dump({"model_max_length": 16}, open(os.path.join(root, "tokenizer", "tokenizer_config.json"), "w"))
+    feat = DS.SDFeaturizer(root, device=DEV, synthetic=False)
+    assert feat.tokenizer is not None and feat.spec.unet == spec.unet and feat.text_spec == ts
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    f = 2 ** (len(spec.vae.block_out) - 1)
+    z = spec.vae.latent_channels
+    n1, n2 = torch.randn(2, z, 64 // f, 64 // f, generator=g), torch.randn(2, z, 64 // f, 64 // f, generator=g)
+    got = feat.forward(img.to(DEV), "a cat", t=1, up_ft_index=0, post_noise=n1.to(DEV), ddim_noise=n2.to(DEV))
+    ids = feat.tokenize("a cat")
+    assert ids.shape == (1, 16) and int(ids[0, 0]) == vocab["<|startoftext|>"] and int(ids[0, -1]) == vocab["<|endoftext|>"]
+    emb = ClipTextEngine(ts, wt, DEV).forward(ids)
+    tok = SdEngine(spec, wu, wv, DEV, up_ft_index=0).forward(img.to(DEV), emb, t=1, post_noise=n1.to(DEV), ddim_noise=n2.to(DEV))
+    want = tok.view(2, 1, got.shape[-2], got.shape[-1], tok.shape[2]).permute(0, 1, 4, 2, 3).squeeze()
+    assert got.shape == want.shape and torch.equal(got, want)

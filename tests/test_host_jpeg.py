@@ -74,3 +74,20 @@ def test_files_this_decoder_does_not_take_say_why():
     good = encode(photo(64, 64, 9), quality=75)
     with pytest.raises(ValueError):
         DJ.entropy_decode(good[: len(good) // 6])                              # truncated inside the headers
+
+
+@pytest.mark.parametrize("kw", [dict(quality=75, subsampling=2), dict(quality=75, subsampling=2, restart_marker_blocks=3)])
+def test_truncated_or_short_entropy_data_is_an_error_not_garbage(kw):
+    """A scan that ends before its MCUs (file cut inside the entropy-coded segment, or an EOI placed early) must not yield blocks decoded
+    from the zero padding: PIL raises "image file is truncated" for the cut file (the reference stops there), so the host decoder reports
+    an error and DeviceJpegDecoder hands the file to PIL, which raises like the reference."""
+    good = encode(photo(160, 120, 21), **kw)
+    info, _, _ = DJ.entropy_decode(good)                                       # the whole file decodes
+    for cut in (len(good) // 2, len(good) - 40):
+        with pytest.raises(ValueError, match="truncated|restart"):
+            DJ.entropy_decode(good[:cut])
+        with pytest.raises(OSError):
+            Image.open(io.BytesIO(good[:cut])).convert("RGB")
+    early_eoi = good[: len(good) // 2] + b"\xff\xd9"                           # complete markers, short scan
+    with pytest.raises(ValueError, match="truncated|restart"):
+        DJ.entropy_decode(early_eoi)
