@@ -44,10 +44,23 @@ BATCH = 256
 N_LAYERS = 23                     # select_layer = -2: the 24th layer is never needed
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0             # HBM3E (MI355X_MICROARCH.md)
-# HBM bytes per fc1 launch at batch 256 with the default (v2) GEMM, from rocprofv3 PMC passes of this kernel at this shape
-# (profiles/round3_final_kernel_stats.md, v2: round2_v2default_kernel_stats.md: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of
-# MI355X_MICROARCH.md "HBM"; round 1 calibrated both on layernorm_rows' known byte count).  Algorithmic bytes are 1.52e9.
-FC1_HBM_BYTES_PER_LAUNCH = {(5, 256): 2.962e9, (2, 256): 3.055e9}
+# roofline.traffic = HBM bytes per fc1 launch.  Hardware counters cannot be read from inside this process (rocprofv3 owns them), so the
+# figure is a CITATION of a committed PMC pass over this kernel at this shape, carried with its provenance: profiles/fc1_traffic.json
+# (written by tools/summarize_pmc.py from `rocprofv3 --pmc` runs: FETCH_SIZE and WRITE_SIZE in separate passes, units and the gfx950
+# FETCH correction as MI355X_MICROARCH.md "HBM" prescribes).  No matching record (other variant / batch, or no file) -> traffic is null.
+FC1_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "fc1_traffic.json")
+
+
+def fc1_traffic(variant, batch):
+    try:
+        with open(FC1_TRAFFIC_FILE) as fh:
+            recs = json.load(fh)["records"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for r in recs:
+        if r.get("gemm_variant") == variant and r.get("batch") == batch:
+            return float(r["hbm_bytes_per_launch"]), {k: r[k] for k in ("source", "method", "collected", "kernel") if k in r}
+    return None, None
 
 
 def flops_per_image(spec, n_layers):
@@ -158,9 +171,11 @@ def fp32_tower_extra(dev, spec, weights, batch=64):
     px = torch.randn(batch, 3, spec.image_size, spec.image_size, device=dev)
     T, d, m = spec.tokens, spec.d, spec.mlp
     fl = N_LAYERS * (2 * T * d * 3 * d + 2 * T * d * d + 4 * T * T * d + 4 * T * d * m) * batch
-    out = {"batch": batch}
-    for route in ("auto", "native"):
-        eng = engine.VitEngineF32(spec, weights, dev, gemm=route)
+    out = {"batch": batch, "default_products": engine.DEFAULT_SPLIT_PRODUCTS}
+    for route, products in (("auto", None), ("split", 6), ("native", None)):
+        if products == engine.DEFAULT_SPLIT_PRODUCTS:
+            continue                                                          # already measured as the default
+        eng = engine.VitEngineF32(spec, weights, dev, gemm=route, products=products)
         for _ in range(2):
             eng.forward(px, n_layers=N_LAYERS)
         torch.cuda.synchronize(dev)
@@ -172,8 +187,13 @@ def fp32_tower_extra(dev, spec, weights, batch=64):
             e1.record()
             torch.cuda.synchronize(dev)
             sec = min(sec, e0.elapsed_time(e1) * 1e-3)
-        out[eng.gemm] = {"ms": round(sec * 1e3, 1), "images_per_s": round(batch / sec, 1), "fp32_equivalent_tflops": round(fl / sec / 1e12, 1),
-                         "frac_of_exact_fp32_mfma_roof": round(fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 3)}
+        ent = {"ms": round(sec * 1e3, 1), "images_per_s": round(batch / sec, 1), "fp32_equivalent_tflops": round(fl / sec / 1e12, 1)}
+        if eng.gemm == "split":      # the pipe it runs on is the bf16 one: `products` bf16 plane-pair products per fp32 product
+            ent.update(products=eng.products, bf16_tflops=round(eng.products * fl / sec / 1e12, 1), bound="mfma (bf16)",
+                       frac=round(eng.products * fl / sec / 1e12 / PEAK_BF16_TFLOPS, 4))
+        else:
+            ent.update(bound="mfma (exact fp32)", frac=round(fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        out[f"split{eng.products}" if eng.gemm == "split" else "native"] = ent
         del eng
     torch.cuda.empty_cache()
     return out
@@ -193,9 +213,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
     ap.add_argument("--sweep", default="full", choices=["off", "reduced", "full"])
+    ap.add_argument("--sweep-precision", default="reference", choices=["reference", "bf16", "fp32"])   # reference: A leg bf16, C leg per the reference's scripts
     ap.add_argument("--no-scores", action="store_true")
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 3, 4, 5])
-    ap.add_argument("--attn-variant", type=int, default=int(os.environ.get("VISREP_ATTN_VARIANT", "0")), choices=[0, 1, 2])   # 0 = library default
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 5])
     args = ap.parse_args()
 
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # host-side weight packing: torch's default (128 here) thrashes, see cpu_baseline
@@ -215,9 +235,7 @@ def main():
     from law_of_vision_representation_in_mllms_amd import _lib, engine
     from law_of_vision_representation_in_mllms_amd import vit_weights as VW
 
-    _lib.load().visrep_set_gemm_variant(args.gemm_variant)
-    if args.attn_variant:
-        _lib.load().visrep_set_attn_variant(args.attn_variant)
+    _lib.load().visrep_set_gemm_variant(args.gemm_variant)              # per-thread knob: this (the launching) thread
     spec = VW.SPECS[MODEL]
     weights = VW.synthetic_weights(spec, seed=1, n_layers=N_LAYERS)      # same tower replica on every rank
     eng = engine.VitEngine(spec, weights, dev)
@@ -324,9 +342,10 @@ def main():
                 head = {"rows": m1, "ms": round(hs * 1e3, 4), "tflops": round(2.0 * m1 * m * d / hs / 1e12, 1)}
         except Exception as e:                                          # never let the extra line take the bench down
             head = {"error": str(e)[:200]}
-        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 3: "gemm_bf16_256p", 4: "gemm_bf16_v4", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
+        traffic, traffic_src = fc1_traffic(args.gemm_variant, B)
+        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
-                "traffic": FC1_HBM_BYTES_PER_LAUNCH.get((args.gemm_variant, B)), "traffic_unit": "HBM bytes per launch (PMC, profiles/round3_final_kernel_stats.md)",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_provenance": traffic_src,
                 "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),
                 "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"], "dominant_kernel_only": head,
                 "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),
@@ -410,7 +429,7 @@ def main():
             torch.cuda.empty_cache()
             from law_of_vision_representation_in_mllms_amd import sweep as SW
             spair = SW.synthetic_spair() if args.sweep == "full" else SW.synthetic_spair(180, 1224)
-            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev)
+            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev, precision=args.sweep_precision, also_bf16=True)
             sweep["size"] = args.sweep
         except Exception as e:                                           # the headline line must survive a sweep failure
             sweep = {"error": f"{type(e).__name__}: {e}"[:300]}

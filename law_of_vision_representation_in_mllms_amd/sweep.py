@@ -68,6 +68,15 @@ SETTINGS = (
     Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 128),
 )
 REFS = ("clip336", "clip224")
+# The dtype the reference runs each tower in on its C path (C_score/extract_feature.py:36-50,80-91: CLIP / OpenCLIP / DINOv2 are built with no
+# dtype cast and fed fp32 pixels; SigLIP and every diffusion tower run in bf16) - keyed by registry id; anything else (diffusion ids) = bf16.
+# Its A path is LLaVA's: the whole model is `.to(bfloat16)`, so every tower and the projector run in bf16 there.
+_C_REF_NAME = {CLIP336: "CLIP", CLIP224: "CLIP", OPENCLIP: "OPENCLIP", DINOV2: "DINOv2", SIGLIP: "SigLIP"}
+
+
+def reference_c_precision(tower_id: str) -> str:
+    from .C_score.extract_feature import _REF_PRECISION
+    return _REF_PRECISION.get(_C_REF_NAME.get(tower_id, ""), "bf16")
 SPAIR_CATEGORIES = ("aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "dog", "horse", "motorbike",
                     "person", "pottedplant", "sheep", "train", "tvmonitor")
 
@@ -122,43 +131,71 @@ class SettingModel:
     """Tower(s) + mlp2x_gelu projector of one setting, built through the drop-in registry (llava_arch.build_function_mapping)."""
 
     def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16", fast_weights: bool = True):
-        """precision: 'bf16' = MFMA throughput engines + bf16 projector (what LLaVA runs); 'fp32' = reference-precision ViT towers and an
-        fp32 projector (diffusion towers are bf16 in the reference too).  fast_weights: draw the synthetic weights with the GPU's
-        generator (seconds instead of minutes for the 1-3 G parameter diffusion models); False keeps the version-stable numpy stream."""
+        """precision:
+          'reference' = the reference's own arithmetic per leg: A leg in bf16 (LLaVA's model.to(bfloat16): towers and projector), C leg per
+                        tower as C_score/extract_feature.py builds it (`reference_c_precision`: fp32 for CLIP / OpenCLIP / DINOv2 and both
+                        fusions, bf16 for SigLIP and the diffusion towers) - a setting whose two legs differ holds two engines per tower;
+          'bf16'      = MFMA throughput engines on both legs + bf16 projector;
+          'fp32'      = reference-precision ViT towers and an fp32 projector on both legs (diffusion towers are bf16 in the reference too).
+        fast_weights: draw the synthetic weights with the GPU's generator (seconds instead of minutes for the 1-3 G parameter diffusion
+        models); False keeps the version-stable numpy stream."""
         from .llava.model import llava_arch as LA
         from .llava.model.multimodal_projector.builder import build_vision_projector
+        if precision not in ("reference", "bf16", "fp32"):
+            raise ValueError(f"precision must be 'reference', 'bf16' or 'fp32', got {precision!r}")
         self.setting, self.device = setting, torch.device(device)
-        self.towers = []
         env = {"VISREP_SYNTHETIC_WEIGHTS": "1"} if synthetic else {}
         if synthetic and fast_weights:
             env["VISREP_FAST_SYNTHETIC"] = "cuda" if self.device.type == "cuda" else "1"
+
+        def tower(tid, prec):
+            cfg = SimpleNamespace(mm_vision_tower=tid, vision_tower=tid, mm_vision_select_layer=-2, mm_vision_select_feature='patch',
+                                  up_ft_index=0, t=1, prompt='', ensemble_size=1, img_size=setting.size,        # train.py:83-87 defaults
+                                  vit_img_size=setting.size, synthetic_weights=synthetic, device=self.device, tower_precision=prec)
+            return LA.build_function_mapping[tid](cfg)
+        a_prec = "fp32" if precision == "fp32" else "bf16"
         with _environ(env):
-            for tid in setting.towers:
-                cfg = SimpleNamespace(mm_vision_tower=tid, vision_tower=tid, mm_vision_select_layer=-2, mm_vision_select_feature='patch',
-                                      up_ft_index=0, t=1, prompt='', ensemble_size=1, img_size=setting.size,        # train.py:83-87 defaults
-                                      vit_img_size=setting.size, synthetic_weights=synthetic, device=self.device, tower_precision=precision)
-                self.towers.append(LA.build_function_mapping[tid](cfg))
+            self.towers = [tower(tid, a_prec) for tid in setting.towers]                      # A leg
+            self.c_towers = []                                                                # C leg: the same objects unless the dtype differs
+            for tid, ta in zip(setting.towers, self.towers):
+                c_prec = reference_c_precision(tid) if precision == "reference" else a_prec
+                same = (ta.dtype == torch.float32) == (c_prec == "fp32") or hasattr(ta, "up_ft_index")
+                self.c_towers.append(ta if same else tower(tid, c_prec))
+        name = lambda ts: "+".join(sorted({"fp32" if t.dtype == torch.float32 else "bf16" for t in ts}))
+        self.dtypes = {"a": name(self.towers), "c": name(self.c_towers)}
         self.width = sum(t.hidden_size for t in self.towers)
         torch.manual_seed(7)                                             # same projector on every rank
         self.projector = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=self.width, hidden_size=hidden))
         if precision != "fp32":
             self.projector = self.projector.to(torch.bfloat16)           # what LLaVA's model.to(bfloat16) leaves: the bf16 MFMA path
         self.split = self.towers[0].hidden_size if len(self.towers) == 2 else 0
-        self._px_dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self._px_dtype = torch.float32 if any(t.dtype == torch.float32 for t in self.towers + self.c_towers) else torch.bfloat16
 
     def warm(self, shapes: Sequence[int]) -> None:
         """Untimed warm-up at every launch shape the sweep will use on this rank (HIP-graph capture of the diffusion towers, engine
-        workspaces): no capture or allocation is left for the timed region."""
+        workspaces), on both legs' engines: no capture or allocation is left for the timed region."""
         if self.device.type != "cuda":
             return
         for n in sorted(set(int(x) for x in shapes if x > 0)):
-            self.project(self.tokens(synthetic_pixels(range(n), self.setting.size, self.device, self._px_dtype)))
+            px = synthetic_pixels(range(n), self.setting.size, self.device, self._px_dtype)
+            self.project(self.tokens(px))
+            if any(c is not a for c, a in zip(self.c_towers, self.towers)):
+                self.c_tokens(px)
+
+    @staticmethod
+    def _run(towers, px):
+        f = [t(px if t.dtype == px.dtype else px.to(t.dtype)) for t in towers]               # every tower is fed (and answers in) its own dtype
+        return f[0] if len(f) == 1 else torch.cat(f, dim=-1)
 
     @torch.no_grad()
     def tokens(self, px: torch.Tensor) -> torch.Tensor:
-        """[B, 3, s, s] -> tower tokens [B, N, C] ('.'-fusion: channel concat of the towers' tokens, llava_arch.py:278-285)."""
-        f = [t(px if t.dtype == px.dtype or not hasattr(t, "up_ft_index") else px.to(t.dtype)) for t in self.towers]   # diffusion towers: bf16 in
-        return f[0] if len(f) == 1 else torch.cat(f, dim=-1)
+        """A leg: [B, 3, s, s] -> tower tokens [B, N, C] ('.'-fusion: channel concat of the towers' tokens, llava_arch.py:278-285)."""
+        return self._run(self.towers, px)
+
+    @torch.no_grad()
+    def c_tokens(self, px: torch.Tensor) -> torch.Tensor:
+        """C leg: the same towers in the dtype C_score/extract_feature.py runs them in (pck_train_two: per-encoder maps, concatenated)."""
+        return self._run(self.c_towers, px)
 
     @torch.no_grad()
     def project(self, tok: torch.Tensor) -> torch.Tensor:
@@ -299,8 +336,9 @@ def c_launch_plan(spair: Sequence[SpairCategory], batch: int, world: int) -> Lis
     return plan_launches((n_items + world - 1) // world, batch)
 
 
-def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int):
-    """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set, every feature resident in HBM.
+def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int, tokens: Optional[Callable] = None):
+    """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set, every feature resident in HBM.  tokens: the tower pass
+    ([B, 3, s, s] -> [B, N, C]); default = the model's C-leg engines (`c_tokens`, else `tokens`).
     1. ONE image-sharded tower pass over all categories' distinct images (global item g = (category, image) on rank g mod world) in
        `c_launch_plan` launches; 2. each launch's maps are all-gathered (async: the gather of launch j runs under launch j + 1) and the
        rows of the categories this rank owns land in its banks; 3. the owner evaluates its categories with _compute_pck(local=True);
@@ -309,6 +347,7 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
     from .C_score import pck_train as PT
     from .C_score.utils.logger import log_weighted_pcks, update_stats
     aggre = PT.DummyAggregationNetwork()
+    tokens = tokens or getattr(model, "c_tokens", None) or model.tokens
     d = _dist() if world > 1 else None
     items = [(ci, i) for ci, cat in enumerate(spair) for i in range(cat.n_images)]
     n_items = len(items)
@@ -343,7 +382,7 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
 
     for sz in plan:
         chunk = mine[off:off + sz]
-        tok = model.tokens(pixels([ci * 100000 + i for ci, i in chunk], model.setting.size)).contiguous()
+        tok = tokens(pixels([ci * 100000 + i for ci, i in chunk], model.setting.size)).contiguous()
         if inflight is not None:
             inflight()
         if d is None:
@@ -388,9 +427,14 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
 # ------------------------------------------------------------------------------------------------ the sweep
 def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spair: Optional[Sequence[SpairCategory]] = None,
               device="cuda", build: Optional[Callable[[Setting], object]] = None, pixels: Optional[Callable] = None, a_hooks=None,
-              hidden: int = 4096, precision: str = "bf16", do_a: bool = True, do_c: bool = True, verbose: bool = False) -> dict:
+              hidden: int = 4096, precision: str = "reference", do_a: bool = True, do_c: bool = True, verbose: bool = False,
+              also_bf16: bool = False) -> dict:
     """Runs the sweep on this process' share (one process per GPU; world size from torch.distributed).  Returns
-    {"wall_s", "setup_s", "per_setting": {name: {"a_s", "c_s", "A", "pck": [..3], "images"}}, "images", "img_s_per_gpu", ...}.
+    {"wall_s", "setup_s", "per_setting": {name: {"a_s", "c_s", "A", "pck": [..3], "images", "dtype": {"a", "c"}}}, "images", ...}.
+    precision: see SettingModel ('reference' = A leg bf16, C leg in the dtype the reference's C path uses per tower).
+    also_bf16 ('reference' only): the settings whose C leg is fp32 run their C leg a second time on the bf16 engines, timed the same way
+    ("c_s_bf16", "pck_bf16"), and "wall_s_all_bf16" is the wall-clock of the sweep with those legs swapped in - the all-bf16 sweep's
+    number without running the eleven other legs twice (they are the same launches in both modes).
     build / pixels / a_hooks: injection points for the CPU tests (stand-in towers; the oracle as the score kernels)."""
     d = _dist()
     rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
@@ -401,19 +445,21 @@ def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spa
     old_level = clog.level
     clog.setLevel(logging.WARNING)                                       # 18 per-category lines x 13 settings are not a bench output
     try:
-        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world)
+        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16)
     finally:
         clog.setLevel(old_level)
 
 
-def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world):
+def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16=False):
     build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision))
-    pixels = pixels or (lambda ids, size: synthetic_pixels(ids, size, dev, torch.float32 if precision == "fp32" else torch.bfloat16))
+    # fp32 pixels wherever an fp32 engine may consume them (every tower is fed its own dtype: SettingModel._run); the bf16 cast of the same
+    # draw is what the all-bf16 mode generates directly, so the three modes see the same images
+    pixels = pixels or (lambda ids, size: synthetic_pixels(ids, size, dev, torch.bfloat16 if precision == "bf16" else torch.float32))
     if spair is None and do_c:
         spair = synthetic_spair()
     per, refs, pending = {}, {}, []
     _, scales_fn = a_hooks or (_a_hooks() if do_a else (None, None))
-    wall = setup = 0.0
+    wall = setup = wall_swap = 0.0
     n_c_images = sum(c.n_images for c in spair) if do_c else 0
     my_a = list(range(rank, n_a_images, world))
     for st in settings:
@@ -447,6 +493,17 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
             ent["c_s"] = round(time.perf_counter() - t0, 4)
             ent["pck"] = [float(x) for x in pck]
             wall += time.perf_counter() - t0
+            dts = getattr(model, "dtypes", None)
+            if also_bf16 and precision == "reference" and dts and dts["c"] != dts["a"]:
+                _fence(dev)
+                t1 = time.perf_counter()
+                pck_b = c_score_of(model, spair, pixels, dev, rank, world, tokens=model.tokens)    # the A leg's (bf16) engines on the C images
+                _fence(dev)
+                ent["c_s_bf16"] = round(time.perf_counter() - t1, 4)
+                ent["pck_bf16"] = [float(x) for x in pck_b]
+                wall_swap += (time.perf_counter() - t1) - (t1 - t0)
+        if getattr(model, "dtypes", None):
+            ent["dtype"] = dict(model.dtypes)
         ent["images"] = (n_a_images if do_a else 0) + n_c_images
         per.setdefault(st.name, {}).update(ent)
         if verbose and rank == 0:
@@ -457,7 +514,8 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
     if pending:
         raise ValueError("the A score needs the clip336 and clip224 settings in the sweep (A_score/compute.py:31-35)")
     images = sum(v["images"] for v in per.values())
-    return {"wall_s": round(wall, 3), "setup_s": round(setup, 3), "world": world, "settings": len(per), "images": images,
+    extra = {"wall_s_all_bf16": round(wall + wall_swap, 3)} if also_bf16 and precision == "reference" and do_c else {}
+    return {"wall_s": round(wall, 3), **extra, "setup_s": round(setup, 3), "world": world, "settings": len(per), "images": images,
             "img_s": round(images / wall, 2) if wall else None, "img_s_per_gpu": round(images / wall / world, 2) if wall else None,
             "a_images_per_setting": n_a_images if do_a else 0, "c_images_per_setting": n_c_images,
             "c_pairs_per_setting": sum(len(c.thresholds) for c in spair) if do_c else 0, "tower_precision": precision,
@@ -466,7 +524,7 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
 
 # ------------------------------------------------------------------------------------------------ encoder-sharded A score (configs[2])
 def a_scores_encoder_sharded(settings: Sequence[Setting], n_images: int, device="cuda", build=None, pixels=None, a_hooks=None, chunk: int = 32,
-                             hidden: int = 4096, precision: str = "bf16") -> Dict[str, float]:
+                             hidden: int = 4096, precision: str = "bf16") -> Dict[str, float]:     # the A leg is bf16 in 'reference' too
     """BASELINE.json configs[2]: "A_score ... encoder-sharded".  The two CLIP reference stacks are needed by every encoder, so they
     are produced image-sharded (every rank runs CLIP336 / CLIP224 on images i = rank mod world) and ALL-GATHERED in chunks of `chunk`
     images per rank: the gather of chunk k is issued asynchronously (it runs on the collective's own stream) and chunk k + 1's tower
@@ -538,7 +596,9 @@ def main(argv=None):
     ap.add_argument("--c-images", type=int, default=1800)
     ap.add_argument("--c-pairs", type=int, default=12234)
     ap.add_argument("--settings", nargs="*", default=None, help="subset of setting names (default: all 13)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"], help="ViT tower precision (fp32 = the reference's C-path dtype)")
+    ap.add_argument("--precision", default="reference", choices=["reference", "bf16", "fp32"],
+                    help="reference = A leg bf16, C leg in the reference's per-tower dtype (fp32 for CLIP / OpenCLIP / DINOv2); bf16 / fp32 = both legs")
+    ap.add_argument("--also-bf16", action="store_true", help="reference mode: time the fp32 C legs on the bf16 engines too (wall_s_all_bf16)")
     ap.add_argument("--mode", default="image", choices=["image", "encoder"], help="image-sharded sweep, or the encoder-sharded A score only")
     a = ap.parse_args(argv)
     from . import dist_env
@@ -547,9 +607,9 @@ def main(argv=None):
         sel = [s for s in SETTINGS if a.settings is None or s.name in a.settings]
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         if a.mode == "encoder":
-            out = a_scores_encoder_sharded(sel, a.a_images, dev, precision=a.precision)
+            out = a_scores_encoder_sharded(sel, a.a_images, dev, precision="fp32" if a.precision == "fp32" else "bf16")
         else:
-            out = run_sweep(sel, a.a_images, synthetic_spair(a.c_images, a.c_pairs), dev, precision=a.precision, verbose=True)
+            out = run_sweep(sel, a.a_images, synthetic_spair(a.c_images, a.c_pairs), dev, precision=a.precision, verbose=True, also_bf16=a.also_bf16)
         if not _dist() or _dist().get_rank() == 0:
             print(json.dumps(out), flush=True)
         return out

@@ -190,3 +190,58 @@ def test_settings_table_is_the_papers():
     assert {"clip336", "clip224", "dino", "dit", "imsd", "openclip", "sd1.5", "sd2.1", "sd3", "sdxl"} <= {s.key for s in S.SETTINGS}
     sp = S.synthetic_spair()
     assert len(sp) == 18 and sum(len(c.thresholds) for c in sp) == 12234 and sum(c.n_images for c in sp) == 1800
+
+
+class TwoLegModel(FakeModel):
+    """A stand-in with the reference mode's two engine sets: the C leg sees `c_tokens` (here: the A-leg tokens, perturbed), `dtypes` says
+    the legs differ."""
+
+    def __init__(self, st):
+        super().__init__(st)
+        self.dtypes = {"a": "bf16", "c": "fp32"} if st.name != "DINOv2" else {"a": "bf16", "c": "bf16"}
+        self.calls = {"a": 0, "c": 0}
+
+    def tokens(self, px):
+        self.calls["a"] += 1
+        return super().tokens(px)
+
+    def c_tokens(self, px):
+        self.calls["c"] += 1
+        return super().tokens(px) * 1.0 + (0.25 if self.dtypes["c"] == "fp32" else 0.0)
+
+
+def test_reference_mode_runs_the_c_leg_on_its_own_engines_and_times_the_bf16_twin(cpu_ops):
+    """precision='reference': the C leg goes through the model's C-leg engines (c_tokens), the A leg through tokens; with also_bf16 the
+    settings whose legs differ run the C leg once more on the A-leg engines ("c_s_bf16", "pck_bf16") and the all-bf16 wall-clock is the
+    reference wall-clock with those legs swapped."""
+    models = {}
+
+    def build(st):
+        models[st.name] = TwoLegModel(st)
+        return models[st.name]
+    out = S.run_sweep(SETTINGS, n_a_images=7, spair=spair_small(), device="cpu", build=build, pixels=fake_pixels, a_hooks=HOOKS, precision="reference",
+                      also_bf16=True)
+    plain = run()
+    assert out["tower_precision"] == "reference" and "wall_s_all_bf16" in out
+    for st in SETTINGS:
+        ent, m = out["per_setting"][st.name], models[st.name]
+        assert ent["dtype"] == m.dtypes
+        assert abs(ent["A"] - plain["per_setting"][st.name]["A"]) < 1e-12                   # the A leg never sees the C-leg engines
+        if m.dtypes["c"] != m.dtypes["a"]:
+            assert m.calls["c"] > 0 and "c_s_bf16" in ent
+            np.testing.assert_allclose(ent["pck_bf16"], plain["per_setting"][st.name]["pck"], atol=1e-12)      # the twin = the A-leg engines
+        else:
+            assert "c_s_bf16" not in ent
+            np.testing.assert_allclose(ent["pck"], plain["per_setting"][st.name]["pck"], atol=1e-12)
+    swap = sum(e["c_s_bf16"] - e["c_s"] for e in out["per_setting"].values() if "c_s_bf16" in e)
+    assert abs(out["wall_s_all_bf16"] - (out["wall_s"] + swap)) < 0.05
+    with pytest.raises(ValueError, match="precision"):
+        S.SettingModel(SETTINGS[0], "cpu", precision="fp16")
+
+
+def test_reference_dtypes_follow_the_reference_scripts():
+    """C_score/extract_feature.py:36-50,80-91: CLIP / OpenCLIP / DINOv2 are built without a dtype cast (fp32), SigLIP and the diffusion
+    towers in bf16; the A path is LLaVA's model.to(bfloat16)."""
+    want = {S.CLIP336: "fp32", S.CLIP224: "fp32", S.OPENCLIP: "fp32", S.DINOV2: "fp32", S.SIGLIP: "bf16", S.SD15: "bf16", S.SD21: "bf16",
+            S.SDXL: "bf16", S.IMSD: "bf16", S.DIT: "bf16", S.SD3: "bf16"}
+    assert {t: S.reference_c_precision(t) for t in want} == want
