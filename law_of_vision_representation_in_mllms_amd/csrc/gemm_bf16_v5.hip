@@ -65,6 +65,15 @@
 #ifndef V5_OWN
 #define V5_OWN OWN_
 #endif
+// 1: group 0 meets the tile's last barrier BEFORE its epilogue instead of after it.  Both groups finish an output tile together (one barrier
+//    interval apart), and with the barrier behind group 0's epilogue the two epilogues ran one after the other with the matrix pipe idle under
+//    both: group 1 sat in that barrier (its M1 of the last K-tile waiting) for all of group 0's epilogue, then group 0 sat in the next one for
+//    all of group 1's.  The epilogue touches no LDS and follows the group's counted wait, so nothing the barrier orders depends on it: with the
+//    barrier in front, group 1's last 32 MFMAs and then its own epilogue run beside group 0's epilogue (two waves per SIMD in VALU / store
+//    work instead of one), and the pipe idles for about one epilogue per tile instead of two (profiles/round4_gemm.md).
+#ifndef V5_EPI_EARLY
+#define V5_EPI_EARLY 1
+#endif
 
 namespace {
 
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 kt = 0;
                 int m0, n0; tw.decode(ti, m0, n0); ++ti;
                 const int mb = m0 + grp * 128, nb = n0 + wn * 64;
+                if (V5_EPI_EARLY && G == 0) barrier();          // this iteration's closing barrier, taken before the epilogue (see V5_EPI_EARLY)
                 if constexpr (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, hi);
                 else if constexpr (EPI == EPI_F32X) gemm_epilogue_f32x<8, 4>(p, acc, mb, nb, fr, hi);
                 else gemm_epilogue_rowmajor<EPI, 8, 4, true>(p, acc, mb, nb, fr, hi);
@@ -273,8 +283,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(V5_EPI_EARLY && G == 0)) barrier();
+            } else {
+                barrier();
             }
-            barrier();
         }
         if (G == 0) barrier();                                 // group 1 executed one extra barrier up front
     };
