@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void ascore_maxcos_pp(const AScoreArgs p) {
     a_wait_vm<INFL>();
     a_barrier();
     const unsigned lds0 = a_lds_addr(smem);
-    auto body = [&](auto G_) {
+    auto body = [&](auto G_) __attribute__((always_inline)) {
         constexpr int G = decltype(G_)::value;
         f32x4 acc[MI][NJ];
 #pragma unroll

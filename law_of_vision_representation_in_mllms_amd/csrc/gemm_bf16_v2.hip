@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
     barrier();                                                 // tile 0 visible to every wave
 
     const unsigned lds0 = lds_addr(smem);
-    auto body = [&](auto G_) {
+    auto body = [&](auto G_) __attribute__((always_inline)) {
         constexpr int G = decltype(G_)::value;
         f32x4 acc[8][4];
 #pragma unroll

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     barrier();
 
     const unsigned lds0 = lds_addr(smem);
-    auto body = [&](auto G_) {
+    auto body = [&](auto G_) __attribute__((always_inline)) {
         constexpr int G = decltype(G_)::value;
         f32x4 acc[8][4];
 #pragma unroll

@@ -17,6 +17,9 @@
 //     LDS-DMA prefetch ring each iteration (verified in the ISA).  Stores the compiler cannot see leave nothing
 //     pending; the hardware still retires them in order with the counted waits of the main loop.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "visrep_internal.h"
 
@@ -30,7 +33,36 @@ VR_DEV void store_b128(void* ptr, f32x4 v) { asm volatile("" ::"v"(ptr), "v"(v))
 #else
 VR_DEV void store_b128(void* ptr, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
 #endif
+// The same stores with a compile-time BYTE offset in the instruction's 13-bit immediate: a row's stores share one 64-bit base address
+// computed once per row instead of one v_mad_i64 + v_lshl_add_u64 chain per store (round 4: the address arithmetic was 20-35 % of the VALU
+// work of the K = 1024 epilogues, profiles/round4_gemm.md).
+#ifdef VISREP_EPI_NO_STORE
+template <int OFF> VR_DEV void store_b64_at(const void* base, u32x2 v) { asm volatile("" ::"v"(base), "v"(v)); }
+template <int OFF> VR_DEV void store_b128_at(const void* base, f32x4 v) { asm volatile("" ::"v"(base), "v"(v)); }
+#else
+template <int OFF> VR_DEV void store_b64_at(const void* base, u32x2 v) {
+    static_assert(OFF >= -4096 && OFF < 4096, "global_store immediate offset range");
+    asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(base), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> VR_DEV void store_b128_at(const void* base, f32x4 v) {
+    static_assert(OFF >= -4096 && OFF < 4096, "global_store immediate offset range");
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(base), "v"(v), "n"(OFF) : "memory");
+}
+#endif
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) - the index is usable as a template argument.
+// The lambdas passed here carry __attribute__((always_inline)): a loop body the inliner leaves out of line takes the accumulators by
+// reference, i.e. through scratch memory (seen: 720 bytes of scratch per lane in the EPI_ACT kernels)
+template <typename F, int... Is> VR_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> VR_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 VR_DEV void drain_visible_loads() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+// An UNCONDITIONAL consumer of a compiler-visible load's result.  hipcc waits for a load where its result is first read; when every reader
+// sits in a conditional region (rows past M: `if (ok) store`, with the arithmetic sunk into the region), the path around the region leaves
+// the load pending as far as the wait-count pass knows, the persistent kernel's K-loop header inherits "a VMEM op may be pending" and gets
+// an s_waitcnt vmcnt(0) in front of every K-tile - which drains the LDS-DMA ring each iteration.  Found in the ISA of the EPI_F32X kernels
+// (all along) and of the round-4 EPI_RESID epilogue: -3 % on fc2 / out-proj until the residual registers were retired this way.
+VR_DEV void retire_load(u32x2 v) { asm volatile("" ::"v"(v)); }
+VR_DEV void retire_load(u32x4 v) { asm volatile("" ::"v"(v)); }
+VR_DEV void retire_load(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 
 // sum of v over the lanes that differ from this one in lane bits 4 (RBLK == 16 only) and 5: the lanes that hold the other column
 // groups of the same accumulator row.  gfx950 lane-swap VALU ops: no LDS traffic, nothing for the waitcnt pass to see.
@@ -50,13 +82,32 @@ template <typename ACC> struct AccGeom { static constexpr int QN = sizeof(ACC) /
 // HAS_ST (EPI_RESID): also emit, per output row and per wave tile (NJ * RBLK columns = one "slot"), the sum and the sum of squares
 // of the bf16-ROUNDED outputs -> p.stat_partial[m * p.stat_slots + slot]; ln_stats_finalize turns the slots of a row into the
 // (rstd, -mean * rstd) the next LayerNorm-folded GEMM wants, so that LayerNorm never reads the residual stream again.
-template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, bool RW, typename ACC>
+// AL (decided once per launch by the caller: ldc % 8 == 0, 16-byte aligned C and residual): 16-byte stores and residual loads - see WIDE / RWIDE.
+// Addresses: one 64-bit base per output row (this lane's first column), every store / residual load of the row at a COMPILE-TIME byte
+// offset from it (the store instructions' immediate field; the column loops are static_for so that the offsets are template arguments).
+template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, bool AL, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK, NC = NJ * QN;   // NC column groups of 4 per lane
+    // Output stores.  16x16 accumulators: the four lanes hg = 0..3 of a row hold 4 consecutive columns each of every 16-column block j, i.e.
+    // 8-byte stores, 32 contiguous bytes per row and instruction.  The K = 1024 GEMMs spend 15-22 % of their time in this store stream
+    // (profiles/round2_store_stream.md), which is issue-bound, not bandwidth-bound.  WIDE: one v_permlane16_swap per word between the lanes
+    // hg and hg ^ 1 regroups a PAIR of column blocks (j, j + 1): even lanes end up with 8 consecutive columns of block j, odd lanes with 8 of
+    // block j + 1 -> one 16-byte store per pair instead of two 8-byte ones (64 contiguous bytes per row and instruction), same bytes, same
+    // addresses.  RWIDE: residual rows are fetched the same way - one 16-byte load per PAIR of column blocks from the address this lane will
+    // store to, then the same swap (an involution) hands each lane its own 4 + 4 columns: half the load instructions.
+    constexpr bool WIDE = AL && QN == 1 && (NC % 2) == 0 && EPI != EPI_F32;
+    constexpr bool RWIDE = WIDE && EPI == EPI_RESID;
+    constexpr int ES = EPI == EPI_F32 ? 4 : 2;               // bytes per output element
+    constexpr int CSTEP = WIDE ? 2 : 1;
     float4 bv[NC], lv[(HAS_LS || HAS_LN) ? NC : 1];           // lv: LayerScale gamma, or the LN column sums s[n]
 #pragma unroll
     for (int c = 0; c < NC; ++c) bv[c] = float4{0.f, 0.f, 0.f, 0.f};
-    auto col = [&](int c) { return nb + (c / QN) * RBLK + (c % QN) * 8 + hg * 4; };
+    auto coff = [](int c) { return (c / QN) * RBLK + (c % QN) * 8; };   // column of group c relative to the lane's first column
+    const int lane_col = nb + hg * 4;                        // this lane's first column (group 0)
+    // WIDE: first column of this lane's 8-column chunk of the pair (c0, c0 + 1) is wide_col + 16 c0: even lanes block c0's columns 8 (hg / 2) ..,
+    // odd lanes block c0 + 1's (col(c0 + 1) - 4 = lane_col + 16 c0 + 12)
+    const int wide_col = lane_col + ((hg & 1) ? 12 : 0);
+    auto col = [&](int c) { return lane_col + coff(c); };
     if (p.bias) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const float4*>(p.bias + col(c));
@@ -81,21 +132,19 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
     constexpr int INFLIGHT = (HAS_LS || QN > 1) ? 8 : 16;   // residual loads in flight per lane (register budget)
     constexpr int RB0 = (INFLIGHT / NC) < 1 ? 1 : ((INFLIGHT / NC) > NI ? NI : (INFLIGHT / NC));
     constexpr int RB = EPI == EPI_PATCH ? 1 : RB0;          // position rows are float4: one row at a time
-#pragma unroll
-    for (int i0 = 0; i0 < NI; i0 += RB) {
+    // (static_for, not `#pragma unroll`: every index into acc / rv / rq is a compile-time constant whatever the unroller decides - an
+    // accumulator array that is indexed dynamically lives in scratch memory)
+    static_assert(NI % RB == 0, "row groups must tile the accumulator rows");
+    static_for<NI / RB>([&](auto I0) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(I0)::value * RB;
         bool ok[RB];
         size_t orow[RB];
+        char* crow[RB];                                       // byte address of (output row, this lane's first column [of its wide chunk])
         u32x2 rv[RB][NC];
         float4 pv[RB][NC];
-        // RWIDE: residual rows are fetched the way the outputs are stored (see WIDE below) - one 16-byte load per PAIR of column blocks from
-        // the address this lane will store to, then the same v_permlane16_swap (an involution) hands each lane its own 4 + 4 columns: half the
-        // load instructions, 64 contiguous bytes per row and instruction instead of 32.
-        // RW is decided once per launch by the caller (ldc % 8 == 0 and a 16-byte aligned residual pointer).
-        constexpr bool RWIDE = RW && EPI == EPI_RESID && QN == 1 && (NC % 2) == 0;
-        constexpr bool rwide = RWIDE;
         u32x4 rq[RB][RWIDE ? NC / 2 : 1];
-#pragma unroll
-        for (int ii = 0; ii < RB; ++ii) {
+        static_for<RB>([&](auto II) __attribute__((always_inline)) {
+            constexpr int ii = decltype(II)::value;
             const int m = mb + (i0 + ii) * RBLK + fr;
             ok[ii] = EDGE ? (m < p.M) : true;               // interior tiles: no exec-masked region at all
             const int mc = ok[ii] ? m : p.M - 1;
@@ -104,55 +153,61 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
             if (EPI == EPI_PATCH) {   // m = b*P + pidx  ->  token row b*T + cls_off + pidx ; add pos[cls_off + pidx]
                 const int b = mc / p.patches, pi = mc - b * p.patches;
                 orow[ii] = (size_t)b * p.tokens + p.cls_off + pi;
-                posrow = p.pos + (size_t)(p.cls_off + pi) * p.N;
+                posrow = p.pos + (size_t)(p.cls_off + pi) * p.N + lane_col;
             }
+            crow[ii] = reinterpret_cast<char*>(p.C) + (orow[ii] * p.ldc + (WIDE ? wide_col : lane_col)) * ES;
             if (EPI == EPI_RESID) {
-                if (RWIDE && rwide) {
+                const bf16_t* rrow = p.resid + orow[ii] * p.ldc + (RWIDE ? wide_col : lane_col);
+                if (RWIDE) {
 #pragma unroll
-                    for (int c0 = 0; c0 < NC; c0 += 2)
-                        rq[ii][c0 / 2] = *reinterpret_cast<const u32x4*>(p.resid + orow[ii] * p.ldc + ((hg & 1) ? col(c0 + 1) - 4 : col(c0)));
+                    for (int c0 = 0; c0 < NC; c0 += 2) rq[ii][c0 / 2] = *reinterpret_cast<const u32x4*>(rrow + 16 * c0);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) rv[ii][c] = *reinterpret_cast<const u32x2*>(p.resid + orow[ii] * p.ldc + col(c));
+                    for (int c = 0; c < NC; ++c) rv[ii][c] = *reinterpret_cast<const u32x2*>(rrow + coff(c));
                 }
             }
             if (EPI == EPI_PATCH) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) pv[ii][c] = *reinterpret_cast<const float4*>(posrow + col(c));
+                for (int c = 0; c < NC; ++c) pv[ii][c] = *reinterpret_cast<const float4*>(posrow + coff(c));
             }
-        }
+        });
+        static_for<RB>([&](auto II) __attribute__((always_inline)) {       // every row group's loads are consumed on EVERY path (see retire_load)
+            constexpr int ii = decltype(II)::value;
+            if (EPI == EPI_RESID) {
+                if (RWIDE) {
 #pragma unroll
-        for (int ii = 0; ii < RB; ++ii) {
-            const int i = i0 + ii;
+                    for (int k = 0; k < (RWIDE ? NC / 2 : 1); ++k) retire_load(rq[ii][k]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) retire_load(rv[ii][c]);
+                }
+            }
+            if (EPI == EPI_PATCH) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) retire_load(pv[ii][c]);
+            }
+        });
+        static_for<RB>([&](auto II) __attribute__((always_inline)) {
+            constexpr int ii = decltype(II)::value, i = i0 + ii;
             float st1 = 0.f, st2 = 0.f;
-            // Output stores.  16x16 accumulators: the four lanes fg = 0..3 of a row hold 4 consecutive columns each of every 16-column block
-            // j, i.e. 8-byte stores, 32 contiguous bytes per row and instruction.  The K = 1024 GEMMs spend 15-22 % of their time in this
-            // store stream (profiles/round2_store_stream.md: the same kernels without their stores), which is issue-bound, not
-            // bandwidth-bound.  WIDE: one v_permlane16_swap per word between the lanes fg and fg ^ 1 regroups a PAIR of column blocks
-            // (j, j + 1): even lanes end up with 8 consecutive columns of block j, odd lanes with 8 of block j + 1 -> one 16-byte store
-            // per pair instead of two 8-byte ones (64 contiguous bytes per row and instruction), same bytes, same addresses.
-            constexpr bool WIDE = QN == 1 && (NC % 2) == 0 && EPI != EPI_F32;
-            const bool wide = WIDE && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;     // uniform
-#pragma unroll
-            for (int c0 = 0; c0 < NC; c0 += (WIDE ? 2 : 1)) {
-                u32x2 o2[WIDE ? 2 : 1];
-                if (RWIDE && rwide) {                         // even lanes loaded (own j, partner's j), odd lanes (partner's j + 1, own j + 1)
-                    const u32x4 q4 = rq[ii][c0 / 2];
+            static_for<NC / CSTEP>([&](auto C0) __attribute__((always_inline)) {
+                constexpr int c0 = decltype(C0)::value * CSTEP;
+                u32x2 o2[CSTEP];
+                if (RWIDE) {                                  // even lanes loaded (own j, partner's j), odd lanes (partner's j + 1, own j + 1)
+                    const u32x4 q4 = rq[ii][RWIDE ? c0 / 2 : 0];
                     const auto s0 = __builtin_amdgcn_permlane16_swap(q4[0], q4[2], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(q4[1], q4[3], false, false);
                     rv[ii][c0] = u32x2{(unsigned)s0[0], (unsigned)s1[0]};
                     rv[ii][c0 + (RWIDE ? 1 : 0)] = u32x2{(unsigned)s0[1], (unsigned)s1[1]};
                 }
-#pragma unroll
-                for (int cc = 0; cc < (WIDE ? 2 : 1); ++cc) {
-                    const int c = c0 + cc;
-                    const int j = c / QN, q = c % QN, n = col(c);
+                static_for<CSTEP>([&](auto CC) __attribute__((always_inline)) {
+                    constexpr int cc = decltype(CC)::value, c = c0 + cc, j = c / QN, q = c % QN;
                     float v0, v1, v2, v3;
                     if (HAS_LN) {       // rstd * (acc - mean * s) + bias'
-                        v0 = __builtin_fmaf(acc[i][j][4 * q + 0], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].x, bv[c].x));
-                        v1 = __builtin_fmaf(acc[i][j][4 * q + 1], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].y, bv[c].y));
-                        v2 = __builtin_fmaf(acc[i][j][4 * q + 2], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].z, bv[c].z));
-                        v3 = __builtin_fmaf(acc[i][j][4 * q + 3], rt_all[i].x, __builtin_fmaf(rt_all[i].y, lv[c].w, bv[c].w));
+                        v0 = __builtin_fmaf(acc[i][j][4 * q + 0], rt_all[HAS_LN ? i : 0].x, __builtin_fmaf(rt_all[HAS_LN ? i : 0].y, lv[HAS_LN ? c : 0].x, bv[c].x));
+                        v1 = __builtin_fmaf(acc[i][j][4 * q + 1], rt_all[HAS_LN ? i : 0].x, __builtin_fmaf(rt_all[HAS_LN ? i : 0].y, lv[HAS_LN ? c : 0].y, bv[c].y));
+                        v2 = __builtin_fmaf(acc[i][j][4 * q + 2], rt_all[HAS_LN ? i : 0].x, __builtin_fmaf(rt_all[HAS_LN ? i : 0].y, lv[HAS_LN ? c : 0].z, bv[c].z));
+                        v3 = __builtin_fmaf(acc[i][j][4 * q + 3], rt_all[HAS_LN ? i : 0].x, __builtin_fmaf(rt_all[HAS_LN ? i : 0].y, lv[HAS_LN ? c : 0].w, bv[c].w));
                     } else {
                         v0 = acc[i][j][4 * q + 0] + bv[c].x; v1 = acc[i][j][4 * q + 1] + bv[c].y;
                         v2 = acc[i][j][4 * q + 2] + bv[c].z; v3 = acc[i][j][4 * q + 3] + bv[c].w;
@@ -161,12 +216,12 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
                         v0 = apply_act(v0, ACT); v1 = apply_act(v1, ACT); v2 = apply_act(v2, ACT); v3 = apply_act(v3, ACT);
                     }
                     if (EPI == EPI_RESID) {
-                        if (HAS_LS) { v0 *= lv[c].x; v1 *= lv[c].y; v2 *= lv[c].z; v3 *= lv[c].w; }
+                        if (HAS_LS) { v0 *= lv[HAS_LS ? c : 0].x; v1 *= lv[HAS_LS ? c : 0].y; v2 *= lv[HAS_LS ? c : 0].z; v3 *= lv[HAS_LS ? c : 0].w; }
                         v0 += bf_lo(rv[ii][c][0]); v1 += bf_hi(rv[ii][c][0]); v2 += bf_lo(rv[ii][c][1]); v3 += bf_hi(rv[ii][c][1]);
                     }
                     if (EPI == EPI_PATCH) { v0 += pv[ii][c].x; v1 += pv[ii][c].y; v2 += pv[ii][c].z; v3 += pv[ii][c].w; }
                     if (EPI == EPI_F32) {
-                        if (ok[ii]) store_b128(reinterpret_cast<float*>(p.C) + orow[ii] * p.ldc + n, f32x4{v0, v1, v2, v3});
+                        if (ok[ii]) store_b128_at<((c / QN) * RBLK + (c % QN) * 8) * 4>(crow[ii], f32x4{v0, v1, v2, v3});
                     } else {
                         o2[cc] = u32x2{pack_bf16(v0, v1), pack_bf16(v2, v3)};
                         if (HAS_ST && ok[ii]) {
@@ -174,25 +229,20 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
                             st1 += (r0 + r1) + (r2 + r3);
                             st2 = __builtin_fmaf(r0, r0, __builtin_fmaf(r1, r1, __builtin_fmaf(r2, r2, __builtin_fmaf(r3, r3, st2))));
                         }
+                        if (!WIDE && ok[ii]) store_b64_at<((c / QN) * RBLK + (c % QN) * 8) * 2>(crow[ii], o2[cc]);
+                    }
+                });
+                if (WIDE) {
+                    // swap(vdst = block j word, src = block j + 1 word): odd 16-lane rows of vdst <-> even rows of src.  Even lanes:
+                    // (own j, partner's j); odd lanes: (partner's j + 1, own j + 1) - ascending columns in both cases.
+                    const auto w0 = __builtin_amdgcn_permlane16_swap(o2[0][0], o2[CSTEP - 1][0], false, false);
+                    const auto w1 = __builtin_amdgcn_permlane16_swap(o2[0][1], o2[CSTEP - 1][1], false, false);
+                    if (ok[ii]) {
+                        const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
+                        store_b128_at<c0 * 16 * 2>(crow[ii], __builtin_bit_cast(f32x4, q4));
                     }
                 }
-                if (EPI != EPI_F32) {
-                    if (WIDE && wide) {
-                        // swap(vdst = block j word, src = block j + 1 word): odd 16-lane rows of vdst <-> even rows of src.  Even lanes:
-                        // (own j, partner's j); odd lanes: (partner's j + 1, own j + 1) - ascending columns in both cases.
-                        const auto w0 = __builtin_amdgcn_permlane16_swap(o2[0][0], o2[WIDE ? 1 : 0][0], false, false);
-                        const auto w1 = __builtin_amdgcn_permlane16_swap(o2[0][1], o2[WIDE ? 1 : 0][1], false, false);
-                        if (ok[ii]) {
-                            const int nn = (hg & 1) ? col(c0 + (WIDE ? 1 : 0)) - 4 : col(c0);
-                            const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
-                            store_b128(p.C + orow[ii] * p.ldc + nn, __builtin_bit_cast(f32x4, q4));
-                        }
-                    } else if (ok[ii]) {
-#pragma unroll
-                        for (int cc = 0; cc < (WIDE ? 2 : 1); ++cc) store_b64(p.C + orow[ii] * p.ldc + col(c0 + cc), o2[cc]);
-                    }
-                }
-            }
+            });
             if (HAS_ST) {                                     // all lanes take part in the lane swaps; one lane per row stores
                 st1 = sum_over_hg<RBLK>(st1);
                 st2 = sum_over_hg<RBLK>(st2);
@@ -201,8 +251,8 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
                     store_b64(p.stat_partial + orow[ii] * p.stat_slots + nb / (NJ * RBLK), o);
                 }
             }
-        }
-    }
+        });
+    });
 }
 
 template <int EPI, int NI, int NJ, int ACT, bool STATS, bool RW, typename ACC>
@@ -230,11 +280,12 @@ VR_DEV void gemm_epilogue_rowmajor_rw(const GemmArgs& p, const ACC (&acc)[NI][NJ
 
 template <int EPI, int NI, int NJ, int ACT, bool STATS, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
-    // wide residual loads (see RWIDE in the implementation): 16-byte aligned residual rows, 16x16 accumulators, an even number of column blocks
-    if (EPI == EPI_RESID && AccGeom<ACC>::QN == 1 && (NJ % 2) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0)
-        gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, EPI == EPI_RESID>(p, acc, mb, nb, fr, hg);
-    else
-        gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, false>(p, acc, mb, nb, fr, hg);
+    // AL: 16-byte stores (and residual loads) - rows of C (and of the residual) 16-byte aligned, 16x16 accumulators, an even number of column
+    // blocks.  One uniform decision per tile; everything below it is compiled once per value (no per-store branches).
+    const bool al = EPI != EPI_F32 && AccGeom<ACC>::QN == 1 && (NJ % 2) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+                    (EPI != EPI_RESID || (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0);
+    if (al) gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, EPI != EPI_F32>(p, acc, mb, nb, fr, hg);
+    else gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, false>(p, acc, mb, nb, fr, hg);
 }
 
 // STATS: only the kernel the dispatcher routes statistics-emitting residual GEMMs to (v2) compiles that epilogue
@@ -396,6 +447,10 @@ VR_DEV void gemm_epilogue_f32x_act(const GemmArgs& p, const f32x4 (&acc)[NI][NJ]
             if (R) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) rv[ii][j] = *reinterpret_cast<const float4*>(R + row[ii] * p.ldc + col(j));
+#ifndef VISREP_F32X_NO_RETIRE                                    // A/B knob (tools/): leaves the K-loop header wait in place
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) retire_load(rv[ii][j]);      // consumed on every path: rows past M skip everything below
+#endif
             }
         }
 #pragma unroll

@@ -302,7 +302,10 @@ def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf1
     raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
 
 
-DEFAULT_SPLIT_PRODUCTS = 6           # plane-pair products of the split-bf16 route (VitEngineF32 / gemm_f32_split); see VitEngineF32.__init__
+# Plane-pair products of the split-bf16 route (VitEngineF32; see its __init__).  3 = (hi,hi) (hi,mid) (mid,hi) over two-plane operands:
+# measured at full size (profiles/round4_precision.md) - CLIP-L/14-336 features 8.6e-6 rel-L2 of the fp32 oracle (six products: 2.5e-6, the
+# bf16 engine: 1.2e-2), A score 1e-7 relative, 0 of 2,400 PCK hits flipped, predictions within 0.001 px - at 1.8x the six-product tower's rate.
+DEFAULT_SPLIT_PRODUCTS = 3
 
 
 def split_planes(products: int) -> int:

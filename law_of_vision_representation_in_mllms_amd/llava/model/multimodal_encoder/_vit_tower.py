@@ -58,7 +58,9 @@ class _EngineModule(nn.Module):
 
 
 def _find_local_checkpoint(name: str) -> Optional[str]:
-    if os.path.isdir(name) and os.path.exists(os.path.join(name, "config.json")):
+    """A local checkpoint directory - transformers layout (config.json) or diffusers layout (model_index.json: unet/ vae/ ... below it) -
+    else the offline HF cache's snapshot of `name`, else None."""
+    if os.path.isdir(name) and any(os.path.exists(os.path.join(name, f)) for f in ("config.json", "model_index.json")):
         return name
     try:                                                     # offline HF cache
         from huggingface_hub import snapshot_download

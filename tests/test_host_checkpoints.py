@@ -164,7 +164,7 @@ def write_diffusers_dir(root, spec, text_spec, wu, wv, wt, fmt="safetensors"):
 def tiny_sd_checkpoint():
     from law_of_vision_representation_in_mllms_amd import sd_weights as SW
     spec = SW.tiny_sd_spec()
-    ts = SW.tiny_text_spec()
+    ts = SW.TextSpec(vocab=99, d=spec.unet.cross_dim, mlp=128, layers=2, heads=1, max_pos=11, act="quick_gelu")     # d = the UNet's cross-attention width
     return spec, ts, SW.synthetic_unet(spec.unet, 21, n_up_blocks=len(spec.unet.block_out)), SW.synthetic_vae(spec.vae, 22), SW.synthetic_text(ts, 23)
 
 
@@ -176,6 +176,7 @@ def test_diffusers_directory_gives_the_spec_and_the_weights(tmp_path, fmt):
     spec, ts, wu, wv, wt = tiny_sd_checkpoint()
     root = str(tmp_path / "tiny-sd")
     write_diffusers_dir(root, spec, ts, wu, wv, wt, fmt)
+    assert DS._find_local_checkpoint(root) == root                     # a diffusers directory has model_index.json, not config.json (found by this test: r4)
     got, got_text = DS.spec_from_checkpoint(spec.name, root)
     assert got.unet == spec.unet and got.vae == spec.vae and got.sched == spec.sched
     assert got_text == ts and got.text_len == ts.max_pos

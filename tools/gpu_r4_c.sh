@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4, call C: epilogue with retired loads vs the pre-rewrite library, split-route GEMMs after the K-loop header wait fix, the two new dropin tests
+O=gpurun_out/r4c; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+P=law_of_vision_representation_in_mllms_amd
+timeout 900 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_kernels.py tests/test_gpu_f32.py -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log
+for r in 1 2; do
+  for v in default oldepi; do
+    if [ $v = default ]; then unset VISREP_LIB; else export VISREP_LIB=$PWD/$P/libvisrep_hip_$v.so; fi
+    timeout 300 python bench.py --sweep off --no-cpu-baseline --no-scores --steps 10 --warmup 3 2>&1 | tail -1 > $O/bench_${v}_$r.json
+    python - <<PY
+import json
+d=json.load(open("$O/bench_${v}_$r.json"))
+print("$v $r", d["value"], d["ms_per_step"], {k.split()[0]: v["ms"] for k, v in d["roofline"]["kernels"].items()})
+PY
+  done
+done
+unset VISREP_LIB
+timeout 600 python tools/f32_probe.py 64 > $O/f32_probe.txt 2>&1; grep -v amdgpu.ids $O/f32_probe.txt | tail -24
