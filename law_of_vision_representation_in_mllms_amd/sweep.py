@@ -336,12 +336,28 @@ def c_launch_plan(spair: Sequence[SpairCategory], batch: int, world: int) -> Lis
     return plan_launches((n_items + world - 1) // world, batch)
 
 
+def c_exchange_plan(n_items: int, item_owner: Sequence[int], world: int, off: int, sz: int):
+    """Who sends which rows of one launch to whom.  Every rank holds the global items g = j * world + r at local position j (the last local
+    positions of a short rank are padding: a repeated image, sent nowhere); the launch covers local positions [off, off + sz) on every rank.
+    Returns send[r][q] = local positions (relative to the launch) that rank r sends to rank q, in increasing order - the same table on
+    every rank, so receivers know what arrives: rows from r land in the order of send[r][me].  A row goes to exactly ONE rank (the owner of
+    its category): 1 / world of an all-gather's bytes."""
+    send = [[[] for _ in range(world)] for _ in range(world)]
+    for r in range(world):
+        for j in range(off, off + sz):
+            g = j * world + r
+            if g < n_items:
+                send[r][item_owner[g]].append(j - off)
+    return send
+
+
 def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int, tokens: Optional[Callable] = None):
     """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set, every feature resident in HBM.  tokens: the tower pass
     ([B, 3, s, s] -> [B, N, C]); default = the model's C-leg engines (`c_tokens`, else `tokens`).
     1. ONE image-sharded tower pass over all categories' distinct images (global item g = (category, image) on rank g mod world) in
-       `c_launch_plan` launches; 2. each launch's maps are all-gathered (async: the gather of launch j runs under launch j + 1) and the
-       rows of the categories this rank owns land in its banks; 3. the owner evaluates its categories with _compute_pck(local=True);
+       `c_launch_plan` launches; 2. each launch's maps go to the rank that OWNS their category - an owner-addressed all_to_all_single (RCCL
+       all-to-all over xGMI: every row crosses the fabric once; the round-3 all-gather sent it to all `world` ranks), asynchronous: the
+       exchange of launch j runs under launch j + 1; 3. the owner evaluates its categories with _compute_pck(local=True);
     4. one all_gather_object of (pck, img_correct) per category; statistics are accumulated in category order on every rank, so the
        result does not depend on the world size."""
     from .C_score import pck_train as PT
@@ -356,42 +372,47 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
     mine = items[rank::world]
     mine = mine + [mine[-1] if mine else items[-1]] * (per - len(mine))      # equal shapes on every rank: a short rank repeats an image
     plan = c_launch_plan(spair, model.setting.batch, world)
-    # where a gathered row goes: global item -> (row of this rank's bank storage) or -1
+    # where a row lands: global item -> row of this rank's bank storage (the categories it owns, in category order)
     base, tot = {}, 0
     for ci, cat in enumerate(spair):
         if owner[ci] == rank:
             base[ci] = tot
             tot += cat.n_images
-    dest_of = torch.full((per * world,), -1, dtype=torch.long)
-    for g, (ci, i) in enumerate(items):
-        if ci in base:
-            dest_of[g] = base[ci] + i
+    item_owner = [owner[ci] for ci, _ in items]
+    dest_of = [base[ci] + i if ci in base else -1 for ci, i in items]
     store, inflight, off = None, None, 0
 
-    def land(rows, o, sz):
-        """rows [world, sz, N, C] of local rows [o, o + sz) of every rank -> this rank's bank storage"""
+    def alloc(like):
         nonlocal store
-        g = ((torch.arange(o, o + sz)[None, :] * world) + torch.arange(rows.shape[0])[:, None]).reshape(-1)    # global item of every row
-        dst = dest_of[g]
-        keep = (dst >= 0).nonzero().squeeze(1)
         if store is None:
-            store = torch.empty((max(tot, 1),) + tuple(rows.shape[2:]), dtype=torch.float32, device=rows.device)
-        if keep.numel():
-            flat = rows.reshape((-1,) + tuple(rows.shape[2:]))
-            store.index_copy_(0, dst[keep].to(rows.device), flat.index_select(0, keep.to(rows.device)).float())
+            store = torch.empty((max(tot, 1),) + tuple(like.shape[1:]), dtype=torch.float32, device=like.device)
 
     for sz in plan:
         chunk = mine[off:off + sz]
         tok = tokens(pixels([ci * 100000 + i for ci, i in chunk], model.setting.size)).contiguous()
+        alloc(tok)
         if inflight is not None:
             inflight()
+        send = c_exchange_plan(n_items, item_owner, world, off, sz)
+        # rows that arrive here from rank r, in order: r's local positions send[r][rank] -> global item -> bank row
+        dst = [dest_of[(off + j) * world + r] for r in range(world) for j in send[r][rank]]
         if d is None:
-            land(tok[None], off, sz)
+            if dst:
+                store.index_copy_(0, torch.tensor(dst, dtype=torch.long, device=tok.device), tok.index_select(0, torch.tensor(send[0][0], dtype=torch.long, device=tok.device)).float())
             inflight = None
         else:
-            parts = [torch.empty_like(tok) for _ in range(world)]
-            h = d.all_gather(parts, tok, async_op=True)
-            inflight = (lambda h=h, parts=parts, o=off, sz=sz: (h.wait(), land(torch.stack(parts, 0), o, sz)))
+            order = [j for q in range(world) for j in send[rank][q]]                      # my rows grouped by destination rank
+            sbuf = tok.index_select(0, torch.tensor(order, dtype=torch.long, device=tok.device)) if order else tok[:0]
+            in_splits = [len(send[rank][q]) for q in range(world)]
+            out_splits = [len(send[r][rank]) for r in range(world)]
+            rbuf = torch.empty((sum(out_splits),) + tuple(tok.shape[1:]), dtype=tok.dtype, device=tok.device)
+            h = d.all_to_all_single(rbuf, sbuf, out_splits, in_splits, async_op=True)
+
+            def finish(h=h, rbuf=rbuf, sbuf=sbuf, dst=dst):
+                h.wait()
+                if dst:
+                    store.index_copy_(0, torch.tensor(dst, dtype=torch.long, device=rbuf.device), rbuf.float())
+            inflight = finish
         off += sz
     if inflight is not None:
         inflight()

@@ -245,3 +245,29 @@ def test_reference_dtypes_follow_the_reference_scripts():
     want = {S.CLIP336: "fp32", S.CLIP224: "fp32", S.OPENCLIP: "fp32", S.DINOV2: "fp32", S.SIGLIP: "bf16", S.SD15: "bf16", S.SD21: "bf16",
             S.SDXL: "bf16", S.IMSD: "bf16", S.DIT: "bf16", S.SD3: "bf16"}
     assert {t: S.reference_c_precision(t) for t in want} == want
+
+
+def test_c_exchange_plan_sends_every_row_once_to_its_owner():
+    """the C leg all-gathered every launch's maps to every rank although only the category owner needs them.  The
+    owner-addressed plan: every real row leaves its producer exactly once, for the rank that owns its category; padding rows (a short
+    rank's repeated image) go nowhere; summed over a setting the fabric carries n_items rows instead of world * n_items."""
+    spair = S.synthetic_spair()
+    items = [(ci, i) for ci, cat in enumerate(spair) for i in range(cat.n_images)]
+    for world in (1, 2, 8):
+        owner = S.category_owners(spair, world)
+        item_owner = [owner[ci] for ci, _ in items]
+        plan = S.c_launch_plan(spair, 16, world)
+        seen, off, rows_on_fabric = set(), 0, 0
+        for sz in plan:
+            send = S.c_exchange_plan(len(items), item_owner, world, off, sz)
+            for r in range(world):
+                for q in range(world):
+                    assert send[r][q] == sorted(send[r][q])
+                    for j in send[r][q]:
+                        g = (off + j) * world + r
+                        assert 0 <= j < sz and g < len(items) and item_owner[g] == q and g not in seen
+                        seen.add(g)
+                        rows_on_fabric += int(q != r)
+            off += sz
+        assert seen == set(range(len(items)))                       # every image's maps reach their owner, once
+        assert rows_on_fabric <= len(items) and (world == 1) == (rows_on_fabric == 0)
