@@ -269,6 +269,14 @@ int visrep_ascore_maxcos_scaled(const void* other, const void* ref, const float*
 int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
                            const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window, int soft_eval,
                            float beta, float anno_stride, float anno_half, int layout, void* stream);
+/* The same transfer for position-major banks ([n_images, P*P, C]) with the key points of SEVERAL pairs packed into one 32-row MFMA tile:
+ * a group = pairs that share a target image, at most 32 key points in total (the caller packs them: one pair alone fills 11.5 of 32 rows
+ * on SPair-71k).  rows_tab int32 [n_groups, 32, 4] = (pair, key-point index, source image, source patch index) per tile row, pair < 0 for an
+ * empty row, 16-byte aligned; tgt int32 [n_groups] = the group's target image; xy [n_pairs, kmax, 2] as above (rows of a group write their own
+ * (pair, key point) slot).  Same arithmetic per row as visrep_cscore_transfer, bit for bit. */
+int visrep_cscore_transfer_packed(const float* feats, const int* rows_tab, const int* tgt, const float* lin, float* xy, int n_groups, int kmax,
+                                  int P, int C, int split, int window, int soft_eval, float beta, float anno_stride, float anno_half,
+                                  void* stream);
 /* per-pair PCK hit counts (C_score/pck_train.py:101,149-163): kps1/kps2 [n_pairs,kmax,3] (x,y,vis) fp32, thresholds
  * fp64 [n_pairs], alphas3 = HOST pointer to 3 floats; counts int32 [n_pairs,4] = hits@a0,a1,a2, n_visible. */
 int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp, int n_pairs,

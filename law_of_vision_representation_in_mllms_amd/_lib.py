@@ -96,6 +96,7 @@ SIGNATURES = {
     "visrep_ascore_row_scale": (_i, [_vp, C.c_long, _i, _i, _vp, _vp]),
     "visrep_ascore_maxcos_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_cscore_transfer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp]),
+    "visrep_cscore_transfer_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "visrep_pck_count": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _vp]),
     "visrep_jpeg_info": (_i, [_vp, _sz, C.POINTER(JpegInfo)]),
     "visrep_jpeg_entropy_decode": (_i, [_vp, _sz, _vp, _vp]),

@@ -36,6 +36,56 @@ struct CArgs {
     float beta, stride, half;      // anno_size / P, floor(stride / 2)
 };
 
+// phase B of the transfer, one wave per key-point similarity row [PP] (LDS): first-index argmax, clamped (2w+1)^2 window, entries outside
+// the window are ZERO and stay in the softmax (reference semantics), expectation over linspace(-1, 1, P), annotation frame
+VR_DEV void soft_argmax_row(const CArgs& p, const float* row, int PP, int lane, float* o) {
+    const int w = p.window;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = lane; t < PP; t += 64) {
+        const float v = row[t];
+        if (v > bv) { bv = v; bi = t; }                        // per lane t increases -> first index kept on ties
+    }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+        const float ov = __shfl_xor(bv, o2);
+        const int oi = __shfl_xor(bi, o2);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    float ox, oy;
+    if (p.soft) {
+        const int mx = bi % p.P, my = bi / p.P;
+        int x0 = 0, x1 = p.P - 1, y0 = 0, y1 = p.P - 1;
+        if (w > 0) {
+            x0 = max(mx - w, 0); x1 = min(mx + w, p.P - 1);
+            y0 = max(my - w, 0); y1 = min(my + w, p.P - 1);
+        }
+        const bool has_out = (x1 - x0 + 1) * (y1 - y0 + 1) < PP;
+        const float Mx = has_out ? fmaxf(bv, 0.f) : bv;
+        float z = 0.f, ex = 0.f, ey = 0.f;
+        for (int t = lane; t < PP; t += 64) {
+            const int ty = t / p.P, tx = t - ty * p.P;
+            const bool in = tx >= x0 && tx <= x1 && ty >= y0 && ty <= y1;
+            const float v = in ? row[t] : 0.f;
+            const float e = expf((v - Mx) / p.beta);
+            z += e; ex += e * p.lin[tx]; ey += e * p.lin[ty];
+        }
+        z = wave_sum(z); ex = wave_sum(ex); ey = wave_sum(ey);
+        const float pm1 = (float)(p.P - 1);
+        float fx = (ex / z + 1.f) * pm1 / 2.0f;
+        float fy = (ey / z + 1.f) * pm1 / 2.0f;
+        ox = fminf(fmaxf(fx, 0.f), pm1);
+        oy = fminf(fmaxf(fy, 0.f), pm1);
+    } else {
+        ox = (float)(bi % p.P);
+        oy = (float)(bi / p.P);
+    }
+    if (lane == 0) {
+        o[0] = ox * p.stride + p.half;
+        o[1] = oy * p.stride + p.half;
+    }
+}
+
 template <bool PM>                 // PM: position-major bank [P^2, C]
 __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -154,54 +204,111 @@ __global__ __launch_bounds__(256) void cscore_transfer(const CArgs p) {
     __syncthreads();
 
     // ---------------- phase B: one wave per keypoint row
-    const int w = p.window;
-    for (int k = wave; k < K; k += 4) {
-        float* row = rows + k * PP;
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int t = lane; t < PP; t += 64) {
-            const float v = row[t];
-            if (v > bv) { bv = v; bi = t; }                        // per lane t increases -> first index kept on ties
+    for (int k = wave; k < K; k += 4) soft_argmax_row(p, rows + k * PP, PP, lane, p.xy + ((size_t)pair * p.kmax + k) * 2);
+}
+
+// ---- packed variant (position-major banks): one workgroup = one 32-row MFMA tile filled with the key points of SEVERAL pairs that share
+// a target image.  A pair alone fills 11.5 of the 32 rows on average (K ~ U{3..20}) and every pair streams the whole target map: packing
+// the pairs of a target (host side, cscore_ops.pack_rows) runs ~2.3x fewer tiles and target-map passes; consecutive groups share a target
+// and are mapped onto ONE XCD (xcd_remap), so the second / third group of a target finds the map in that XCD's L2 (round 3 measured 7
+// fabric fetches per map: the seven pairs of a target landed on seven XCDs).
+// rows_tab[g][r] = (pair, k, source image, source patch index), pair < 0 = empty row; tgt[g] = target image.
+struct CPackArgs {
+    CArgs c;
+    const int4* rows_tab;
+    const int* tgt;
+    int n_groups;
+};
+
+__global__ __launch_bounds__(256) void cscore_transfer_packed(const CPackArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const CArgs& p = q.c;
+    const int PP = p.P * p.P;
+    float* rows = sm;                     // [32][PP]
+    const int group = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const size_t map_elems = (size_t)p.C * PP;
+    const int4 ent = q.rows_tab[(size_t)group * 32 + lq];                    // this lane's key-point row
+    const float* F2 = p.feats + (size_t)q.tgt[group] * map_elems;
+    // empty rows read the target's first descriptor (finite data, results never used)
+    const float* a_ptr = ent.x >= 0 ? p.feats + (size_t)ent.z * map_elems + (size_t)ent.w * p.C : F2;
+
+    const int ntile = (PP + 31) >> 5;
+    const bool two = p.split > 0;
+    const int c_mid = two ? p.split : p.C;
+    float fa = 0.f, fb = 0.f;
+    bool first = true;
+    auto gram = [&](int c0, int c1, const float* bp, f32x16& acc, float& n1, float& n2) {
+        int c = c0;
+        const float* ar = a_ptr + 16 * hi;
+        const float* br = bp + 16 * hi;
+        for (; c + 32 <= c1; c += 32) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const float4*>(ar + c + 4 * u);
+                b[u] = *reinterpret_cast<const float4*>(br + c + 4 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bw[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    n1 += av[e] * av[e];
+                    n2 += bw[e] * bw[e];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bw[e], acc, 0, 0, 0);
+                }
+            }
+        }
+        for (; c < c1; c += 2) {
+            const float a = a_ptr[c + hi];
+            const float b = bp[c + hi];
+            n1 += a * a;
+            n2 += b * b;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    };
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int t = tile * 32 + lq;
+        const int tc = t < PP ? t : PP - 1;
+        const float* b_ptr = F2 + (size_t)tc * p.C;
+        f32x16 acc_a = f32x16{}, acc_b = f32x16{};
+        float n1a = 0.f, n1b = 0.f, n2a = 0.f, n2b = 0.f;
+        gram(0, c_mid, b_ptr, acc_a, n1a, n2a);
+        if (two) gram(c_mid, p.C, b_ptr, acc_b, n1b, n2b);
+        if (first) {
+            n1a += __shfl_xor(n1a, 32); n1b += __shfl_xor(n1b, 32);
+            const float ia = 1.0f / (sqrtf(n1a) + 1e-10f);
+            if (two) {
+                const float ib = 1.0f / (sqrtf(n1b) + 1e-10f);
+                const float inv = 1.0f / (sqrtf(n1a * ia * ia + n1b * ib * ib) + 1e-10f);
+                fa = ia * inv; fb = ib * inv;
+            } else {
+                fa = ia;
+            }
+            first = false;
+        }
+        n2a += __shfl_xor(n2a, 32); n2b += __shfl_xor(n2b, 32);
+        float ga = 1.0f / (sqrtf(n2a) + 1e-10f), gb = 0.f;
+        if (two) {
+            gb = 1.0f / (sqrtf(n2b) + 1e-10f);
+            const float inv = 1.0f / (sqrtf(n2a * ga * ga + n2b * gb * gb) + 1e-10f);
+            ga *= inv; gb *= inv;
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(bv, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float v = acc_a[r] * ga * __shfl(fa, k);
+            if (two) v += acc_b[r] * gb * __shfl(fb, k);
+            if (t < PP) rows[k * PP + t] = v;
         }
-        float ox, oy;
-        if (p.soft) {
-            const int mx = bi % p.P, my = bi / p.P;
-            int x0 = 0, x1 = p.P - 1, y0 = 0, y1 = p.P - 1;
-            if (w > 0) {
-                x0 = max(mx - w, 0); x1 = min(mx + w, p.P - 1);
-                y0 = max(my - w, 0); y1 = min(my + w, p.P - 1);
-            }
-            const bool has_out = (x1 - x0 + 1) * (y1 - y0 + 1) < PP;
-            const float Mx = has_out ? fmaxf(bv, 0.f) : bv;
-            float z = 0.f, ex = 0.f, ey = 0.f;
-            for (int t = lane; t < PP; t += 64) {
-                const int ty = t / p.P, tx = t - ty * p.P;
-                const bool in = tx >= x0 && tx <= x1 && ty >= y0 && ty <= y1;
-                const float v = in ? row[t] : 0.f;
-                const float e = expf((v - Mx) / p.beta);
-                z += e; ex += e * p.lin[tx]; ey += e * p.lin[ty];
-            }
-            z = wave_sum(z); ex = wave_sum(ex); ey = wave_sum(ey);
-            const float pm1 = (float)(p.P - 1);
-            float fx = (ex / z + 1.f) * pm1 / 2.0f;
-            float fy = (ey / z + 1.f) * pm1 / 2.0f;
-            ox = fminf(fmaxf(fx, 0.f), pm1);
-            oy = fminf(fmaxf(fy, 0.f), pm1);
-        } else {
-            ox = (float)(bi % p.P);
-            oy = (float)(bi / p.P);
-        }
-        if (lane == 0) {
-            float* o = p.xy + ((size_t)pair * p.kmax + k) * 2;
-            o[0] = ox * p.stride + p.half;
-            o[1] = oy * p.stride + p.half;
-        }
+    }
+    __syncthreads();
+    for (int k = wave; k < 32; k += 4) {
+        const int4 e = q.rows_tab[(size_t)group * 32 + k];                    // uniform
+        if (e.x < 0) continue;
+        soft_argmax_row(p, rows + k * PP, PP, lane, p.xy + ((size_t)e.x * p.kmax + e.y) * 2);
     }
 }
 
@@ -372,6 +479,25 @@ extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const
     if (layout) hipLaunchKernelGGL(cscore_transfer<true>, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(cscore_transfer<false>, dim3(n_pairs), dim3(256), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "cscore_transfer: launch failed");
+}
+
+extern "C" int visrep_cscore_transfer_packed(const float* feats, const int* rows_tab, const int* tgt, const float* lin, float* xy, int n_groups, int kmax,
+                                             int P, int C, int split, int window, int soft_eval, float beta, float anno_stride, float anno_half,
+                                             void* stream) {
+    if (n_groups <= 0) return 0;
+    if (!feats || !rows_tab || !tgt || !lin || !xy) return visrep_set_error(VISREP_ERR_ARG, "cscore_packed: null pointer");
+    if ((C & 3) || (split & 3)) return visrep_set_error(VISREP_ERR_SHAPE, "cscore_packed: position-major banks need C and split to be multiples of 4");
+    if (kmax <= 0 || kmax > 32) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: kmax must be in 1..32");
+    if (P <= 0 || P > 32 || C <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: need 1 <= P <= 32");
+    if (split < 0 || split >= C) return visrep_set_error(VISREP_ERR_SHAPE, "cscore: split must be in [0, C)");
+    if ((uintptr_t)rows_tab & 15) return visrep_set_error(VISREP_ERR_ARG, "cscore_packed: rows_tab must be 16-byte aligned");
+    CPackArgs a{{feats, nullptr, nullptr, nullptr, nullptr, lin, xy, 0, kmax, P, C, split, window, soft_eval, beta, anno_stride, anno_half},
+                reinterpret_cast<const int4*>(rows_tab), tgt, n_groups};
+    const size_t lds = sizeof(float) * ((size_t)32 * P * P);
+    static VisrepLdsOptIn opt;
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(cscore_transfer_packed), (int)lds);
+    hipLaunchKernelGGL(cscore_transfer_packed, dim3(n_groups), dim3(256), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "cscore_transfer_packed: launch failed");
 }
 
 extern "C" int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp,

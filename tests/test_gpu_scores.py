@@ -209,3 +209,39 @@ def test_cscore_rejects_too_many_keypoints():
     bank = torch.zeros(2, 8, 16, device=DEV)
     with pytest.raises(RuntimeError, match="kmax"):
         cscore_ops.transfer(bank, torch.tensor([0]), torch.tensor([1]), torch.zeros(1, 40, dtype=torch.int32), torch.tensor([40]), 4)
+
+
+@pytest.mark.parametrize("P,C,split", [(16, 256, 0), (14, 192, 64), (6, 132, 0)])
+def test_packed_keypoint_tiles_equal_one_tile_per_pair(P, C, split):
+    """the key points of several pairs that share a target image ride in one 32-row MFMA tile.  Same per-row arithmetic:
+    the packed launch must reproduce the one-tile-per-pair launch BIT FOR BIT on an SPair-shaped pair list (targets reused ~7 times,
+    K ~ U{0..20} incl. empty pairs), one- and two-encoder banks, and stay at the oracle's distance."""
+    rs = np.random.RandomState(P * 100 + C)
+    n_img, n = 23, 160
+    g = torch.Generator().manual_seed(P)
+    bank = torch.randn(n_img, P * P, C, generator=g).to(DEV)
+    i1 = torch.from_numpy(rs.randint(0, n_img, n).astype(np.int32))
+    i2 = torch.from_numpy(rs.randint(0, n_img, n).astype(np.int32))
+    nkp = torch.from_numpy(rs.randint(0, 21, n).astype(np.int32))
+    idx = torch.from_numpy(rs.randint(0, P * P, (n, 20)).astype(np.int32))
+    one = cscore_ops.transfer(bank, i1, i2, idx, nkp, P, split=split, layout="pc", packed=False)
+    pk = cscore_ops.transfer(bank, i1, i2, idx, nkp, P, split=split, layout="pc")
+    valid = (torch.arange(20)[None] < nkp[:, None]).to(DEV)
+    assert torch.equal(one[valid], pk[valid])
+    assert (pk[~valid] == 0).all()                                           # rows past a pair's key points are never written
+    tab, tgt = cscore_ops.pack_rows(i1.numpy(), i2.numpy(), idx.numpy(), nkp.numpy())
+    assert len(tgt) < 0.6 * int((nkp > 0).sum())                             # fewer tiles than pairs
+    again = cscore_ops.transfer(bank, i1, i2, idx, nkp, P, split=split, layout="pc", packed=cscore_ops.packed_rows_on(bank.device, i1, i2, idx, nkp))
+    assert torch.equal(again, pk)
+    # oracle on a few pairs
+    for z in (0, 7, 31):
+        K = int(nkp[z])
+        if K == 0:
+            continue
+        d1, d2 = bank[int(i1[z])].cpu()[None], bank[int(i2[z])].cpu()[None]
+        if split:
+            d1, d2 = OC.normalize_feats_two(d1, split), OC.normalize_feats_two(d2, split)
+        else:
+            d1, d2 = OC.normalize_feats(d1), OC.normalize_feats(d2)
+        want = OC.keypoint_transfer(d1, d2, idx[z, :K].numpy(), P)
+        assert (pk[z, :K].cpu() - want).abs().max().item() < 5e-3

@@ -279,3 +279,34 @@ def test_adapt_flip_eval_matches_reference_eval(tmp_path, cpu_ops):
     a.MUTUAL_NN = False
     with pytest.raises(NotImplementedError, match="60x60"):
         PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+
+
+def test_pack_rows_packs_the_pairs_of_a_target_into_32_row_tiles():
+    """cscore_ops.pack_rows (host half of the packed key-point transfer): every key point of every pair sits in exactly one tile row, a tile
+    holds pairs of ONE target, at most 32 rows, pairs are never split, the groups of a target are consecutive; on an SPair-shaped list the
+    tiles are > 75 % full (one tile per pair: 36 %)."""
+    from law_of_vision_representation_in_mllms_amd import cscore_ops as CO
+    rs = np.random.RandomState(5)
+    n = 12234
+    img1, img2 = rs.randint(0, 1800, n), rs.randint(0, 1800, n)
+    nkp = rs.randint(3, 21, n)
+    nkp[:50] = 0                                                          # pairs without key points take no row
+    idx = rs.randint(0, 256, (n, 20))
+    tab, tgt = CO.pack_rows(img1, img2, idx, nkp)
+    assert tab.shape[1:] == (32, 4) and tab.dtype == np.int32 and len(tgt) == len(tab)
+    used = tab[:, :, 0] >= 0
+    assert used.sum() == nkp.sum() and used.mean() > 0.75
+    seen = set()
+    for g in range(len(tab)):
+        rows = tab[g][used[g]]
+        assert (used[g][: len(rows)]).all()                               # rows are filled from the top
+        for z in np.unique(rows[:, 0]):
+            r = rows[rows[:, 0] == z]
+            assert img2[z] == tgt[g] and len(r) == nkp[z] and (r[:, 1] == np.arange(nkp[z])).all()       # whole pair, in key-point order
+            assert (r[:, 2] == img1[z]).all() and (r[:, 3] == idx[z, : nkp[z]]).all()
+            assert z not in seen
+            seen.add(int(z))
+    assert seen == set(np.nonzero(nkp)[0].tolist())
+    assert (np.diff(tgt) >= 0).all()                                      # groups of one target are consecutive (and targets ascend)
+    e_tab, e_tgt = CO.pack_rows(img1[:0], img2[:0], idx[:0], nkp[:0])
+    assert e_tab.shape == (0, 32, 4) and e_tgt.shape == (0,)
