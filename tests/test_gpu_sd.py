@@ -613,3 +613,27 @@ def test_sd15_full_depth_256px_parity(monkeypatch):
     got_tok = got.permute(1, 2, 0).reshape(1, 64, 1280)
     e_hip, e_ref = rel_err(got_tok, want), rel_err(ref_bf16, want)
     assert e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)
+
+
+def test_vae_mid_block_attention_at_9216_tokens():
+    """the 768-px VAE's mid-block attention (96 x 96 = 9,216 latent pixels, ONE head of width 512: fp32 score GEMM ->
+    softmax_rows -> role-swapped V^T GEMM -> P V GEMM, per image through HBM) was only ever compared at 1,024 tokens.  Here at the real token
+    count and head width: a two-level VAE (64 -> 512 channels, one 2x downsample) on a 192-px image has exactly SD1.5's mid block at 768 px;
+    posterior moments against the fp32 oracle, bounded by the oracle's own bf16 run."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    vae = SW.VaeSpec(block_out=(64, 512), layers_per_block=1)
+    base = SW.tiny_sd_spec()
+    sp = SW.SdSpec("vae-mid-9216", unet=base.unet, vae=vae, sched=base.sched, text_len=base.text_len)
+    wv = SW.synthetic_vae(vae, 22)
+    wu = SW.synthetic_unet(sp.unet, 21, n_up_blocks=1)
+    eng = SE.SdEngine(sp, wu, wv, DEV, up_ft_index=0)
+    img = torch.from_numpy(np.random.RandomState(3).uniform(-1, 1, (1, 3, 192, 192)).astype(np.float32))
+    mom, h, w = eng.vae_moments(img.to(DEV))
+    assert (h, w) == (96, 96) and h * w == 9216
+    Z = vae.latent_channels
+    mean, logvar = untokens(mom[:, :Z], 1, h, w).cpu(), untokens(mom[:, Z: 2 * Z], 1, h, w).cpu()
+    m32, l32 = OD.vae_encode_moments(vae, wv, img)                                         # fp32 oracle
+    m16, l16 = OD.vae_encode_moments(vae, {k: bf(v) for k, v in wv.items()}, bf(img))      # the same arithmetic with bf16 weights / input
+    assert torch.isfinite(mean).all() and torch.isfinite(logvar).all()
+    assert rel_err(mean, m32) < max(2.0 * rel_err(m16, m32), 2e-2), (rel_err(mean, m32), rel_err(m16, m32))
+    assert rel_err(logvar, l32) < max(2.0 * rel_err(l16, l32), 2e-2), (rel_err(logvar, l32), rel_err(l16, l32))
