@@ -326,10 +326,16 @@ def main():
             sec = time_kernel(fn)
             kern[name] = {"ms": round(sec * 1e3, 4), "tflops": round(fl / sec / 1e12, 1)}
         # attention (its own kernel): 4*T*T*d flop per image per layer
-        qk_act = torch.randn(M, 2 * d, device=dev).to(torch.bfloat16)
+        # the launch of the default forward: Q pre-scaled by head_dim^-0.5 * log2(e) in the projection weights (engine.VitEngine), scale <= 0
+        qk_f = torch.randn(M, 2 * d, device=dev)
+        if eng.q_prescaled:
+            qk_f[:, :d] *= 0.125 * 1.4426950408889634
+        qk_act = qk_f.to(torch.bfloat16)
+        del qk_f
         vt = engine.linear_vt(x, wo, None)
-        sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, spec.tokens, spec.heads, 0.125))
-        kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1)}
+        sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, spec.tokens, spec.heads, 0.0 if eng.q_prescaled else 0.125))
+        kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1),
+                                            "kernel": "attn_fwd<1, pre-scaled Q>" if eng.q_prescaled else "attn_fwd<1>"}
         top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
         # the 256x256 kernel on its own: the rows its full rounds cover (the dispatcher hands the last <= 256 rows to a 128x128 launch
         # pair) - this is the launch rocprofv3 lists as gemm_bf16_256<1>, so the two averages can be compared directly

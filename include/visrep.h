@@ -108,7 +108,8 @@ int visrep_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw,
 /* ---- multi-head self-attention forward (HF CLIPAttention / Dinov2SelfAttention / SiglipAttention: softmax(QK^T
  * scale) V, fp32 softmax).  qk: [B*T, 2*H*64] bf16 (Q | K, head-major columns); vt: V^T as written by
  * visrep_gemm_bf16(..., VISREP_EPI_VT): [H*64, ldvt] with ldvt >= round_up(B*T, 64), % 64 == 0, columns beyond B*T
- * finite; out: [B*T, H*64] bf16.  head_dim must be 64. */
+ * finite; out: [B*T, H*64] bf16.  head_dim must be 64.  scale <= 0: Q already carries scale * log2(e) (folded into the Q projection by
+ * the caller): the kernel computes p = 2^(q.k - reference) with the reference subtracted inside the matrix pipe (accumulator init). */
 int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo, int B, int T, int H, int head_dim,
                     float scale, void* stream);
 
@@ -120,7 +121,7 @@ int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* ou
  * VISREP_EPI_VT over the key rows, ldvt >= round_up(key rows, 64); out: [B*Tq, ldo].  head_dim in {64, 128, 192}: the
  * weight packer zero-pads narrower heads (SD1.5: 40 / 80 / 160), which changes nothing in softmax(QK^T)V.
  * causal = 1 masks keys after the query position (HF CLIPTextTransformer's causal mask: the prompt encoder behind
- * pipe.encode_prompt, dift_sd.py:258-263). */
+ * pipe.encode_prompt, dift_sd.py:258-263).  scale <= 0 (head_dim 64 only): pre-scaled Q, as for visrep_mhsa_fwd. */
 int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo, int B, int Tq,
                          int Tk, int H, int head_dim, int kv_shared, int causal, float scale, void* stream);
 
@@ -134,6 +135,10 @@ int visrep_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
 typedef struct {
     int image_size, patch, d, heads, mlp, layers, tokens, has_cls, pre_ln, act, kpad;
     float eps;
+    /* 1: the Q rows of wqkv (and of bqkv) carry head_dim^-0.5 * log2(e) - folded in by the weight packer (the bf16 engine does it while it
+     * folds LayerNorm: same single rounding of the fp32 product) - and the attention kernel exponentiates the raw scores (visrep_mhsa_fwd
+     * with scale <= 0).  bf16 tower only; the fp32 towers ignore it. */
+    int q_prescaled;
 } visrep_vit_config;
 typedef struct {           /* device pointers; matrices bf16 [out,in], vectors fp32; ls1/ls2 NULL when no LayerScale */
     const float *ln1_g, *ln1_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo; const float* ls1;

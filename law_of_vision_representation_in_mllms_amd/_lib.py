@@ -19,7 +19,7 @@ ACT = {"none": 0, "quick_gelu": 1, "gelu": 2, "gelu_erf": 2, "gelu_tanh": 3, "ge
 
 class VitConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("image_size", "patch", "d", "heads", "mlp", "layers", "tokens", "has_cls", "pre_ln",
-                                       "act", "kpad")] + [("eps", C.c_float)]
+                                       "act", "kpad")] + [("eps", C.c_float), ("q_prescaled", C.c_int)]
 
 
 class VitLayer(C.Structure):

@@ -50,7 +50,12 @@ struct AttnArgs {
     float sc;                              // softmax scale * log2(e)
 };
 
-template <int ND>                          // head width D = 64 * ND
+// PS ("pre-scaled", round 4): the caller folded scale * log2(e) into Q (the ViT engine folds it into the Q rows of the Q|K projection
+// weights), so the raw MFMA result is already the exponent of 2 - and the running reference maximum is subtracted INSIDE the matrix pipe:
+// the Q.K^T accumulators start from a register tile holding -m_ref instead of zeros, p = exp2(acc) with no per-element scale-and-shift FMA
+// (32 of the ~250 VALU instructions per key tile, profiles/round4_attention.md).  The reference is moved (scores shifted, O and the running
+// sum rescaled, the init tile rewritten) only on an image's first key tile and when some row's maximum grew by more than 2^THR.
+template <int ND, bool PS = false>         // head width D = 64 * ND
 __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs p) {
     constexpr int D = 64 * ND, KV_B = ND * TILE_B, STAGE_B = 2 * KV_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -113,7 +118,8 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
     f32x16 o[2 * ND];
 #pragma unroll
     for (int dt = 0; dt < 2 * ND; ++dt) o[dt] = f32x16{};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = PS ? 0.f : -INFINITY, l_run = 0.f;       // PS: m_run = the reference already subtracted in the accumulators
+    f32x16 minit = f32x16{};                               // PS: -m_run in every element (the C operand of the first Q.K^T MFMA of a chain)
 
     stage(0);
     __syncthreads();
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 
         // ---- S^T tiles: s[kt2] = K[kt2*32.., :] . Q^T
         f32x16 s[2];
-        s[0] = f32x16{}; s[1] = f32x16{};
+        if (PS) { s[0] = minit; s[1] = minit; }
+        else { s[0] = f32x16{}; s[1] = f32x16{}; }
 #pragma unroll
         for (int kk = 0; kk < 4 * ND; ++kk) {
 #pragma unroll
@@ -169,6 +176,39 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
             const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             mloc = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
         }
+        float psum = 0.f;
+        uint32_t pb[2][8];
+        if constexpr (PS) {
+            // s = true exponent - m_run.  Move the reference on the first tile (to the row's true maximum, whatever its sign) and when a
+            // row's maximum exceeds it by more than THR (p <= 2^THR otherwise: bf16 keeps its relative precision, sums are fp32)
+            if (it == 0 || __any(mloc > (float)(VISREP_ATTN_V1_THR > 0 ? VISREP_ATTN_V1_THR : 0))) {     // wave-uniform
+                const float delta = it == 0 ? mloc : fmaxf(mloc, 0.f);
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kt2][r] -= delta;
+                if (it > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < 2 * ND; ++dt) o[dt][r] *= alpha;
+                }
+                m_run += delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) minit[r] = -m_run;
+            }
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = (VISREP_ATTN_ABLATE & 1) ? s[kt2][r] : __builtin_amdgcn_exp2f(s[kt2][r]);
+                    const float p1 = (VISREP_ATTN_ABLATE & 1) ? s[kt2][r + 1] : __builtin_amdgcn_exp2f(s[kt2][r + 1]);
+                    psum += p0 + p1;
+                    pb[kt2][r >> 1] = pack_bf16(p0, p1);
+                }
+        } else {
 #if VISREP_ATTN_V1_THR > 0                                  // deferred maximum: keep the old one while no row's maximum grew by more than THR (exp2 units):
         // p <= 2^THR then (bf16 keeps its relative precision, sums are fp32) and most tiles skip the rescale branch below; -2.4 % (round 3)
         const float m_new = __any((mloc - m_run) * p.sc > (float)VISREP_ATTN_V1_THR) ? fmaxf(m_run, mloc) : m_run;
@@ -176,8 +216,6 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
         const float m_new = fmaxf(m_run, mloc);             // finite: every image's first tile holds >= 1 valid key
 #endif
         const float msc = m_new * p.sc;
-        float psum = 0.f;
-        uint32_t pb[2][8];
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -196,6 +234,7 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
 #pragma unroll
                 for (int dt = 0; dt < 2 * ND; ++dt) o[dt][r] *= alpha;
             m_run = m_new;
+        }
         }
         l_run += psum;
 
@@ -278,6 +317,8 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out;
     a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.Mk = (int)Mk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.kv_shared = kv_shared; a.causal = causal;
     a.sc = scale * 1.4426950408889634f;
+    const bool ps = scale <= 0.f;                           // the caller folded scale * log2(e) into Q (see attn_fwd PS)
+    if (ps && head_dim != 64) return visrep_set_error(VISREP_ERR_ARG, "attention: pre-scaled Q (scale <= 0) is built for head_dim 64");
     const int nqt = (Tq + 127) / 128, nd = head_dim / 64;
     const dim3 grid(nqt * H * B), block(256);
     size_t lds = (size_t)nd * 4 * TILE_B;                   // double-buffered K + V^T tiles
@@ -292,7 +333,8 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     }
 #endif
     hipStream_t st = (hipStream_t)stream;
-    if (nd == 1) hipLaunchKernelGGL(attn_fwd<1>, grid, block, lds, st, a);
+    if (nd == 1 && ps) hipLaunchKernelGGL((attn_fwd<1, true>), grid, block, lds, st, a);
+    else if (nd == 1) hipLaunchKernelGGL(attn_fwd<1>, grid, block, lds, st, a);
     else if (nd == 2) hipLaunchKernelGGL(attn_fwd<2>, grid, block, lds, st, a);
     else {
         static VisrepLdsOptIn opt3;                         // 96 KB of dynamic LDS needs the opt-in once per device

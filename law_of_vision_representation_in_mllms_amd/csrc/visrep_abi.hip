@@ -182,7 +182,7 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
     if (hipMemsetAsync(rt, 0, (up(M, 128) + 8) * sizeof(float2), s) != hipSuccess) return visrep_set_error(VISREP_ERR_LAUNCH, "vit_forward: memset failed");
 
     float2* part = (float2*)(base + L.part);
-    const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
+    const float scale = c->q_prescaled ? 0.f : 0.125f;   // head_dim^-0.5, head_dim = 64; 0 = folded into the Q weights (attn_fwd PS)
     bool rt_ready = false;        // rt already holds the statistics of x (left by the previous layer's fc2 GEMM)
     for (int l = 0; l < n_layers; ++l) {
         const visrep_vit_layer& W = w->layers[l];

@@ -85,20 +85,33 @@ class VitEngine:
         n = len(weights["layers"])
         self.n_layers = n
         self._layers = (_lib.VitLayer * max(n, 1))()
-        def fold(Wm, bias, g, b):
-            """Linear(LayerNorm(x)) = rstd * (x (g o W)^T - mean * s) + (W b + bias): (g o W in bf16, s over the ROUNDED rows, b')."""
+        # softmax scale in the exponent's base, folded into the Q rows of the Q|K|V projection (attn_fwd PS): q' = c * q with
+        # c = head_dim^-0.5 * log2(e), so that 2^(q'.k) = e^(q.k / sqrt(head_dim)).  VISREP_Q_PRESCALE=0 keeps the scale in the kernel.
+        self.q_prescaled = os.environ.get("VISREP_Q_PRESCALE", "1") != "0"
+        qc = torch.ones(3 * spec.d)
+        if self.q_prescaled:
+            qc[: spec.d] = 0.125 * 1.4426950408889634
+
+        def fold(Wm, bias, g, b, rowscale=None):
+            """Linear(LayerNorm(x)) = rstd * (x (g o W)^T - mean * s) + (W b + bias): (g o W in bf16, s over the ROUNDED rows, b').
+            rowscale (the Q rows' softmax scale) multiplies the fp32 product before its single rounding to bf16."""
             Wb = Wm.detach().float().to(torch.bfloat16).float()               # the weights the unfused path multiplies with
-            Wf = (Wb * g.detach().float()[None]).to(torch.bfloat16)
+            rs = torch.ones(Wb.shape[0]) if rowscale is None else rowscale
+            Wf = (Wb * g.detach().float()[None] * rs[:, None]).to(torch.bfloat16)
             shift = Wb @ b.detach().float()                                  # beta pushed through the linear map
-            return Wf, Wf.float().sum(1), shift if bias is None else shift + bias.detach().float()
+            return Wf, Wf.float().sum(1), (shift if bias is None else shift + bias.detach().float()) * rs
 
         for i, L in enumerate(weights["layers"]):
             ent = self._layers[i]
             L = dict(L)
             extra = {"sqkv": None, "s1": None}
             if self.fuse_ln:
-                L["wqkv"], extra["sqkv"], L["bqkv"] = fold(L["wqkv"], L.get("bqkv"), L["ln1_g"], L["ln1_b"])
+                L["wqkv"], extra["sqkv"], L["bqkv"] = fold(L["wqkv"], L.get("bqkv"), L["ln1_g"], L["ln1_b"], qc)
                 L["w1"], extra["s1"], L["b1"] = fold(L["w1"], L.get("b1"), L["ln2_g"], L["ln2_b"])
+            elif self.q_prescaled:                                             # unfused path: scale the (bf16-rounded) rows, round once more
+                L["wqkv"] = L["wqkv"].detach().float().to(torch.bfloat16).float() * qc[:, None]
+                if L.get("bqkv") is not None:
+                    L["bqkv"] = L["bqkv"].detach().float() * qc
             for k in ("wqkv", "wo", "w1", "w2"):
                 setattr(ent, k, mat(L[k]).data_ptr())
             for k in ("ln1_g", "ln1_b", "bqkv", "bo", "ls1", "ln2_g", "ln2_b", "b1", "b2", "ls2"):
@@ -113,7 +126,7 @@ class VitEngine:
             setattr(self._w, k, 0 if v is None else v.data_ptr())
         self._w.layers = C.cast(self._layers, C.POINTER(_lib.VitLayer))
         self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
-                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
+                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps), int(self.q_prescaled))
         self._ws: Dict[int, torch.Tensor] = {}
         self._pinned = set()                 # batch sizes whose workspace a captured HIP graph refers to
 

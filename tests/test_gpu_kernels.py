@@ -234,6 +234,34 @@ def test_attention_matches_torch(B, T, H, gemm_variant, attn_variant):
     assert rel_err(out, want) < 1e-2
 
 
+@pytest.mark.parametrize("B,T,H,spread", [(3, 577, 2, 1.0), (2, 257, 4, 1.0), (5, 17, 2, 1.0), (2, 1, 2, 1.0), (3, 300, 1, 6.0), (2, 130, 2, 25.0)])
+def test_attention_prescaled_q(B, T, H, spread):
+    """scale <= 0 = "Q carries head_dim^-0.5 * log2(e)" (the ViT engine folds it into the Q projection): the kernel exponentiates the raw
+    scores with the running reference subtracted inside the matrix pipe.  Against the fp32 softmax of the SAME (pre-scaled, bf16-rounded)
+    Q, and against the plain kernel on the unscaled Q (same math, one more bf16 rounding of Q).  spread > 1: peaked rows, large negative
+    and positive first-tile maxima (the reference has to move on the first tile whatever its sign, and again when a later tile overtakes it)."""
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    d = H * 64
+    M = B * T
+    q = torch.randn(M, d, generator=g) * spread
+    k = torch.randn(M, d, generator=g) * spread
+    if spread > 1:
+        q[::3] -= 2.0 * spread                                               # rows whose scores are all strongly negative / positive
+        k[T // 2:: 7] += 1.5 * spread                                        # late keys that overtake the running reference
+    v = bf(torch.randn(M, d, generator=g))
+    c = 0.125 * 1.4426950408889634
+    qs = bf(q * c)                                                           # what the folded projection writes
+    qk_ps = torch.cat([qs, bf(k)], 1).to(DEV)
+    vt = engine.linear_vt(v.to(DEV), bf(torch.eye(d)).to(DEV), None)
+    out = engine.mhsa(qk_ps, vt, B, T, H, 0.0)
+    qf, kf, vf = [t.float().view(B, T, H, 64).transpose(1, 2) for t in (qs, bf(k), v)]
+    want = (torch.softmax((qf @ kf.transpose(-1, -2)) * math.log(2.0), -1) @ vf).transpose(1, 2).reshape(M, d)
+    assert torch.isfinite(out.float()).all()
+    assert max_err(out, want) < 1.5e-2 and rel_err(out, want) < 1e-2
+    plain = engine.mhsa(torch.cat([bf(q), bf(k)], 1).to(DEV), vt, B, T, H, 0.125)
+    assert rel_err(out, plain) < (2e-2 if spread == 1.0 else 0.2)           # one more rounding of Q; peaked rows amplify it
+
+
 def test_attention_peaked_softmax(attn_variant):
     # one key dominates each query by a huge margin: exercises the running-max rescale path at every tile
     B, T, H, d = 2, 300, 2, 128
