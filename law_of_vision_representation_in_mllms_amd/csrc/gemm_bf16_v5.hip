@@ -62,8 +62,15 @@
 // 0: every wave stages 32 rows of both operands (v3's scheme).
 // Measured (same process, rows = 147,456): N >= 2048 gains (fc1 1.122 -> 1.103 ms, Q|K 0.544 -> 0.531), N = 1024 loses (fc2 0.938 -> 0.970, out 0.328 -> 0.337,
 // V^T 0.269 -> 0.280): the kernel is compiled both ways and the launcher picks by N.  -DV5_OWN=0 / =1 forces one scheme (A/B builds).
+#ifndef V5_DMA_IN_M
+#define V5_DMA_IN_M 0
+#endif
 #ifndef V5_OWN
+#if V5_DMA_IN_M == 2
+#define V5_OWN 0
+#else
 #define V5_OWN OWN_
+#endif
 #endif
 // 1: group 0 meets the tile's last barrier BEFORE its epilogue instead of after it.  Both groups finish an output tile together (one barrier
 //    interval apart), and with the barrier behind group 0's epilogue the two epilogues ran one after the other with the matrix pipe idle under
@@ -74,6 +81,11 @@
 #ifndef V5_EPI_EARLY
 #define V5_EPI_EARLY 1
 #endif
+// A/B knob V5_DMA_IN_M (round 4; measured slower, profiles/round4_gemm.md section 4): issue the LDS-DMA pieces BETWEEN the MFMAs of the M
+// segments (one piece after every fourth MFMA) instead of inside the load segments, whose length - not the 512 matrix-pipe cycles of an M
+// segment - sets the barrier cadence.  1: the OWN_ = true kernels only (group 0: 8 pieces in M0, 4 in M1; group 1: 4 in M1); the counted-wait
+// ledger is unchanged (every piece is issued later than before, the waits stay put).  2: every kernel with the OWN_ = false staging (4 pieces
+// per wave in M0 and in M1, both groups); group 1 then confirms W(s+1) and X(s+1) with vmcnt(0) at the end of L1(s) - nothing newer is in flight.
 
 namespace {
 
@@ -216,6 +228,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         if (cw.k == p.K) { cw.k = 0; cw.kin = 0; cw.seg = 0; ++cw.ti; set_w(cw); }
     };
 
+    // piece-wise forms of issue_x / issue_w (V5_DMA_IN_M): piece j of the pending item, the cursor advances with the last piece
+    auto issue_x_piece = [&](int j) {
+        char* dst = smem + ((2 * cx.idx) % NSLOT) * XW_BYTES + wave * 4096;
+        glds16(cx.p[j] + col_of(cx, p.tab_a), dst + j * 1024);
+        if (j == 3) {
+            advance(cx);
+            if (cx.k == p.K) { cx.k = 0; cx.kin = 0; cx.seg = 0; ++cx.ti; set_x(cx); }
+        }
+    };
+    auto issue_w_piece = [&](int j) {                         // OWN: group 0, eight pieces, rows 64 wn + 8 j + lane>>3; else four pieces like X
+        if (!V5_OWN) {
+            char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wave * 4096;
+            glds16(cw.p[j] + col_of(cw, p.tab_w), dst + j * 1024);
+            if (j == 3) {
+                advance(cw);
+                if (cw.k == p.K) { cw.k = 0; cw.kin = 0; cw.seg = 0; ++cw.ti; set_w(cw); }
+            }
+            return;
+        }
+        char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wn * 8192;
+        const size_t step = (size_t)16 * p.ldw;
+        glds16(cw.p[j & 1] + (j >> 1) * step + col_of(cw, p.tab_w), dst + j * 1024);
+        if (j == 7) {
+            advance(cw);
+            if (cw.k == p.K) { cw.k = 0; cw.kin = 0; cw.seg = 0; ++cw.ti; set_w(cw); }
+        }
+    };
+
     // ---- fragment read offsets (16x16x32 operands): row = base16 + (lane&15), logical slot = 4*h + (lane>>4),
     //      physical slot = logical ^ ((row>>1)&7) (16-row steps leave (row>>1)&7 alone); the k-half h only flips slot bit 2 -> one XOR
     const int fr = lane & 15, hi = lane >> 4;
@@ -248,22 +288,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 // ---------------- L(h): 12 fragment reads of k-half h + four LDS-DMA loads (L0: W of tile s+1, L1: X of tile s+2)
                 const unsigned xa = (sx + xbase) ^ (h << 6), wa = (sw + wbase) ^ (h << 6);
                 if (V5_PRIO) __builtin_amdgcn_s_setprio(1);    // the load segment gets the issue priority
-                if (V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) { if (!V5_OWN || G == 0) issue_w(); } else issue_x(); }
+                constexpr bool IN_M = V5_DMA_IN_M == 2 || (V5_DMA_IN_M == 1 && OWN_);      // the pieces go out between the MFMAs of M(h) instead
+                if (!IN_M && V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) { if (!V5_OWN || G == 0) issue_w(); } else issue_x(); }
                 if (!(DBG & 4)) lds_issue12(xf, wf, xa, wa);
-                if (!V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) { if (!V5_OWN || G == 0) issue_w(); } else issue_x(); }
-                if (!V5_OWN && h == 1 && G == 1) wait_vm4();
+                if (!IN_M && !V5_DMA_FIRST && !(DBG & 2)) { if (h == 0) { if (!V5_OWN || G == 0) issue_w(); } else issue_x(); }
+                if (!V5_OWN && h == 1 && G == 1) { if (IN_M) wait_vm0(); else wait_vm4(); }
                 lds_wait12(xf, wf);
                 if (V5_PRIO) __builtin_amdgcn_s_setprio(0);
                 barrier();
                 // ---------------- M(h): 32 MFMAs 16x16x32, nothing else
                 if (!(DBG & 1))
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (EPI == EPI_VT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[j], acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
                     }
+                    if (IN_M && !(DBG & 2)) {                    // one piece behind every fourth MFMA: W(s+1) in M0 (group 0: 8 pieces), X(s+2) in M1 (4)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (h == 0) { if (V5_OWN ? G == 0 : i < 4) issue_w_piece(i); }
+                        else if (i < 4) issue_x_piece(i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 if (h == 0) barrier();
             }
             // the wait must stay BEHIND the segment's MFMAs (hipcc otherwise hoists it to after the first one: the wave then sits in the wait
