@@ -78,8 +78,9 @@ def _device_input_stream(chunks, processor, image_aspect_ratio, device):
     from ... import device_jpeg as DJ
     from ... import device_preprocess as DP
     dec = DJ.DeviceJpegDecoder(device)
-    dproc = DP.DevicePreprocessor.like(processor, device)
-    bg = tuple(int(x * 255) for x in processor.image_mean)
+    # ViT towers: the device twin of their SimpleImageProcessor; diffusion towers: DiffImageProcessor.device_twin (resize-only, [-1, 1])
+    dproc = processor.device_twin(device) if hasattr(processor, "device_twin") else DP.DevicePreprocessor.like(processor, device)
+    bg = tuple(int(x * 255) for x in dproc.image_mean)
     pending = dec.submit([p for p, _ in chunks[0]]) if chunks else None
     for i, chunk in enumerate(chunks):
         nxt = dec.submit([p for p, _ in chunks[i + 1]]) if i + 1 < len(chunks) else None
@@ -103,8 +104,8 @@ def inference(model_args, data_args, training_args, model=None, workers=8, devic
     written = 0
     if device_decode is None:
         device_decode = os.environ.get("VISREP_DEVICE_DECODE") == "1"
-    if device_decode and not hasattr(processor, "resize_to"):
-        raise ValueError("device_decode needs the ViT towers' SimpleImageProcessor geometry (the diffusion towers' resize-only processor is not ported)")
+    if device_decode and not (hasattr(processor, "resize_to") or hasattr(processor, "device_twin")):
+        raise ValueError("device_decode needs an image processor with a device twin (SimpleImageProcessor geometry or DiffImageProcessor)")
 
     def host_stream(pool):
         submit = lambda chunk: [pool.submit(load_image, p, processor, data_args.image_aspect_ratio) for p, _ in chunk]

@@ -46,6 +46,17 @@ class DiffImageProcessor(nn.Module):
         u8 = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)            # what PILToTensor() returns
         return {"pixel_values": [(u8 / 255.0 - 0.5) * 2]}
 
+    def device_twin(self, device, dtype=torch.float32):
+        """The same preprocessing on the GPU for the device input pipeline (llava/feature/extract.inference(device_decode=True)):
+        `img.resize(img_size)` is PIL's default BICUBIC to exactly img_size (no aspect handling, no crop) and (u8 / 255 - 0.5) * 2 equals
+        (u8 / 255 - 0.5) / 0.5 bit for bit (a power of two), i.e. a DevicePreprocessor with square_resize, mean = std = 0.5.  Needs a positive
+        img_size: without the resize the images of a batch have different sizes."""
+        if self.img_size[0] <= 0 or self.img_size[0] != self.img_size[1]:
+            raise ValueError("the device input pipeline batches images: DiffImageProcessor needs a positive square img_size")
+        from ...... import device_preprocess as DP
+        side = int(self.img_size[0])
+        return DP.DevicePreprocessor(side, side, [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], square_resize=True, device=device, dtype=dtype)
+
 
 class DiffVisionTower(nn.Module):
     def __init__(self, args):

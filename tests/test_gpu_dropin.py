@@ -267,6 +267,15 @@ def test_device_preprocessor_equals_cpu_processors(tmp_path):
     assert torch.equal(MU.process_images(imgs, DP.DevicePreprocessor.like(cpu, DEV), cfg).cpu(), MU.process_images(imgs, cpu, cfg))
     imgs[0].save(tmp_path / "a.jpg")
     assert torch.equal(EF._load_pixels_device(str(tmp_path / "a.jpg"), 224, DEV).cpu(), EF._load_pixels(str(tmp_path / "a.jpg"), 224))
+    # the diffusion towers' resize-only processor (diffusion_encoder.py:30-41: PIL resize to img_size, (x / 255 - 0.5) * 2) has a device twin too
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder.diffLVLM.diffusion_encoder import DiffImageProcessor
+    for side in (64, 96):
+        dp = DiffImageProcessor([side, side])
+        want = torch.stack([dp.preprocess(im)["pixel_values"][0] for im in imgs])
+        got = dp.device_twin(DEV).preprocess(imgs)["pixel_values"]
+        assert got.shape == want.shape == (3, 3, side, side) and torch.equal(got.cpu(), want), side
+    with pytest.raises(ValueError, match="positive square"):
+        DiffImageProcessor([0, 0]).device_twin(DEV)
 
 
 def test_fused_pipelines_equal_the_file_route(small_towers, tmp_path):
