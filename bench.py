@@ -332,10 +332,17 @@ def main():
             qk_f[:, :d] *= 0.125 * 1.4426950408889634
         qk_act = qk_f.to(torch.bfloat16)
         del qk_f
-        vt = engine.linear_vt(x, wo, None)
-        sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, spec.tokens, spec.heads, 0.0 if eng.q_prescaled else 0.125))
-        kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * spec.tokens ** 2 * d / sec / 1e12, 1),
-                                            "kernel": "attn_fwd<1, pre-scaled Q>" if eng.q_prescaled else "attn_fwd<1>"}
+        T = spec.tokens
+        if getattr(eng, "_q_mode", 0) >= 2 and spec.has_cls and engine.mhsa_cls_supported(T):      # what visrep_vit_forward launches for this tower
+            vt = engine.gemm_rows(x, T - 1, T, 1, B * (T - 1), wo, None, epilogue=_lib.EPI_VT)
+            vcls = engine.gemm_rows(x, 1, T, 0, B, wo, None)
+            sec = time_kernel(lambda: engine.mhsa_cls(qk_act, vt, vcls, B, T, spec.heads))
+            which = "attn_fwd_cls (image-aligned key tiles, pre-scaled Q)"
+        else:
+            vt = engine.linear_vt(x, wo, None)
+            sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, T, spec.heads, 0.0 if eng.q_prescaled else 0.125))
+            which = "attn_fwd<1, pre-scaled Q>" if eng.q_prescaled else "attn_fwd<1>"
+        kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * T ** 2 * d / sec / 1e12, 1), "kernel": which}
         top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
         # the 256x256 kernel on its own: the rows its full rounds cover (the dispatcher hands the last <= 256 rows to a 128x128 launch
         # pair) - this is the launch rocprofv3 lists as gemm_bf16_256<1>, so the two averages can be compared directly

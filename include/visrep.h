@@ -102,6 +102,12 @@ int visrep_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, const fl
  * reads the residual stream again (HF blocks: x = x + attn(ln1(x)); x = x + mlp(ln2(x))).  The 256x256 kernel emits per-row partial
  * sums of the bf16-rounded outputs from its epilogue (partial: scratch of M * N / 64 float2) which are reduced in a fixed order;
  * shapes routed elsewhere (split-K, 128x128 tail rows) run visrep_layernorm_stats on the rows they wrote.  N <= 2048. */
+/* A GEMM over a periodic subset of A's rows: logical row r reads physical row (r / row_period) * row_stride + r % row_period + row_first
+ * (e.g. the patch tokens of every image: period T - 1, stride T, first 1 - the reference's feature_select `[:, 1:]`,
+ * clip_encoder.py:37-44 - or the CLS rows: period 1, stride T, first 0) without gathering them first.  ln_rt / ln_s (both or neither):
+ * folded LayerNorm, statistics indexed by PHYSICAL row.  Epilogues BIAS, ACT, VT (row_period % 4 == 0), F32. */
+int visrep_gemm_bf16_rows(const void* A, int lda, int row_period, int row_stride, int row_first, const void* W, int ldw, const float* bias,
+                          const void* ln_rt, const float* ln_s, void* C, int ldc, int M, int N, int K, int epilogue, int act, void* stream);
 int visrep_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
                                  const void* resid, const float* ls, void* rt, void* partial, float eps, void* stream);
 
@@ -112,6 +118,16 @@ int visrep_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw,
  * the caller): the kernel computes p = 2^(q.k - reference) with the reference subtracted inside the matrix pipe (accumulator init). */
 int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo, int B, int T, int H, int head_dim,
                     float scale, void* stream);
+
+/* ---- image-aligned self-attention of a CLS tower whose patch count is a multiple of 64 (T = 1 + 64 n: CLIP-L/14-336 577, the 224-px
+ * L/14 towers 257), pre-scaled Q only.  qk as for visrep_mhsa_fwd; vt: V^T of the PATCH tokens only, [H*64, ldvt], column
+ * b (T - 1) + t - 1 (perm16 inside 16-token blocks, as VISREP_EPI_VT writes it), ldvt >= B (T - 1); vcls: the V rows of the CLS tokens
+ * [B, ldvc] row-major.  An image's keys are then whole 64-key tiles (no masks, one tile less per image than the global tiling of
+ * visrep_mhsa_fwd) and the CLS key enters as the initial state of the online softmax (m = q.k_cls, l = 1, O = v_cls).
+ * visrep_mhsa_cls_supported(T) says whether T qualifies.  Same semantics as visrep_mhsa_fwd(scale <= 0). */
+int visrep_mhsa_cls_supported(int T);
+int visrep_mhsa_cls_fwd(const void* qk, int ldqk, const void* vt, int ldvt, const void* vcls, int ldvc, void* out, int ldo, int B, int T,
+                        int H, int head_dim, void* stream);
 
 /* ---- general multi-head attention forward for the diffusion towers' transformer blocks (vendored diffusers
  * attention_processor.py AttnProcessor2_0 / SlicedAttnProcessor called from attention.py:241-283 BasicTransformerBlock):
@@ -137,7 +153,9 @@ typedef struct {
     float eps;
     /* 1: the Q rows of wqkv (and of bqkv) carry head_dim^-0.5 * log2(e) - folded in by the weight packer (the bf16 engine does it while it
      * folds LayerNorm: same single rounding of the fp32 product) - and the attention kernel exponentiates the raw scores (visrep_mhsa_fwd
-     * with scale <= 0).  bf16 tower only; the fp32 towers ignore it. */
+     * with scale <= 0).  2: as 1, and towers with a CLS token and 64 n patches use the image-aligned kernel (visrep_mhsa_cls_fwd: V
+     * projected by two row-mapped GEMMs, patch rows -> V^T, CLS rows -> [B, d]); other shapes behave as 1.  bf16 tower only; the fp32
+     * towers ignore it. */
     int q_prescaled;
 } visrep_vit_config;
 typedef struct {           /* device pointers; matrices bf16 [out,in], vectors fp32; ls1/ls2 NULL when no LayerScale */

@@ -52,10 +52,13 @@ SIGNATURES = {
     "visrep_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "visrep_mhsa_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "visrep_mhsa_cls_supported": (_i, [_i]),
+    "visrep_mhsa_cls_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "visrep_set_scratch": (_i, [_vp, _sz]),
     "visrep_set_stream_scratch": (_i, [_vp, _vp, _sz]),
     "visrep_layernorm_stats": (_i, [_vp, _i, _vp, _i, _i, _f, _vp]),
     "visrep_gemm_bf16_ln": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "visrep_gemm_bf16_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_gemm_bf16_resid_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp]),
     "visrep_attention_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "visrep_groupnorm_workspace_bytes": (_sz, [_i, _i, _i]),

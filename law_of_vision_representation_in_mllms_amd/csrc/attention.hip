@@ -285,6 +285,182 @@ __global__ __launch_bounds__(256, ND == 1 ? 2 : 1) void attn_fwd(const AttnArgs 
         }
 }
 
+
+// ---- image-aligned self-attention for CLS towers with (T - 1) % 64 == 0 (CLIP-L/14-336: 577 = 1 + 9 * 64; the 224-px towers: 257 = 1 + 4 * 64)
+// and pre-scaled Q (round 4).  attn_fwd tiles the keys on GLOBAL 64-token blocks, so an image of 577 tokens always spans ten key tiles for
+// 9.02 tiles of data, two of them masked.  Here the PATCH keys 1 .. T-1 of an image are exactly (T - 1) / 64 full tiles - K rows read from
+// row b T + 1 on, V^T columns image-aligned (the V projection writes them that way: a row-mapped GEMM over the patch tokens, column
+// b (T - 1) + t - 1) - and the CLS key is a rank-1 side term handled once per wave before the tile loop:
+//     s_cls[q] = q . k_cls (32 FMAs per lane + one lane swap), reference m = s_cls, p_cls = 1, l = 1, O = v_cls
+// (v_cls: the V projection of the CLS rows, [B, H * 64] row-major).  No masks, no first / last tile special cases, one tile less per image.
+struct AttnClsArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vt; const bf16_t* vcls; bf16_t* out;
+    int B, T, H, ldq, ldk, ldvt, ldvc, ldo;
+};
+
+__global__ __launch_bounds__(256, 4) void attn_fwd_cls(const AttnClsArgs p) {
+    constexpr int STAGE_B = 2 * TILE_B;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const int nqt = (p.T + 127) >> 7, P = p.T - 1, ntile = P >> 6;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % p.H;
+    const int b = id / p.H;
+
+    const int qloc = qt * 128 + wave * 32 + lq;
+    const size_t qrow = (size_t)b * p.T + (qloc < p.T ? qloc : p.T - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(p.q + qrow * p.ldq + h * 64 + kk * 16 + hi * 8);
+
+    // ---- staging: every tile is full and in range, the cursors only advance
+    const int srow = tid >> 3;
+    const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
+    const bf16_t* kcur = p.k + h * 64 + lslot * 8 + ((size_t)b * p.T + 1 + srow) * p.ldk;
+    const bf16_t* vcur = p.vt + (size_t)(h * 64 + srow) * p.ldvt + lslot * 8 + (size_t)b * P;
+    const size_t kstep = (size_t)KT * p.ldk, khalf = (size_t)32 * p.ldk, vhalf = (size_t)32 * p.ldvt;
+    auto stage = [&](int buf) {
+        char* sk = smem + buf * STAGE_B + wave * 1024;
+        char* sv = sk + TILE_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(kcur + j * khalf, sk + j * 4096);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(vcur + j * vhalf, sv + j * 4096);
+        kcur += kstep; vcur += KT;
+    };
+    const int rsw = (lq >> 1) & 7;
+    const int rbase = lq * 128;
+
+    stage(0);
+    __syncthreads();
+    if (qt * 128 + wave * 32 >= p.T) {                         // an empty wave only stages its share and meets the barriers
+        for (int it = 0; it < ntile; ++it) {
+            if (it + 1 < ntile) stage((it & 1) ^ 1);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- the CLS key: s_cls = q . k_cls over this lane's half of the head (d = 16 kk + 8 hi .. + 8), the other half lives in lane ^ 32
+    float m_run, l_run;
+    f32x16 o[2], minit;
+    {
+        const bf16_t* kc = p.k + (size_t)b * p.T * p.ldk + h * 64 + hi * 8;
+        float dot = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x4 kw = *reinterpret_cast<const u32x4*>(kc + kk * 16);
+            const u32x4 qw = __builtin_bit_cast(u32x4, qf[kk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(bf_lo(qw[e]), bf_lo(kw[e]), __builtin_fmaf(bf_hi(qw[e]), bf_hi(kw[e]), dot));
+        }
+        dot += __shfl_xor(dot, 32);
+        m_run = dot;                                          // the reference: p_cls = 2^0
+        l_run = hi == 0 ? 1.f : 0.f;                          // the two halves of a row are added at the end: count the CLS key once
+        // O = p_cls * v_cls: lane holds O[q][d = 32 dt + 8 rg + 4 hi + e] in o[dt][4 rg + e]
+        const bf16_t* vc = p.vcls + (size_t)b * p.ldvc + h * 64 + hi * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const u32x2 vw = *reinterpret_cast<const u32x2*>(vc + dt * 32 + rg * 8);
+                o[dt][4 * rg + 0] = bf_lo(vw[0]); o[dt][4 * rg + 1] = bf_hi(vw[0]);
+                o[dt][4 * rg + 2] = bf_lo(vw[1]); o[dt][4 * rg + 3] = bf_hi(vw[1]);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) minit[r] = -m_run;
+    }
+
+    for (int it = 0; it < ntile; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < ntile) stage(cur ^ 1);
+        const char* sk = smem + cur * STAGE_B;
+        const char* sv = sk + TILE_B;
+        f32x16 s[2];
+        s[0] = minit; s[1] = minit;                           // the reference is subtracted inside the matrix pipe
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + kt2 * 4096 + rbase + (((2 * kk + hi) ^ rsw) << 4));
+                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt2], 0, 0, 0);
+            }
+        float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]), mloc1 = fmaxf(fmaxf(s[1][0], s[1][1]), s[1][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) {
+            mloc = fmaxf(fmaxf(mloc, s[0][r]), s[0][r + 1]);
+            mloc1 = fmaxf(fmaxf(mloc1, s[1][r]), s[1][r + 1]);
+        }
+        mloc = fmaxf(fmaxf(mloc, s[0][15]), fmaxf(mloc1, s[1][15]));
+        {
+            const unsigned u = __builtin_bit_cast(unsigned, mloc);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+        }
+        if (__any(mloc > (float)(VISREP_ATTN_V1_THR > 0 ? VISREP_ATTN_V1_THR : 0))) {     // wave-uniform: some row outgrew the reference by > 2^THR
+            const float delta = fmaxf(mloc, 0.f);
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt2][r] -= delta;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            m_run += delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) minit[r] = -m_run;
+        }
+        float psum = 0.f;
+        uint32_t pb[2][8];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kt2][r]), p1 = __builtin_amdgcn_exp2f(s[kt2][r + 1]);
+                psum += p0 + p1;
+                pb[kt2][r >> 1] = pack_bf16(p0, p1);
+            }
+        l_run += psum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 w = {pb[c >> 1][4 * (c & 1) + 0], pb[c >> 1][4 * (c & 1) + 1], pb[c >> 1][4 * (c & 1) + 2], pb[c >> 1][4 * (c & 1) + 3]};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + dt * 4096 + rbase + (((2 * c + hi) ^ rsw) << 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_run;
+    bf16_t* orow = p.out + ((size_t)b * p.T + (qloc < p.T ? qloc : p.T - 1)) * p.ldo + h * 64;
+    const bool wide = (p.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;          // uniform
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg += 2) {
+            u32x2 a = {pack_bf16(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv), pack_bf16(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv)};
+            u32x2 c = {pack_bf16(o[dt][4 * rg + 4] * inv, o[dt][4 * rg + 5] * inv), pack_bf16(o[dt][4 * rg + 6] * inv, o[dt][4 * rg + 7] * inv)};
+            if (wide) {
+                const auto w0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                if (qloc < p.T) {
+                    const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
+                    *reinterpret_cast<u32x4*>(orow + dt * 32 + (rg + hi) * 8) = q4;
+                }
+            } else if (qloc < p.T) {
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + rg * 8 + hi * 4) = a;
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + (rg + 1) * 8 + hi * 4) = c;
+            }
+        }
+}
+
 }  // namespace
 
 thread_local int t_visrep_attn_variant = 1;   // 1 = attn_fwd<ND> for every head width (default); 2 = attn_fwd_ab (attention_ab.hip, VISREP_EXPERIMENTS builds) for head width 64
@@ -342,6 +518,24 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
         hipLaunchKernelGGL(attn_fwd<3>, grid, block, lds, st, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "attention: launch failed");
+}
+
+extern "C" int visrep_mhsa_cls_supported(int T) { return T > 64 && (T - 1) % 64 == 0 ? 1 : 0; }
+
+// Image-aligned self-attention of a CLS tower with pre-scaled Q (attn_fwd_cls): qk as for visrep_mhsa_fwd; vt = V^T of the PATCH tokens,
+// column b (T - 1) + perm16(t - 1) (a row-mapped V projection writes it); vcls = the V projection of the CLS rows [B, ldvc].
+extern "C" int visrep_mhsa_cls_fwd(const void* qk, int ldqk, const void* vt, int ldvt, const void* vcls, int ldvc, void* out, int ldo, int B, int T, int H,
+                                   int head_dim, void* stream) {
+    if (head_dim != 64) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa_cls: only head_dim 64 is implemented");
+    if (!qk || !vt || !vcls || !out) return visrep_set_error(VISREP_ERR_ARG, "mhsa_cls: null pointer");
+    if (B <= 0 || H <= 0 || !visrep_mhsa_cls_supported(T)) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa_cls: needs T = 1 + a multiple of 64 (CLS + full key tiles)");
+    if ((ldqk % 8) || (ldvt % 64) || (ldo % 4) || (ldvc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "attention: bad leading dimension");
+    if (ldvt < B * (T - 1)) return visrep_set_error(VISREP_ERR_SHAPE, "mhsa_cls: ldvt must cover B (T - 1) columns");
+    AttnClsArgs a;
+    a.q = (const bf16_t*)qk; a.k = (const bf16_t*)qk + (size_t)H * 64; a.vt = (const bf16_t*)vt; a.vcls = (const bf16_t*)vcls; a.out = (bf16_t*)out;
+    a.B = B; a.T = T; a.H = H; a.ldq = ldqk; a.ldk = ldqk; a.ldvt = ldvt; a.ldvc = ldvc; a.ldo = ldo;
+    hipLaunchKernelGGL(attn_fwd_cls, dim3(((T + 127) / 128) * H * B), dim3(256), (size_t)4 * TILE_B, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mhsa_cls: launch failed");
 }
 
 extern "C" int visrep_mhsa_fwd(const void* qk, int ldqk, const void* vt, int ldvt, void* out, int ldo,

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
             pb[j] = b * p.cH * p.cW;
             ga[j] = p.A + lslot * 8;
         } else {
-            ga[j] = p.A + (size_t)ra * p.lda + kbase + lslot * 8;
+            ga[j] = p.A + (size_t)visrep_a_row(p, ra) * p.lda + kbase + lslot * 8;
         }
         int rw = n0 + j * 32 + srow;
         rw = rw < p.N ? rw : p.N - 1;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vt(const float* __restrict_
         if (m + e < p.M) {
             float a = part[(size_t)(m + e) * p.N + n];
             for (int s = 1; s < S; ++s) a += part[s * plane + (size_t)(m + e) * p.N + n];
-            if (p.ln_rt) { const float2 rt = p.ln_rt[m + e]; a = __builtin_fmaf(a, rt.x, rt.y * p.ln_s[n]); }
+            if (p.ln_rt) { const float2 rt = p.ln_rt[visrep_a_row(p, m + e)]; a = __builtin_fmaf(a, rt.x, rt.y * p.ln_s[n]); }
             v[e] = a + (p.bias ? p.bias[n] : 0.f);
         }
     }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     if (p.ln_rt) {                                             // LayerNorm folded into the GEMM: rstd * (acc - mean * s)
-        const float2 rt = p.ln_rt[m];
+        const float2 rt = p.ln_rt[visrep_a_row(p, m)];
         const float4 sv = *reinterpret_cast<const float4*>(p.ln_s + n);
         acc.x = __builtin_fmaf(acc.x, rt.x, rt.y * sv.x); acc.y = __builtin_fmaf(acc.y, rt.x, rt.y * sv.y);
         acc.z = __builtin_fmaf(acc.z, rt.x, rt.y * sv.z); acc.w = __builtin_fmaf(acc.w, rt.x, rt.y * sv.w);
@@ -409,6 +409,8 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: leading dimensions must keep 16-B row alignment");
     if (a.stat_rt && a.epi != EPI_RESID) return visrep_set_error(VISREP_ERR_ARG, "gemm: row statistics are an EPI_RESID feature");
+    if (a.a_period > 0 && (a.conv || a.epi == EPI_RESID || a.epi == EPI_PATCH || a.a_stride < a.a_period || a.a_first < 0))
+        return visrep_set_error(VISREP_ERR_ARG, "gemm: the A row map serves plain BIAS / ACT / VT / F32 epilogues only");
     const int variant = t_visrep_gemm_variant;
     {
         const int sk = run_split_k(a, s);
@@ -427,12 +429,13 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 GemmArgs head = a, tail = a;
                 head.M = m1;
                 tail.M = a.M - m1;
-                tail.A = a.A + (size_t)m1 * a.lda;
+                if (a.a_period > 0) tail.a_row0 = a.a_row0 + m1;              // row-mapped A: the map carries the offset, the pointers stay
+                else tail.A = a.A + (size_t)m1 * a.lda;
                 if (a.epi == EPI_VT) tail.C = a.C + m1;                  // V^T: token axis is the column axis (m1 % 16 == 0 keeps perm16)
                 else if (a.epi == EPI_F32) tail.C = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(a.C) + (size_t)m1 * a.ldc);
                 else tail.C = a.C + (size_t)m1 * a.ldc;
                 if (a.resid) tail.resid = a.resid + (size_t)m1 * a.ldc;
-                if (a.ln_rt) tail.ln_rt = a.ln_rt + m1;
+                if (a.ln_rt && a.a_period <= 0) tail.ln_rt = a.ln_rt + m1;
                 if (a.stat_rt) tail.stat_rt = a.stat_rt + m1;
                 const int rc = run_one(head, s, variant);
                 if (rc) return rc;

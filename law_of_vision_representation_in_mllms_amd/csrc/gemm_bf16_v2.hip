@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256(const GemmArgs p) {
         int m0, n0; tw.decode(c.ti, m0, n0);
         int r0 = m0 + wave * 32 + lrow, r1 = r0 + 16;
         r0 = r0 < p.M ? r0 : p.M - 1; r1 = r1 < p.M ? r1 : p.M - 1;
-        c.p0 = p.A + (size_t)r0 * p.lda + lslot * 8; c.p1 = p.A + (size_t)r1 * p.lda + lslot * 8;
+        c.p0 = p.A + (size_t)visrep_a_row(p, r0) * p.lda + lslot * 8; c.p1 = p.A + (size_t)visrep_a_row(p, r1) * p.lda + lslot * 8;
     };
     auto set_w = [&](Cur& c) {
         int m0, n0; tw.decode(c.ti, m0, n0);

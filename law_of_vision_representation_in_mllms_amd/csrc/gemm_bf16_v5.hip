@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             int r = m0 + wave * 32 + j * 8 + (lane >> 3);
             r = r < p.M ? r : p.M - 1;                           // rows past M are computed but never stored
-            c.p[j] = p.A + (size_t)r * p.lda + (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 3);
+            c.p[j] = p.A + (size_t)visrep_a_row(p, r) * p.lda + (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 3);
         }
     };
     auto set_w = [&](Cur& c) {

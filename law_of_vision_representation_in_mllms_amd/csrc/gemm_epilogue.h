@@ -123,7 +123,7 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int m = mb + i * RBLK + fr;
-            rt_all[i] = p.ln_rt[(EDGE && m >= p.M) ? p.M - 1 : m];
+            rt_all[i] = p.ln_rt[visrep_a_row(p, (EDGE && m >= p.M) ? p.M - 1 : m)];
         }
     }
     drain_visible_loads();
@@ -331,7 +331,9 @@ VR_DEV void gemm_epilogue_vt_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], i
 #pragma unroll
                 for (int q = 0; q < QN; ++q) {
                     const int m = mb + (i0 + i) * RBLK + q * 8 + hg * 4;
-                    const float4* src = reinterpret_cast<const float4*>(p.ln_rt + m);
+                    // four consecutive tokens: consecutive physical rows too (a row map's period is a multiple of 4).  Rows past M read the zero
+                    // padding of the statistics buffer; with a row map they are clamped to the last four rows instead (never stored either way)
+                    const float4* src = reinterpret_cast<const float4*>(p.ln_rt + visrep_a_row(p, (p.a_period > 0 && m + 4 > p.M) ? p.M - 4 : m));
                     ra[i * QN + q] = src[0];                // (rstd0, t0, rstd1, t1)
                     rb[i * QN + q] = src[1];                // (rstd2, t2, rstd3, t3)
                 }

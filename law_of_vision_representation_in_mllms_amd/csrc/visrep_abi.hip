@@ -82,6 +82,19 @@ extern "C" int visrep_gemm_bf16_ln(const void* A, int lda, const void* W, int ld
     return visrep_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+extern "C" int visrep_gemm_bf16_rows(const void* A, int lda, int row_period, int row_stride, int row_first, const void* W, int ldw,
+                                     const float* bias, const void* ln_rt, const float* ln_s, void* C, int ldc, int M, int N, int K, int epilogue,
+                                     int act, void* stream) {
+    if (!A || !W || !C || ((ln_rt == nullptr) != (ln_s == nullptr))) return visrep_set_error(VISREP_ERR_ARG, "gemm_rows: null pointer");
+    if (row_period <= 0 || row_stride < row_period || row_first < 0) return visrep_set_error(VISREP_ERR_ARG, "gemm_rows: bad row map");
+    if (epilogue == VISREP_EPI_VT && row_period % 4) return visrep_set_error(VISREP_ERR_ARG, "gemm_rows: EPI_VT needs row_period % 4 == 0");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.ln_rt = (const float2*)ln_rt; a.ln_s = ln_s;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.epi = epilogue; a.act = act;
+    a.a_period = row_period; a.a_stride = row_stride; a.a_first = row_first;
+    return visrep_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 extern "C" int visrep_gemm_bf16_resid_stats(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
                                             int K, const void* resid, const float* ls, void* rt, void* partial, float eps, void* stream) {
     if (!A || !W || !C || !resid || !rt || !partial) return visrep_set_error(VISREP_ERR_ARG, "gemm_resid_stats: null pointer");
@@ -117,7 +130,7 @@ extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, co
 namespace {
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Ws {
-    size_t h, qk, vt, mlp, rt, part, total;
+    size_t h, qk, vt, vcls, mlp, rt, part, total;
     int ldvt;
 };
 Ws layout(const visrep_vit_config* c, int B) {
@@ -129,6 +142,7 @@ Ws layout(const visrep_vit_config* c, int B) {
     w.h = off;   off += up(Mp * c->d * 2, 256);
     w.qk = off;  off += up(Mp * 2 * c->d * 2, 256);
     w.vt = off;  off += up((size_t)c->d * w.ldvt * 2, 256);
+    w.vcls = off; off += up((size_t)B * c->d * 2, 256);              // V rows of the CLS tokens (image-aligned attention)
     const size_t mlp_b = Mp * c->mlp * 2;
     const size_t cols_b = up((size_t)B * (c->tokens - c->has_cls), 128) * c->kpad * 2;
     w.mlp = off; off += up(mlp_b > cols_b ? mlp_b : cols_b, 256);   // im2col columns alias the MLP buffer
@@ -162,6 +176,7 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
     bf16_t* h = (bf16_t*)(base + L.h);
     bf16_t* qk = (bf16_t*)(base + L.qk);
     bf16_t* vt = (bf16_t*)(base + L.vt);
+    bf16_t* vcls = (bf16_t*)(base + L.vcls);
     bf16_t* mlp = (bf16_t*)(base + L.mlp);
     const int d = c->d, T = c->tokens, P = grid * grid, M = B * T;
 
@@ -183,6 +198,9 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
 
     float2* part = (float2*)(base + L.part);
     const float scale = c->q_prescaled ? 0.f : 0.125f;   // head_dim^-0.5, head_dim = 64; 0 = folded into the Q weights (attn_fwd PS)
+    // Image-aligned attention (attn_fwd_cls): the patch tokens of an image are whole key tiles and the CLS key is a side term, so V is
+    // projected by two row-mapped GEMMs - the patch rows into V^T (column b (T - 1) + t - 1), the CLS rows into vcls [B, d]
+    const bool aligned = c->q_prescaled >= 2 && c->has_cls && visrep_mhsa_cls_supported(T) && t_visrep_attn_variant == 1;
     bool rt_ready = false;        // rt already holds the statistics of x (left by the previous layer's fc2 GEMM)
     for (int l = 0; l < n_layers; ++l) {
         const visrep_vit_layer& W = w->layers[l];
@@ -203,8 +221,17 @@ extern "C" int visrep_vit_forward(const visrep_vit_config* c, const visrep_vit_w
         // V projection written transposed + perm16 for the attention kernel
         a.W = (const bf16_t*)W.wqkv + (size_t)2 * d * d; a.N = d; a.C = vt; a.ldc = L.ldvt; a.bias = W.bqkv + 2 * d; a.epi = EPI_VT;
         if (fold) a.ln_s = W.sqkv + 2 * d;
-        VR_TRY(visrep_gemm_dispatch(a, s));
-        VR_TRY(visrep_mhsa_fwd(qk, 2 * d, vt, L.ldvt, h, d, B, T, c->heads, 64, scale, stream));
+        if (aligned) {
+            GemmArgs v = a;
+            v.M = B * (T - 1); v.a_period = T - 1; v.a_stride = T; v.a_first = 1;
+            VR_TRY(visrep_gemm_dispatch(v, s));
+            v.M = B; v.a_period = 1; v.a_first = 0; v.C = vcls; v.ldc = d; v.epi = EPI_BIAS;
+            VR_TRY(visrep_gemm_dispatch(v, s));
+            VR_TRY(visrep_mhsa_cls_fwd(qk, 2 * d, vt, L.ldvt, vcls, d, h, d, B, T, c->heads, 64, stream));
+        } else {
+            VR_TRY(visrep_gemm_dispatch(a, s));
+            VR_TRY(visrep_mhsa_fwd(qk, 2 * d, vt, L.ldvt, h, d, B, T, c->heads, 64, scale, stream));
+        }
         // out projection + LayerScale + residual (in place on x)
         a.A = h; a.ln_rt = nullptr; a.ln_s = nullptr;
         a.W = (const bf16_t*)W.wo; a.N = d; a.C = x; a.ldc = d; a.bias = W.bo; a.epi = EPI_RESID; a.resid = x; a.ls = W.ls1;

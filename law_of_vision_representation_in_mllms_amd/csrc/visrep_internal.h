@@ -35,6 +35,12 @@ struct GemmArgs {
     int epi, act;
     int patches, tokens, cls_off;   // EPI_PATCH row remap
     int kslice;                     // split-K (v1, EPI_F32 only): blockIdx.y = slice, K elements per slice; 0 = no split
+    // Row map of the A operand (and of ln_rt, which is indexed like A's rows), a_period > 0: logical row r of this GEMM is the physical row
+    //   ((r + a_row0) / a_period) * a_stride + (r + a_row0) % a_period + a_first
+    // of A - "rows 1 .. T-1 of every image" (a_period = T - 1, a_stride = T, a_first = 1: the V projection over the patch tokens, written into
+    // image-aligned V^T columns) or "row 0 of every image" (a_period = 1, a_stride = T: the CLS tokens).  a_row0 carries the logical offset of
+    // a tail launch (the dispatcher does not shift A / ln_rt then).  0 = identity.
+    int a_period, a_stride, a_first, a_row0;
     // implicit 3x3 convolution (v1 kernel, conv = 1): A is the channels-last activation [B, cH, cW, cC] and the A tile of
     // K-tile (tap, c0) is gathered on the fly: row m = (b, oy, ox) reads x[b, (oy*cstride+ky-cpad)>>cup, (ox*cstride+kx-cpad)>>cup, c0..]
     int conv, cH, cW, cC, cHo, cWo, cstride, cpad, cup;
@@ -54,6 +60,13 @@ struct GemmArgs {
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };
 
+#ifdef __HIPCC__
+__device__ __forceinline__ int visrep_a_row(const GemmArgs& p, int r) {          // logical -> physical row of A / ln_rt
+    if (p.a_period <= 0) return r;
+    const int g = r + p.a_row0, q = g / p.a_period;
+    return q * p.a_stride + (g - q * p.a_period) + p.a_first;
+}
+#endif
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s);
 int visrep_ln_stats_finalize(const float2* partial, int slots, float2* rt, int rows, int d, float eps, hipStream_t s);
 bool visrep_gemm_v2_supports(const GemmArgs& a);

@@ -87,7 +87,9 @@ class VitEngine:
         self._layers = (_lib.VitLayer * max(n, 1))()
         # softmax scale in the exponent's base, folded into the Q rows of the Q|K|V projection (attn_fwd PS): q' = c * q with
         # c = head_dim^-0.5 * log2(e), so that 2^(q'.k) = e^(q.k / sqrt(head_dim)).  VISREP_Q_PRESCALE=0 keeps the scale in the kernel.
-        self.q_prescaled = os.environ.get("VISREP_Q_PRESCALE", "1") != "0"
+        # VISREP_Q_PRESCALE=2 (default) additionally lets towers with a CLS token and 64 n patches run the image-aligned attention kernel.
+        self._q_mode = int(os.environ.get("VISREP_Q_PRESCALE", "2"))
+        self.q_prescaled = self._q_mode != 0
         qc = torch.ones(3 * spec.d)
         if self.q_prescaled:
             qc[: spec.d] = 0.125 * 1.4426950408889634
@@ -126,7 +128,7 @@ class VitEngine:
             setattr(self._w, k, 0 if v is None else v.data_ptr())
         self._w.layers = C.cast(self._layers, C.POINTER(_lib.VitLayer))
         self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
-                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps), int(self.q_prescaled))
+                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps), self._q_mode)
         self._ws: Dict[int, torch.Tensor] = {}
         self._pinned = set()                 # batch sizes whose workspace a captured HIP graph refers to
 
@@ -412,6 +414,26 @@ def linear_vt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ou
     return out
 
 
+def gemm_rows(a: torch.Tensor, period: int, stride: int, first: int, rows: int, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              epilogue: int = _lib.EPI_BIAS, act: str = "none", ln_rt: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GEMM over a periodic subset of a's rows (visrep_gemm_bf16_rows): logical row r = physical (r // period) * stride + r % period + first.
+    EPI_VT returns / fills a V^T buffer [N, ld] (columns = logical rows, perm16), the others [rows, N]."""
+    lib = _lib.require_gpu()
+    N, K = w.shape[0], a.shape[1]
+    if (rows - 1) // period * stride + (rows - 1) % period + first >= a.shape[0]:
+        raise ValueError("gemm_rows: the row map reaches past a")
+    if out is None:
+        if epilogue == _lib.EPI_VT:
+            out = torch.zeros(N, _round_up(rows, 64) + 64, dtype=torch.bfloat16, device=a.device)
+        else:
+            out = torch.empty(rows, N, dtype=torch.float32 if epilogue == _lib.EPI_F32 else torch.bfloat16, device=a.device)
+    rc = lib.visrep_gemm_bf16_rows(_lib.ptr(a), a.stride(0), period, stride, first, _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(ln_rt),
+                                   _lib.ptr(ln_s), _lib.ptr(out), out.stride(0), rows, N, K, epilogue, _lib.ACT[act], _lib.stream_ptr())
+    _lib.check(rc, "visrep_gemm_bf16_rows")
+    return out
+
+
 def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
     lib = _lib.require_gpu()
     y = torch.empty_like(x)
@@ -427,4 +449,19 @@ def mhsa(qk: torch.Tensor, vt: torch.Tensor, B: int, T: int, H: int, scale: floa
     rc = lib.visrep_mhsa_fwd(_lib.ptr(qk), qk.stride(0), _lib.ptr(vt), vt.stride(0), _lib.ptr(out), out.stride(0), B, T, H, 64,
                              scale, _lib.stream_ptr())
     _lib.check(rc, "visrep_mhsa_fwd")
+    return out
+
+
+def mhsa_cls_supported(T: int) -> bool:
+    return bool(_lib.load().visrep_mhsa_cls_supported(int(T)))
+
+
+def mhsa_cls(qk: torch.Tensor, vt: torch.Tensor, vcls: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+    """Image-aligned self-attention (visrep_mhsa_cls_fwd): qk [B T, 2 H 64] with pre-scaled Q; vt = V^T of the patch tokens (column
+    b (T - 1) + t - 1, as linear_vt over the patch rows writes it); vcls = V rows of the CLS tokens [B, H 64]."""
+    lib = _lib.require_gpu()
+    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device=qk.device)
+    rc = lib.visrep_mhsa_cls_fwd(_lib.ptr(qk), qk.stride(0), _lib.ptr(vt), vt.stride(0), _lib.ptr(vcls), vcls.stride(0), _lib.ptr(out),
+                                 out.stride(0), B, T, H, 64, _lib.stream_ptr())
+    _lib.check(rc, "visrep_mhsa_cls_fwd")
     return out

@@ -53,7 +53,7 @@ class DiffImageProcessor(nn.Module):
         img_size: without the resize the images of a batch have different sizes."""
         if self.img_size[0] <= 0 or self.img_size[0] != self.img_size[1]:
             raise ValueError("the device input pipeline batches images: DiffImageProcessor needs a positive square img_size")
-        from ...... import device_preprocess as DP
+        from ..... import device_preprocess as DP
         side = int(self.img_size[0])
         return DP.DevicePreprocessor(side, side, [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], square_resize=True, device=device, dtype=dtype)
 

@@ -262,6 +262,86 @@ def test_attention_prescaled_q(B, T, H, spread):
     assert rel_err(out, plain) < (2e-2 if spread == 1.0 else 0.2)           # one more rounding of Q; peaked rows amplify it
 
 
+@pytest.mark.parametrize("B,T,H,spread", [(3, 577, 2, 1.0), (2, 257, 4, 1.0), (5, 65, 2, 1.0), (3, 321, 1, 6.0), (2, 129, 2, 25.0)])
+def test_attention_image_aligned(B, T, H, spread):
+    """visrep_mhsa_cls_fwd: patch keys as whole 64-key tiles of their image (V^T over the patch rows only, written by a row-mapped GEMM),
+    the CLS key as the initial state of the online softmax (V rows of the CLS tokens in their own buffer).  Same semantics as
+    visrep_mhsa_fwd with pre-scaled Q: compared with the fp32 softmax and with that kernel.  spread > 1: CLS scores far below / above the
+    patch scores (the reference starts AT the CLS score and has to move - or never moves - from there)."""
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    d = H * 64
+    M = B * T
+    assert engine.mhsa_cls_supported(T) and not engine.mhsa_cls_supported(T + 1) and not engine.mhsa_cls_supported(1)
+    q = torch.randn(M, d, generator=g) * spread
+    k = torch.randn(M, d, generator=g) * spread
+    if spread > 1:
+        q[::3] -= 2.0 * spread
+        k[T // 2:: 7] += 1.5 * spread
+        k[0::T][::2] += 3.0 * spread * torch.sign(q[0::T][::2])              # every other image: a CLS key that dominates its own query row
+    v = bf(torch.randn(M, d, generator=g))
+    c = 0.125 * 1.4426950408889634
+    qs = bf(q * c)
+    qk = torch.cat([qs, bf(k)], 1).to(DEV)
+    eye = bf(torch.eye(d)).to(DEV)
+    vd = v.to(DEV)
+    vt = engine.gemm_rows(vd, T - 1, T, 1, B * (T - 1), eye, None, epilogue=_lib.EPI_VT)       # patch rows -> V^T, image-aligned columns
+    vcls = engine.gemm_rows(vd, 1, T, 0, B, eye, None)                                          # CLS rows
+    assert torch.equal(vcls.cpu(), v[0::T])
+    out = engine.mhsa_cls(qk, vt, vcls, B, T, H)
+    qf, kf, vf = [t.float().view(B, T, H, 64).transpose(1, 2) for t in (qs, bf(k), v)]
+    want = (torch.softmax((qf @ kf.transpose(-1, -2)) * math.log(2.0), -1) @ vf).transpose(1, 2).reshape(M, d)
+    assert torch.isfinite(out.float()).all()
+    assert max_err(out, want) < 1.5e-2 and rel_err(out, want) < 1e-2
+    glob = engine.mhsa(qk, engine.linear_vt(vd, eye, None), B, T, H, 0.0)                       # the globally tiled kernel, same inputs
+    assert rel_err(out, glob) < 1e-2
+
+
+def test_attention_image_aligned_rejects_other_shapes():
+    qk = torch.zeros(2 * 50, 256, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(128, 192, dtype=torch.bfloat16, device=DEV)
+    vcls = torch.zeros(2, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        engine.mhsa_cls(qk, vt, vcls, 2, 50, 2)
+
+
+@pytest.mark.parametrize("period,stride,first,groups,N,K,epi", [(576, 577, 1, 3, 128, 256, "vt"), (1, 577, 0, 7, 192, 128, "bias"), (64, 65, 1, 37, 1024, 1024, "vt"),
+                                                               (256, 257, 1, 5, 2048, 1024, "act"), (100, 130, 7, 11, 256, 192, "bias")])
+def test_gemm_row_map(period, stride, first, groups, N, K, epi):
+    """visrep_gemm_bf16_rows == the plain GEMM on the gathered rows, BITWISE (same kernels, same order of accumulation; only the A row
+    addresses differ), with and without the folded LayerNorm (statistics indexed by physical row)."""
+    g = torch.Generator().manual_seed(period + N)
+    rows = period * groups
+    phys = (groups - 1) * stride + period + first + 3
+    a = bf(torch.randn(phys, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    idx = torch.tensor([(r // period) * stride + r % period + first for r in range(rows)], device=DEV)
+    gathered = a[idx].contiguous()
+    if epi == "vt":
+        got = engine.gemm_rows(a, period, stride, first, rows, w, bias, epilogue=_lib.EPI_VT)
+        want = engine.linear_vt(gathered, w, bias)
+    else:
+        act = "quick_gelu" if epi == "act" else "none"
+        e = _lib.EPI_ACT if epi == "act" else _lib.EPI_BIAS
+        got = engine.gemm_rows(a, period, stride, first, rows, w, bias, epilogue=e, act=act)
+        want = engine.gemm(gathered, w, bias, epilogue=e, act=act)
+    assert torch.equal(got, want)
+    # folded LayerNorm: rt per physical row
+    lib = _lib.require_gpu()
+    rt = torch.zeros(phys + 8, 2, dtype=torch.float32, device=DEV)
+    _lib.check(lib.visrep_layernorm_stats(_lib.ptr(a), a.stride(0), _lib.ptr(rt), phys, K, 1e-5, _lib.stream_ptr()), "stats")
+    s_n = w.float().sum(1).contiguous()
+    rt_g = torch.zeros(rows + 8, 2, dtype=torch.float32, device=DEV)
+    rt_g[:rows] = rt[idx]
+    e = {"vt": _lib.EPI_VT, "act": _lib.EPI_ACT, "bias": _lib.EPI_BIAS}[epi]
+    act = "quick_gelu" if epi == "act" else "none"
+    got = engine.gemm_rows(a, period, stride, first, rows, w, bias, epilogue=e, act=act, ln_rt=rt, ln_s=s_n)
+    want = torch.zeros_like(got)
+    _lib.check(lib.visrep_gemm_bf16_ln(_lib.ptr(gathered), gathered.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(rt_g), _lib.ptr(s_n),
+                                       _lib.ptr(want), want.stride(0), rows, N, K, e, _lib.ACT[act], _lib.stream_ptr()), "gemm_ln")
+    assert torch.equal(got, want)
+
+
 def test_attention_peaked_softmax(attn_variant):
     # one key dominates each query by a huge margin: exercises the running-max rescale path at every tile
     B, T, H, d = 2, 300, 2, 128

@@ -56,6 +56,8 @@ def test_diffusion_spec_tables_and_image_processor():
     img = Image.fromarray(np.full((10, 14, 3), 255, np.uint8))
     px = DE.DiffImageProcessor([8, 8]).preprocess(img)["pixel_values"][0]
     assert px.shape == (3, 8, 8) and float(px.min()) == 1.0
+    twin = DE.DiffImageProcessor([8, 8]).device_twin("cpu")                            # the device-side twin is constructible on any host
+    assert type(twin).__name__ == "DevicePreprocessor"
 
 
 def test_delay_load_gives_config_only_tower():

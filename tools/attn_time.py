@@ -19,7 +19,10 @@ w = (torch.randn(d, d, device="cuda") * 0.03).to(torch.bfloat16)
 vt = engine.linear_vt(x, w, None)
 tag = os.path.basename(os.environ.get("VISREP_LIB", "default"))
 ref = None
-for name, fn in (("classic", lambda: engine.mhsa(qk, vt, B, T, H, 0.125)), ("pre-scaled Q", lambda: engine.mhsa(qk_ps, vt, B, T, H, 0.0))):
+vt_p = engine.gemm_rows(x, T - 1, T, 1, B * (T - 1), w, None, epilogue=_lib.EPI_VT)        # patch rows only, image-aligned columns
+vcls = engine.gemm_rows(x, 1, T, 0, B, w, None)
+for name, fn in (("classic", lambda: engine.mhsa(qk, vt, B, T, H, 0.125)), ("pre-scaled Q", lambda: engine.mhsa(qk_ps, vt, B, T, H, 0.0)),
+                 ("image-aligned", lambda: engine.mhsa_cls(qk_ps, vt_p, vcls, B, T, H))):
     for _ in range(10): out = fn()
     torch.cuda.synchronize()
     if ref is None: ref = out.float()
