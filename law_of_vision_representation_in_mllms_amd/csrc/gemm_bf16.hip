@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
         ra = ra < p.M ? ra : p.M - 1;                          // clamp: rows past M are computed but never stored
         if (CONV) {
             const int hw = p.cHo * p.cWo;
-            const int b = ra / hw, pix = ra - b * hw;
+            const int rc = ra + p.a_row0;                      // a tail launch of the dispatcher: its rows follow the head's
+            const int b = rc / hw, pix = rc - b * hw;
             const int oy = pix / p.cWo, ox = pix - oy * p.cWo;
             iy0[j] = oy * p.cstride - p.cpad;
             ix0[j] = ox * p.cstride - p.cpad;
@@ -296,7 +297,10 @@ int visrep_scratch_register(bool any_stream, hipStream_t s, void* ptr, size_t by
 
 namespace {
 int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
-    if (a.conv) {                                              // implicit 3x3 convolution: 128x128 kernel only
+    if (a.conv) {                                              // implicit 3x3 convolution: the 256x256 kernel when whole rounds of its tiles exist
+#ifndef VISREP_NO_CONV5                                           // A/B builds (tools/): every convolution on the 128x128 kernel, as until round 4
+        if (variant == 5 && visrep_gemm_v5_supports_conv(a) && (long)((a.M + 255) / 256) * (a.N / 256) >= 2L * visrep_cu_count()) return visrep_gemm_v5_dispatch(a, s);
+#endif
         switch (a.epi) {
             case EPI_BIAS: return launch<EPI_BIAS, true>(a, s);
             case EPI_RESID: return launch<EPI_RESID, true>(a, s);
@@ -404,6 +408,16 @@ int run_split_k(const GemmArgs& a, hipStream_t s) {              // 1 = handled,
 }
 }  // namespace
 
+namespace {
+bool conv5_ok(const GemmArgs& a, int variant) {
+#ifdef VISREP_NO_CONV5
+    return false;
+#else
+    return variant == 5 && visrep_gemm_v5_supports_conv(a);
+#endif
+}
+}  // namespace
+
 int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: empty problem");
     if (a.N % 64 != 0 || a.K % BK != 0) return visrep_set_error(VISREP_ERR_SHAPE, "gemm: N and K must be multiples of 64");
@@ -420,7 +434,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     // The BASELINE shapes have M = 256 * 577 (577 is prime): 2308 / 4616 / 9232 tiles = 9 / 18 / 36 full rounds + a 4..16-tile
     // remainder that would cost a whole extra round on 252 idle CUs.  When the remainder is small, the rows of the last
     // round are split off and run as 128x128 tiles (v1), which spread over many CUs and finish in a fraction of a round.
-    if (variant >= 2 && a.N % 256 == 0 && a.epi != EPI_PATCH && !a.conv) {
+    if (variant >= 2 && a.N % 256 == 0 && a.epi != EPI_PATCH && (!a.conv || conv5_ok(a, variant))) {
         const int ncu = cu_count(), ntn = a.N / 256, ntm = (a.M + 255) / 256;
         const long tiles = (long)ntm * ntn, rounds = tiles / ncu, rem = tiles % ncu;
         if (rounds >= 1 && rem > 0 && rem * 4 <= ncu && (rounds * ncu) % ntn == 0) {
@@ -429,7 +443,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 GemmArgs head = a, tail = a;
                 head.M = m1;
                 tail.M = a.M - m1;
-                if (a.a_period > 0) tail.a_row0 = a.a_row0 + m1;              // row-mapped A: the map carries the offset, the pointers stay
+                if (a.a_period > 0 || a.conv) tail.a_row0 = a.a_row0 + m1;   // row-mapped A / convolution: the map carries the offset, the pointers stay
                 else tail.A = a.A + (size_t)m1 * a.lda;
                 if (a.epi == EPI_VT) tail.C = a.C + m1;                  // V^T: token axis is the column axis (m1 % 16 == 0 keeps perm16)
                 else if (a.epi == EPI_F32) tail.C = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(a.C) + (size_t)m1 * a.ldc);

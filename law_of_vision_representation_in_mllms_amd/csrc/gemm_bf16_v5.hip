@@ -143,7 +143,13 @@ struct TileWalk {           // the block's list of output tiles: chunk of its XC
     }
 };
 
-template <int EPI, bool OWN_>
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page5[4] = {0u, 0u, 0u, 0u};   // source of padded (out-of-image) conv taps
+
+// CONV_ (round 4): implicit 3x3 convolution (NHWC, K index = tap * C + channel, C % 64 == 0 so a K-tile lies inside one tap; stride 1 | 2,
+// symmetric or (0,1,0,1) padding, no upsampling): the X rows are output pixels, a lane's four row cursors point at the pixel's top-left tap
+// and carry a 9-bit "tap is inside the image" mask; per K-tile the tap's offset (ky W + kx) C + c0 is one scalar and a lane whose tap is
+// padding fetches the zero page instead.  W, the ring, the ledger and the epilogues are the plain GEMM's.
+template <int EPI, bool OWN_, bool CONV_ = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,21 +180,55 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     // EPI_F32X: K = nprod * ksplit walks the (A plane, W plane) pairs of p.tab_a / p.tab_w (two bits per segment); the logical position k maps
     // to column plane * ksplit + (k mod ksplit) of the operand's [rows, nplanes * ksplit] plane matrix
     constexpr bool SPLIT = EPI == EPI_F32X;
-    struct Cur { const bf16_t* p[4]; int k, ti, idx, kin, seg; };
+    static_assert(!(CONV_ && (SPLIT || OWN_)), "the convolution gather exists for the plain staging scheme only");
+    struct Cur { const bf16_t* p[4]; int k, ti, idx, kin, seg; int xo[4]; unsigned mk[2]; };     // xo / mk: CONV only (element offsets, 2 x 9-bit tap masks per word)
     Cur cx, cw;
     auto col_of = [&](const Cur& c, unsigned tab) { return SPLIT ? (int)((tab >> (2 * c.seg)) & 3u) * p.ksplit + c.kin : c.k; };
+    const int seg_len = CONV_ ? p.cC : p.ksplit;              // CONV: seg = tap, kin = channel offset inside the tap
     auto advance = [&](Cur& c) {
         ++c.idx; c.k += TK;
-        if (SPLIT) { c.kin += TK; if (c.kin == p.ksplit) { c.kin = 0; ++c.seg; } }
+        if (SPLIT || CONV_) { c.kin += TK; if (c.kin == seg_len) { c.kin = 0; ++c.seg; } }
     };
     auto set_x = [&](Cur& c) {
         int m0, n0; tw.decode(c.ti, m0, n0);
+        if (CONV_) {
+            // rows r0 + 8 j (j = 0..3): one division for the first, the others step 8 pixels along the output raster (cWo >= 8: one wrap at most).
+            // Rows past M get an empty mask (zero page for every tap): their pixel may lie past the last image.
+            const int r0 = m0 + wave * 32 + (lane >> 3);
+            const int hw = p.cHo * p.cWo;
+            const int g = r0 + p.a_row0;
+            int b = g / hw;
+            const int pix = g - b * hw;
+            int oy = pix / p.cWo, ox = pix - oy * p.cWo;
+            c.mk[0] = c.mk[1] = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy0 = oy * p.cstride - p.cpad, ix0 = ox * p.cstride - p.cpad;
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    mk |= (unsigned)((unsigned)(iy0 + t / 3) < (unsigned)p.cH && (unsigned)(ix0 + t % 3) < (unsigned)p.cW) << t;
+                if (r0 + 8 * j >= p.M) mk = 0u;
+                c.mk[j >> 1] |= mk << (16 * (j & 1));
+                c.xo[j] = ((b * p.cH + iy0) * p.cW + ix0) * p.cC + ((((lane & 7) ^ ((4 * j + (lane >> 4)) & 7))) << 3);   // top-left tap (used only where the mask allows)
+                ox += 8;
+                if (ox >= p.cWo) { ox -= p.cWo; if (++oy == p.cHo) { oy = 0; ++b; } }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int r = m0 + wave * 32 + j * 8 + (lane >> 3);
             r = r < p.M ? r : p.M - 1;                           // rows past M are computed but never stored
             c.p[j] = p.A + (size_t)visrep_a_row(p, r) * p.lda + (((lane & 7) ^ ((4 * j + (lane >> 4)) & 7)) << 3);
         }
+    };
+    // the source of piece j for the K-tile the cursor stands on (CONV: tap = seg, channels kin .. kin + 64)
+    auto x_src = [&](const Cur& c, int j, int kc) -> const bf16_t* {
+        if (!CONV_) return c.p[j] + kc;
+        const int ky = (c.seg >= 3) + (c.seg >= 6), kx = c.seg - 3 * ky;
+        const int off = (ky * p.cW + kx) * p.cC + c.kin;       // uniform
+        return ((c.mk[j >> 1] >> (c.seg + 16 * (j & 1))) & 1u) ? p.A + (ptrdiff_t)(c.xo[j] + off) : reinterpret_cast<const bf16_t*>(g_zero_page5);
     };
     auto set_w = [&](Cur& c) {
         int m0, n0; tw.decode(c.ti, m0, n0);
@@ -208,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         char* dst = smem + ((2 * cx.idx) % NSLOT) * XW_BYTES + wave * 4096;
         const int kc = col_of(cx, p.tab_a);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(cx.p[j] + kc, dst + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16(x_src(cx, j, kc), dst + j * 1024);
         advance(cx);
         if (cx.k == p.K) { cx.k = 0; cx.kin = 0; cx.seg = 0; ++cx.ti; set_x(cx); }
     };
@@ -231,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     // piece-wise forms of issue_x / issue_w (V5_DMA_IN_M): piece j of the pending item, the cursor advances with the last piece
     auto issue_x_piece = [&](int j) {
         char* dst = smem + ((2 * cx.idx) % NSLOT) * XW_BYTES + wave * 4096;
-        glds16(cx.p[j] + col_of(cx, p.tab_a), dst + j * 1024);
+        glds16(x_src(cx, j, col_of(cx, p.tab_a)), dst + j * 1024);
         if (j == 3) {
             advance(cx);
             if (cx.k == p.K) { cx.k = 0; cx.kin = 0; cx.seg = 0; ++cx.ti; set_x(cx); }
@@ -343,14 +383,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     wait_vm0();                                                // drain the (unused) run-ahead loads before exit
 }
 
-template <int EPI, bool OWN_>
+template <int EPI, bool OWN_, bool CONV_ = false>
 int launch5o(const GemmArgs& a, hipStream_t s) {
     static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device)
-    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_>), LDS2);
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_, CONV_>), LDS2);
     const int ncu = visrep_cu_count();
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_>), dim3(grid), dim3(512), LDS2, s, a);
+    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_, CONV_>), dim3(grid), dim3(512), LDS2, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
 
@@ -366,7 +406,17 @@ bool visrep_gemm_v5_supports(const GemmArgs& a) {
     return a.N % TN == 0 && a.K % TK == 0;
 }
 
+// implicit 3x3 convolution in the 256x256 kernel: whole column tiles, 64-channel K-tiles inside one tap, no upsampled source
+bool visrep_gemm_v5_supports_conv(const GemmArgs& a) {
+    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && (a.epi == EPI_BIAS || a.epi == EPI_RESID) &&
+           (long)a.M / (a.cHo * a.cWo) * a.cH * a.cW * a.cC < (1L << 31) - (3L * a.cW + 3) * a.cC;     // 32-bit element offsets
+}
+
 int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s) {
+    if (a.conv) {
+        if (!visrep_gemm_v5_supports_conv(a)) return visrep_set_error(VISREP_ERR_ARG, "gemm v5: unsupported convolution");
+        return a.epi == EPI_BIAS ? launch5o<EPI_BIAS, false, true>(a, s) : launch5o<EPI_RESID, false, true>(a, s);
+    }
     switch (a.epi) {
         case EPI_PATCH: return launch5<EPI_PATCH>(a, s);
         case EPI_BIAS: return launch5<EPI_BIAS>(a, s);

@@ -74,6 +74,7 @@ int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v4_supports(const GemmArgs& a);
 int visrep_gemm_v4_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v5_supports(const GemmArgs& a);
+bool visrep_gemm_v5_supports_conv(const GemmArgs& a);
 int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v3_supports(const GemmArgs& a);
 int visrep_gemm_v3_dispatch(const GemmArgs& a, hipStream_t s);

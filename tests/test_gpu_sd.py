@@ -107,6 +107,46 @@ def test_conv3x3_implicit_gemm(B, H, W, Ci, Co, stride, pad_mode, up):
     assert rel_err(o, tokens(want - b[None, :, None, None])) < 5e-3
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,pad_mode", [(4, 192, 192, 64, 256, 1, 0),      # 576 tiles: 2 full rounds + a 64-tile remainder (tail launch, row offset)
+                                                        (9, 128, 120, 128, 256, 1, 0),     # 540 tiles, W % 8 == 0 but rows wrap inside a lane's four pieces
+                                                        (5, 301, 223, 64, 256, 2, 1),      # stride 2, (0,1,0,1) padding, odd sizes, M % 256 != 0
+                                                        (3, 150, 147, 64, 512, 2, 0),      # two column tiles, stride 2 symmetric
+                                                        (2, 260, 259, 128, 256, 1, 0)])
+def test_conv3x3_in_the_256_kernel(B, H, W, Ci, Co, stride, pad_mode):
+    """Shapes with >= 2 rounds of 256x256 tiles take the persistent ping-pong kernel (gemm_bf16_256q<EPI, false, CONV>): equal to the 128x128
+    kernel's result BITWISE (same K order, same MFMA shape, fp32 accumulation) and to F.conv2d within the bf16 tolerance; BIAS and RESID."""
+    g = torch.Generator().manual_seed(H + W + Ci)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = torch.randn(Co, generator=g) * 0.1
+    if pad_mode == 1:
+        want = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b, stride=stride, padding=0)
+    else:
+        want = F.conv2d(x.float(), w.float(), b, stride=stride, padding=1)
+    wp = bf(w.float().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)).to(DEV)
+    xt = tokens(x).to(DEV)
+    lib = _lib.load()
+    got, Ho, Wo = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_BIAS)
+    assert (Ho, Wo) == tuple(want.shape[2:]) and (B * Ho * Wo + 255) // 256 * (Co // 256) >= 512
+    res = bf(torch.randn(B * Ho * Wo, Co, generator=g)).to(DEV)
+    got_r, _, _ = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_RESID, resid=res)
+    lib.visrep_set_gemm_variant(1)
+    try:
+        small, _, _ = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_BIAS)
+        small_r, _, _ = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_RESID, resid=res)
+    finally:
+        lib.visrep_set_gemm_variant(5)
+    # the rows of the whole tile rounds are bitwise the 128x128 kernel's; the remainder rows (a 128x128 tail launch, split-K when K >= 1024:
+    # another summation order) agree to rounding
+    ntn, ntm = Co // 256, (B * Ho * Wo + 255) // 256
+    head = (ntm * ntn) // 256 * 256 // ntn * 256
+    assert head >= 2 * 256 * 256 // ntn
+    assert torch.equal(got[:head], small[:head]) and torch.equal(got_r[:head], small_r[:head])
+    assert (got.float() - small.float()).abs().max().item() < 2e-2 and (got_r.float() - small_r.float()).abs().max().item() < 4e-2
+    assert rel_err(got, tokens(want)) < 5e-3
+    assert rel_err(got_r, res.float().cpu() + tokens(want)) < 5e-3
+
+
 def test_conv3x3_rejects_narrow_channels():
     x = torch.zeros(64, 8, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="multiple of 64"):
