@@ -109,8 +109,8 @@ def test_conv3x3_implicit_gemm(B, H, W, Ci, Co, stride, pad_mode, up):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride,pad_mode", [(4, 192, 192, 64, 256, 1, 0),      # 576 tiles: 2 full rounds + a 64-tile remainder (tail launch, row offset)
                                                         (9, 128, 120, 128, 256, 1, 0),     # 540 tiles, W % 8 == 0 but rows wrap inside a lane's four pieces
-                                                        (5, 301, 223, 64, 256, 2, 1),      # stride 2, (0,1,0,1) padding, odd sizes, M % 256 != 0
-                                                        (3, 150, 147, 64, 512, 2, 0),      # two column tiles, stride 2 symmetric
+                                                        (8, 301, 223, 64, 256, 2, 1),      # stride 2, (0,1,0,1) padding, odd sizes, M % 256 != 0
+                                                        (12, 150, 147, 64, 512, 2, 0),     # two column tiles, stride 2 symmetric
                                                         (2, 260, 259, 128, 256, 1, 0)])
 def test_conv3x3_in_the_256_kernel(B, H, W, Ci, Co, stride, pad_mode):
     """Shapes with >= 2 rounds of 256x256 tiles take the persistent ping-pong kernel (gemm_bf16_256q<EPI, false, CONV>): equal to the 128x128
