@@ -135,7 +135,9 @@ int visrep_mhsa_cls_fwd(const void* qk, int ldqk, const void* vt, int ldvt, cons
  * q: [B*Tq, ldq] bf16, head h in columns [h*head_dim, (h+1)*head_dim); k: [B*Tk, ldk] likewise ([Tk, ldk] when
  * kv_shared = 1: one key/value sequence - the prompt - serves every batch item); vt: [H*head_dim, ldvt] as written by
  * VISREP_EPI_VT over the key rows, ldvt >= round_up(key rows, 64); out: [B*Tq, ldo].  head_dim in {64, 128, 192}: the
- * weight packer zero-pads narrower heads (SD1.5: 40 / 80 / 160), which changes nothing in softmax(QK^T)V.
+ * weight packer zero-pads narrower heads (SD1.5: 40 / 80 / 160), which changes nothing in softmax(QK^T)V.  head_dim 512 (the single head of
+ * the diffusion VAE's mid-block attention, AutoencoderKL: 9216 latent pixels at 768 px) runs a wide-head kernel that needs whole key tiles
+ * (Tk % 64 == 0), causal = 0 and scale > 0.
  * causal = 1 masks keys after the query position (HF CLIPTextTransformer's causal mask: the prompt encoder behind
  * pipe.encode_prompt, dift_sd.py:258-263).  scale <= 0 (head_dim 64 only): pre-scaled Q, as for visrep_mhsa_fwd. */
 int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo, int B, int Tq,

@@ -461,6 +461,233 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_cls(const AttnClsArgs p) {
         }
 }
 
+
+// ---- wide-head attention (head width D = 64 ND up to 512: the single 512-wide head of the diffusion VAE's mid-block attention over all 9216
+// latent pixels, AutoencoderKL encoder).  The flash loop of attn_fwd with the register file of ONE wave per SIMD: 32 Q fragments (128 VGPRs) and
+// the 32 x 512 output accumulators (256 registers) stay resident; a K tile and a V^T tile (64 keys x 512 = 64 KB each) are single-buffered
+// and refilled alternately - K(t+1) streams in under tile t's softmax and P.V, V^T(t+1) under tile t+1's Q.K^T - with counted vmcnt waits
+// (the LDS-DMA queue is in order: K(t+1) was issued before V^T(t+1), V^T(t) before K(t+1)).  Fragment reads are hand-written ds_read_b128
+// (hipcc would otherwise put an s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA issue and serialise the refills).
+// Key tiles must be whole (Tk % 64 == 0): no masks.  Replaces the materialised-score route (fp32 [T, T] scores per image through the GEMM
+// kernel, softmax_rows, P.V GEMM: ~1 GB of HBM traffic per image at T = 9216).
+VR_DEV unsigned attn_lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+VR_DEV void lds_read4(bf16x8 (&f)[4], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+VR_DEV void lds_wait4(bf16x8 (&f)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); }
+
+template <int ND, int NDO>                  // NDO = 64-wide blocks of the head a workgroup accumulates O for (the register budget: 32 x 64 NDO fp32 per wave)
+__global__ __launch_bounds__(256, 1) void attn_fwd_wide(const AttnArgs p) {
+    constexpr int D = 64 * ND, KV_B = ND * TILE_B, NPK = 2 * ND, NPV = 2 * NDO;      // LDS-DMA pieces per wave: K tile / V^T tile
+    static_assert(NPK <= 31 && ND % NDO == 0, "the counted waits below encode the piece counts in vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // K tile | V^T tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const int nqt = (p.Tq + 127) >> 7;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int dh = id % (ND / NDO); id /= (ND / NDO);          // which slice of the head's width this workgroup produces (Q.K^T is over all of it)
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % p.H;
+    const int b = id / p.H;
+    const int tok0 = p.kv_shared ? 0 : b * p.Tk;
+    const int ntile = p.Tk >> 6;
+
+    const int qloc = qt * 128 + wave * 32 + lq;
+    const size_t qrow = (size_t)b * p.Tq + (qloc < p.Tq ? qloc : p.Tq - 1);
+    bf16x8 qf[4 * ND];
+#pragma unroll
+    for (int kk = 0; kk < 4 * ND; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(p.q + qrow * p.ldq + h * D + kk * 16 + hi * 8);
+
+    // Staging addresses = a wave-uniform tile / piece base (scalar registers, scalar arithmetic) + ONE 32-bit per-lane byte offset per operand:
+    // with a 64-bit per-lane pointer per piece the 24 pieces of a tile pair cost 48 registers of loop-invariant addresses (spilled).
+    const int srow = tid >> 3;
+    const int lslot = (tid & 7) ^ ((srow >> 1) & 7);
+    const unsigned koff = (unsigned)(srow * p.ldk + lslot * 8) * 2u, voff = (unsigned)(srow * p.ldvt + lslot * 8) * 2u;
+    const char* const kbase_g = reinterpret_cast<const char*>(p.k + h * D + (size_t)tok0 * p.ldk);
+    const char* const vbase_g = reinterpret_cast<const char*>(p.vt + (size_t)(h * D + dh * NDO * 64) * p.ldvt + tok0);
+    const size_t kstep = (size_t)KT * p.ldk * 2, khalf = (size_t)32 * p.ldk * 2, vhalf = (size_t)32 * p.ldvt * 2;
+    char* const sk_w = smem + wave * 1024;
+    char* const sv_w = smem + KV_B + wave * 1024;
+    int kt_next = 0, vt_next = 0;                              // next tile to stage (uniform)
+    auto stage_k = [&]() {
+        const char* const t = kbase_g + (size_t)kt_next * kstep;
+        unsigned ko = koff;
+        asm volatile("" : "+v"(ko));                            // opaque per call: keeps "piece base + lane offset" a two-instruction add per piece
+#pragma unroll                                                  // instead of 16 hoisted (and spilled) 64-bit per-lane addresses
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(t + j * khalf + nd * 128 + (size_t)ko, sk_w + nd * TILE_B + j * 4096);
+        ++kt_next;
+    };
+    auto stage_v = [&]() {
+        const char* const t = vbase_g + (size_t)vt_next * (KT * 2);
+        unsigned vo = voff;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int nd = 0; nd < NDO; ++nd)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(t + (size_t)(2 * nd + j) * vhalf + (size_t)vo, sv_w + nd * TILE_B + j * 4096);
+        ++vt_next;
+    };
+    auto wait_k = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPV) : "memory"); };     // K(t) landed: only the V^T pieces issued after it may be pending
+    auto wait_v = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPK) : "memory"); };     // V^T(t) landed: only K(t + 1) may be pending
+    auto wait_0 = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int rsw = (lq >> 1) & 7;
+    const unsigned kbase = attn_lds_addr(smem) + lq * 128, vbase = kbase + KV_B;
+    unsigned foff[8];                                          // byte offset of logical 16-byte slot 2 c + hi (c = 0..3), + 4096 for the second 32 rows
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { foff[c] = ((2 * c + hi) ^ rsw) << 4; foff[4 + c] = foff[c] + 4096; }
+
+    // Softmax reference.  O is never rescaled inside the tile loop: a VALU multiply of the accumulators in the loop body makes the register
+    // allocator move all of O (128 accumulation registers) into the architectural file at every loop entry, which evicts the Q fragments to
+    // scratch.  Instead every row's exponentials are taken against a FIXED reference m_ref - the row's maximum over the first key tile, a lower
+    // bound of the row's true maximum - so p = 2^((s - m_ref) sc) >= 1 for the largest key (no underflow of the sums) and fp32 / bf16 hold it up
+    // to 2^127: only a row whose later scores exceed its first tile's by more than 2^100 could overflow.  The true running maximum is tracked on
+    // the side; if any row of the workgroup crossed that bound the whole pass is repeated once with m_ref = the true maximum (then p <= 1).
+    f32x16 o[2 * NDO];
+    float m_ref = 0.f, m_true = 0.f, l_run = 0.f;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+#pragma unroll
+    for (int dt = 0; dt < 2 * NDO; ++dt) o[dt] = f32x16{};
+    l_run = 0.f;
+    kt_next = 0; vt_next = 0;
+    stage_k();
+    stage_v();
+    for (int it = 0; it < ntile; ++it) {
+        const bool more = it + 1 < ntile;                      // uniform
+        // ---- K(it) has landed everywhere (V^T(it), issued after it, may still be in flight)
+        wait_k();
+        bar();
+        f32x16 s[2];
+        s[0] = f32x16{}; s[1] = f32x16{};
+        {
+            bf16x8 fa[4], fb[4];
+            // S^T += K[kt2 * 32 + lq][16 kk + 8 hi ..] . Q: groups of four fragment reads = (kk, kk + 1) x (kt2 = 0, 1), one group ahead
+            lds_read4(fa, kbase + foff[0], kbase + foff[4], kbase + foff[1], kbase + foff[5]);
+#pragma unroll
+            for (int g = 0; g < 2 * ND; ++g) {                 // group g: kk = 2 g, 2 g + 1
+                bf16x8 (&cur)[4] = (g & 1) ? fb : fa;
+                bf16x8 (&nxt)[4] = (g & 1) ? fa : fb;
+                lds_wait4(cur);
+                if (g + 1 < 2 * ND) {
+                    const int k2 = 2 * (g + 1);
+                    const unsigned t = kbase + (k2 >> 2) * TILE_B;
+                    lds_read4(nxt, t + foff[k2 & 3], t + foff[4 + (k2 & 3)], t + foff[(k2 + 1) & 3], t + foff[4 + ((k2 + 1) & 3)]);
+                }
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], qf[2 * g], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], qf[2 * g], s[1], 0, 0, 0);
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[2], qf[2 * g + 1], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3], qf[2 * g + 1], s[1], 0, 0, 0);
+            }
+        }
+        // ---- every wave is done with the K tile: refill it (under the softmax and P.V of this tile)
+        bar();
+        if (more) stage_k();
+        uint32_t pb[2][8];
+        {
+            float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]), mloc1 = fmaxf(fmaxf(s[1][0], s[1][1]), s[1][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) {
+                mloc = fmaxf(fmaxf(mloc, s[0][r]), s[0][r + 1]);
+                mloc1 = fmaxf(fmaxf(mloc1, s[1][r]), s[1][r + 1]);
+            }
+            mloc = fmaxf(fmaxf(mloc, s[0][15]), fmaxf(mloc1, s[1][15]));
+            {
+                const unsigned u = __builtin_bit_cast(unsigned, mloc);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mloc = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+            }
+            if (it == 0) {                                      // uniform
+                if (attempt == 0) m_ref = mloc;
+                m_true = mloc;
+            } else {
+                m_true = fmaxf(m_true, mloc);
+            }
+            const float msc = m_ref * p.sc;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r], p.sc, -msc));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][r + 1], p.sc, -msc));
+                    psum += p0 + p1;
+                    pb[kt2][r >> 1] = pack_bf16(p0, p1);
+                }
+            l_run += psum;
+        }
+        // ---- V^T(it) has landed everywhere (K(it + 1) may be in flight)
+        if (more) wait_v(); else wait_0();
+        bar();
+        {
+            bf16x8 pf[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4 w = {pb[c >> 1][4 * (c & 1) + 0], pb[c >> 1][4 * (c & 1) + 1], pb[c >> 1][4 * (c & 1) + 2], pb[c >> 1][4 * (c & 1) + 3]};
+                pf[c] = __builtin_bit_cast(bf16x8, w);
+            }
+            // O^T[dt] += V^T[dt * 32 + lq][16 c + ..] . P: one group = the four key chunks c of one 32-row block dt
+            bf16x8 fa[4], fb[4];
+            lds_read4(fa, vbase + foff[0], vbase + foff[1], vbase + foff[2], vbase + foff[3]);
+#pragma unroll
+            for (int dt = 0; dt < 2 * NDO; ++dt) {
+                bf16x8 (&cur)[4] = (dt & 1) ? fb : fa;
+                bf16x8 (&nxt)[4] = (dt & 1) ? fa : fb;
+                lds_wait4(cur);
+                if (dt + 1 < 2 * NDO) {
+                    const unsigned t = vbase + ((dt + 1) >> 1) * TILE_B + ((dt + 1) & 1) * 4096;
+                    lds_read4(nxt, t + foff[0], t + foff[1], t + foff[2], t + foff[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[c], pf[c], o[dt], 0, 0, 0);
+            }
+        }
+        // ---- every wave is done with the V^T tile: refill it (under the next tile's Q.K^T)
+        bar();
+        if (more) stage_v();
+    }
+    // ---- did any row of the workgroup outgrow its reference by more than 2^100 ?  (block-uniform: the waves share the tiles and the barriers)
+    const bool over = __any((m_true - m_ref) * p.sc > 100.f) != 0;
+    int* const flags = reinterpret_cast<int*>(smem);            // the K tile is idle: every wave passed the loop's last barrier, nothing is in flight
+    if (lane == 0) flags[wave] = over ? 1 : 0;
+    __syncthreads();
+    const int any_over = flags[0] | flags[1] | flags[2] | flags[3];
+    __syncthreads();                                            // before anybody's LDS-DMA overwrites the flags
+    if (!any_over) break;
+    m_ref = m_true;
+    }
+
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_run;
+    bf16_t* orow = p.out + ((size_t)b * p.Tq + (qloc < p.Tq ? qloc : p.Tq - 1)) * p.ldo + h * D + dh * NDO * 64;
+    const bool wide = (p.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;          // uniform
+#pragma unroll
+    for (int dt = 0; dt < 2 * NDO; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg += 2) {
+            u32x2 a = {pack_bf16(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv), pack_bf16(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv)};
+            u32x2 c = {pack_bf16(o[dt][4 * rg + 4] * inv, o[dt][4 * rg + 5] * inv), pack_bf16(o[dt][4 * rg + 6] * inv, o[dt][4 * rg + 7] * inv)};
+            if (wide) {
+                const auto w0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                if (qloc < p.Tq) {
+                    const u32x4 q4 = {(unsigned)w0[0], (unsigned)w1[0], (unsigned)w0[1], (unsigned)w1[1]};
+                    *reinterpret_cast<u32x4*>(orow + dt * 32 + (rg + hi) * 8) = q4;
+                }
+            } else if (qloc < p.Tq) {
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + rg * 8 + hi * 4) = a;
+                *reinterpret_cast<u32x2*>(orow + dt * 32 + (rg + 1) * 8 + hi * 4) = c;
+            }
+        }
+}
+
 }  // namespace
 
 thread_local int t_visrep_attn_variant = 1;   // 1 = attn_fwd<ND> for every head width (default); 2 = attn_fwd_ab (attention_ab.hip, VISREP_EXPERIMENTS builds) for head width 64
@@ -479,12 +706,23 @@ extern "C" int visrep_set_attn_variant(int variant) {          // per-thread; re
 
 extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
                                     int B, int Tq, int Tk, int H, int head_dim, int kv_shared, int causal, float scale, void* stream) {
-    if (head_dim != 64 && head_dim != 128 && head_dim != 192)
-        return visrep_set_error(VISREP_ERR_SHAPE, "attention: head_dim must be 64, 128 or 192 (pad narrower heads with zero weights)");
+    if (head_dim != 64 && head_dim != 128 && head_dim != 192 && head_dim != 512)
+        return visrep_set_error(VISREP_ERR_SHAPE, "attention: head_dim must be 64, 128, 192 or 512 (pad narrower heads with zero weights)");
     if (B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "attention: empty problem");
     if ((ldq % 8) || (ldk % 8) || (ldvt % 64) || (ldo % 4)) return visrep_set_error(VISREP_ERR_SHAPE, "attention: bad leading dimension");
     const long Mk = kv_shared ? Tk : (long)B * Tk;
     if (ldvt < ((Mk + 63) / 64) * 64) return visrep_set_error(VISREP_ERR_SHAPE, "attention: ldvt must cover round_up(key rows, 64)");
+    if (head_dim == 512) {                                      // attn_fwd_wide<8, 4>: whole key tiles, no masks; two workgroups per query tile (256 output columns each)
+        if (causal || Tk % 64 || scale <= 0.f) return visrep_set_error(VISREP_ERR_SHAPE, "attention: head_dim 512 needs Tk % 64 == 0, no causal mask, scale > 0");
+        AttnArgs w;
+        w.q = (const bf16_t*)q; w.k = (const bf16_t*)k; w.vt = (const bf16_t*)vt; w.out = (bf16_t*)out;
+        w.B = B; w.Tq = Tq; w.Tk = Tk; w.H = H; w.Mk = (int)Mk; w.ldq = ldq; w.ldk = ldk; w.ldvt = ldvt; w.ldo = ldo; w.kv_shared = kv_shared; w.causal = 0;
+        w.sc = scale * 1.4426950408889634f;
+        static VisrepLdsOptIn optw;
+        visrep_lds_opt_in(optw, (const void*)attn_fwd_wide<8, 4>, 16 * TILE_B);
+        hipLaunchKernelGGL((attn_fwd_wide<8, 4>), dim3(2 * ((Tq + 127) / 128) * H * B), dim3(256), (size_t)16 * TILE_B, (hipStream_t)stream, w);
+        return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "attention: launch failed");
+    }
 #ifdef VISREP_EXPERIMENTS
     if (head_dim == 64 && t_visrep_attn_variant == 2)
         return visrep_attention_ab_launch(q, ldq, k, ldk, vt, ldvt, out, ldo, B, Tq, Tk, H, kv_shared, causal, scale, (hipStream_t)stream);

@@ -119,6 +119,51 @@ __global__ __launch_bounds__(256) void groupnorm_apply(const bf16_t* __restrict_
     *reinterpret_cast<u32x4*>(y + row * C + c0) = out;
 }
 
+// Row-streaming form for C / 8 a power of two <= 256 (the VAE's 128 / 256 / 512 channels, the transformer widths): a thread keeps ONE 8-channel
+// vector position for the whole launch - its (scale, shift) pairs (rstd gamma, beta - mean rstd gamma) are built once from 8 gamma, 8 beta
+// and the one or two group statistics - and walks the rows of its image chunk with four 16-byte loads in flight.  groupnorm_apply above
+// re-derives row, image, group (integer divisions by run-time values) and re-loads 80 bytes of parameters for every 16 bytes of payload:
+// 3.85 TB/s of read + write traffic at 768^2 x 128 channels against ~5 here (round 4, profiles/round4_sd15_kernel_stats.md).
+template <bool SILU>
+__global__ __launch_bounds__(256) void groupnorm_apply_rows(const bf16_t* __restrict__ x, const float2* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16_t* __restrict__ y, int HW, int C, int cpg, int rows_per_block) {
+    const int cv8 = C >> 3, R = 256 / cv8;
+    const int tc = threadIdx.x & (cv8 - 1), tr = threadIdx.x / cv8;
+    const int b = blockIdx.y, G = C / cpg, c0 = tc * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float2 st = stats[(size_t)b * G + (c0 + e) / cpg];
+        const float gsc = st.y * gamma[c0 + e];
+        sc[e] = gsc;
+        sh[e] = __builtin_fmaf(-st.x, gsc, beta[c0 + e]);
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    const size_t base = (size_t)b * HW * C + c0;
+    auto norm = [&](const u32x4 raw) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(raw[e]); v[2 * e + 1] = bf_hi(raw[e]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = __builtin_fmaf(v[e], sc[e], sh[e]);
+            if (SILU) o = o * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o * -1.4426950408889634f));
+            v[e] = o;
+        }
+        return u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    };
+    int r = r0 + tr;
+    for (; r + 3 * R < r1; r += 4 * R) {
+        u32x4 raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw[k] = *reinterpret_cast<const u32x4*>(x + base + (size_t)(r + k * R) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(y + base + (size_t)(r + k * R) * C) = norm(raw[k]);
+    }
+    for (; r < r1; r += R) *reinterpret_cast<u32x4*>(y + base + (size_t)r * C) = norm(*reinterpret_cast<const u32x4*>(x + base + (size_t)r * C));
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 gather
 struct Im2colArgs {
     const bf16_t* x; bf16_t* y;
@@ -312,6 +357,16 @@ extern "C" int visrep_groupnorm(const void* x, const float* gamma, const float* 
     const int BG = B * groups;
     hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 3) / 4), dim3(256), 0, st, (const float2*)partial, stats, BG, groups, nblk,
                        1.0f / ((float)HW * (float)cpg), eps);
+    const int cv8 = C / 8;
+    if (cv8 <= 256 && (cv8 & (cv8 - 1)) == 0) {                 // row-streaming form; 64 rows per thread unless the image is small
+        const int Ra = 256 / cv8;
+        int arows = 64 * Ra;
+        while (arows > 4 * Ra && (long)((HW + arows - 1) / arows) * B < 2048) arows >>= 1;      // keep >= 8 blocks per CU in flight
+        const dim3 grid((HW + arows - 1) / arows, B);
+        if (silu) hipLaunchKernelGGL(groupnorm_apply_rows<true>, grid, dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta, (bf16_t*)y, HW, C, cpg, arows);
+        else hipLaunchKernelGGL(groupnorm_apply_rows<false>, grid, dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta, (bf16_t*)y, HW, C, cpg, arows);
+        return launched("groupnorm: launch failed");
+    }
     const long total = (long)B * HW * (C / 8);
     hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta,
                        (bf16_t*)y, total, HW, C, cpg, silu);

@@ -19,6 +19,7 @@ MI355X-first layout: activations are channels-last token matrices [B*H*W, C] bf1
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -155,6 +156,7 @@ class SdEngine:
         self._dyn_ctx = None
         self.graph = graph
         self.implicit_conv = True
+        self.vae_flash = os.environ.get("VISREP_VAE_FLASH", "1") != "0"      # 0: the materialised-score route (A/B, tools/)
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
 
@@ -421,17 +423,24 @@ class SdEngine:
         return mom, H, W
 
     def _vae_attention(self, x, B, T):
-        """Single-head attention over all T latent pixels, head width = C (512 for SD): materialised scores per image
-        (fp32 [T, T]) through the GEMM kernel - a 512-wide head does not fit the flash kernel's register budget."""
+        """Single-head attention over all T latent pixels, head width = C (512 for SD): the wide-head flash kernel (attn_fwd_wide) when
+        C == 512 and T % 64 == 0, else materialised scores per image (fp32 [T, T]) through the GEMM kernel."""
         a = "encoder.mid_block.attentions.0"
         P = self.P
         C = x.shape[1]
         n = groupnorm(x, *P[f"{a}.group_norm"], B, self.spec.vae.groups, 1e-6, False)
         q = gemm(n, P[f"{a}.to_q"].w, P[f"{a}.to_q"].b)
         k = gemm(n, P[f"{a}.to_k"].w, P[f"{a}.to_k"].b)
+        wv, bv = P[f"{a}.to_v"].w, P[f"{a}.to_v.bias"]
+        lo = P[f"{a}.to_out.0"]
+        if C == 512 and T % 64 == 0 and self.vae_flash:
+            # one flash launch for the whole batch (attn_fwd_wide: the 512-wide head in two 256-column workgroups per query tile, K / V^T tiles
+            # streamed through LDS once per workgroup): no [T, T] score matrix in HBM
+            vt = linear_vt(n, wv[:C], bv)
+            o = attention(q, k, vt, C, B, T, T, 1, C, C ** -0.5, False)
+            return gemm(o, lo.w, lo.b, _lib.EPI_RESID, resid=x)
         Tp = _ru(T, 64)
         o = torch.empty(B * T, C, dtype=torch.bfloat16, device=x.device)
-        wv, bv = P[f"{a}.to_v"].w, P[f"{a}.to_v.bias"]
         for b in range(B):
             sl = slice(b * T, (b + 1) * T)
             kb, nb = k[sl], n[sl]
@@ -444,7 +453,6 @@ class SdEngine:
             p = softmax_rows(s, T, Tp, C ** -0.5)
             vt = gemm(wv[:C], nb, None)                                        # V^T = Wv X^T : [C, Tp]
             gemm(p, vt, bv, out=o[sl])
-        lo = P[f"{a}.to_out.0"]
         return gemm(o, lo.w, lo.b, _lib.EPI_RESID, resid=x)
 
     # ---------------------------------------------------------------- UNet up to the captured up block

@@ -360,6 +360,43 @@ def test_attention_peaked_softmax(attn_variant):
     assert max_err(out, want) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,Tq,Tk,H,shared,grow", [(2, 256, 256, 1, False, 0.0), (1, 200, 320, 1, False, 0.0), (3, 130, 64, 1, True, 0.0),
+                                                   (1, 128, 1024, 2, False, 0.0), (2, 160, 512, 1, False, 40.0), (1, 96, 256, 1, False, 400.0)])
+def test_attention_head512(B, Tq, Tk, H, shared, grow):
+    """visrep_attention_fwd at head width 512 (attn_fwd_wide: the diffusion VAE's mid-block attention): whole 64-key tiles, Q.K^T over all 512
+    channels, O in two 256-column workgroups.  The softmax reference of a row is fixed at its maximum over the FIRST key tile; grow > 0 puts
+    keys after the first tile whose scores are far larger - 40: inside the range the fixed reference carries (p up to 2^58), 400: beyond it
+    (2^100), the workgroup repeats its pass with the true maxima."""
+    from law_of_vision_representation_in_mllms_amd import sd_engine as SE
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    d = H * 512
+    qh = torch.randn(B * Tq, d, generator=g)
+    kh = torch.randn((1 if shared else B) * Tk, d, generator=g)
+    scale = 512 ** -0.5
+    if grow > 0:                                                            # keys 64.. of every sequence: + grow / scale along a few queries' directions
+        for b in range(1 if shared else B):
+            for j in range(5):
+                qrow = qh[(b if not shared else 0) * Tq + 7 * j].view(H, 512)
+                kh[b * Tk + 64 + 13 * j].view(H, 512).add_(qrow * (grow / scale) / (qrow * qrow).sum(1, keepdim=True))
+    q, k = bf(qh).to(DEV), bf(kh).to(DEV)
+    v = bf(torch.randn((1 if shared else B) * Tk, d, generator=g)).to(DEV)
+    vt = engine.linear_vt(v, bf(torch.eye(d)).to(DEV), None)
+    out = SE.attention(q, k, vt, d, B, Tq, Tk, H, 512, scale, shared)
+    qf = q.float().cpu().view(B, Tq, H, 512).transpose(1, 2)
+    kf, vf = [(t.float().cpu().view(1, Tk, H, 512).expand(B, -1, -1, -1) if shared else t.float().cpu().view(B, Tk, H, 512)).transpose(1, 2) for t in (k, v)]
+    want = (torch.softmax((qf @ kf.transpose(-1, -2)) * scale, -1) @ vf).transpose(1, 2).reshape(B * Tq, d)
+    assert torch.isfinite(out.float()).all()
+    assert max_err(out, want) < 2e-2
+    assert rel_err(out, want) < 1e-2
+
+
+def test_attention_head512_needs_whole_key_tiles():
+    from law_of_vision_representation_in_mllms_amd import sd_engine as SE
+    z = torch.zeros(128, 512, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="head_dim 512"):
+        SE.attention(z, z[:100], torch.zeros(512, 192, dtype=torch.bfloat16, device=DEV), 512, 1, 128, 100, 1, 512, 1.0, False)
+
+
 @pytest.mark.parametrize("B,Tq,Tk,H,shared,causal", [(2, 77, 77, 2, False, True), (3, 256, 77, 2, True, False), (2, 100, 11, 4, True, False),
                                                      (2, 130, 130, 2, False, True), (2, 96, 200, 2, False, False), (1, 320, 64, 1, False, False),
                                                      (4, 65, 513, 2, False, False)])
