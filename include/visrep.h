@@ -334,6 +334,21 @@ int visrep_im2col3x3(const void* x, void* y, int B, int H, int W, int C, int str
 int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
                         int stride, int pad_mode, int upsample, int epilogue, const void* resid, void* stream);
 
+/* The same convolution (no upsampling, epilogue BIAS | RESID) that ALSO emits the GroupNorm statistics of its output - the norm1 / norm2 /
+ * conv_norm_out that follows it in diffusers resnet.py:ResnetBlock2D / vae.py:Encoder - as partial sums from its epilogue:
+ * gn_partial[((b * (Ho Wo / 64) + slot) * groups + g)] = (sum, sum of squares) of the fp32 outputs of image b, rows [64 slot, 64 slot + 64), group g
+ * (visrep_conv_gn_partial_bytes(B, Ho Wo, groups) bytes, every entry written).  visrep_groupnorm_from_partials() then normalises without
+ * reading the tensor for its statistics.  Supported when visrep_conv_gn_supported(B, Ho Wo, Cout, groups): Ho Wo % 128 == 0, Cout % 64 == 0,
+ * Cout / groups in {4, 8, 16}, and a problem the 128x128 kernel runs (the 768^2 and 384^2 128-channel layers of the VAE encoder: the
+ * largest tensors; the 256x256 kernel's epilogue has no registers left for the running sums). */
+int visrep_conv_gn_supported(int B, int HWo, int Cout, int groups);
+size_t visrep_conv_gn_partial_bytes(int B, int HWo, int groups);
+int visrep_conv3x3_bf16_gn(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
+                           int stride, int pad_mode, int epilogue, const void* resid, void* gn_partial, int groups, void* stream);
+/* GroupNorm (+ SiLU) of x [B*HW, C] from such partial sums (HW % 64 == 0): finalize + apply.  workspace: >= B * groups * 8 bytes. */
+int visrep_groupnorm_from_partials(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups, float eps,
+                                   int silu, const void* partial, void* workspace, void* stream);
+
 /* activations.py GEGLU: y[m, f] = x[m, f] * gelu_erf(x[m, F + f]); x [M, >= 2F] bf16, y [M, >= F] bf16. */
 int visrep_geglu(const void* x, int ldx, void* y, int ldy, long M, int F, void* stream);
 

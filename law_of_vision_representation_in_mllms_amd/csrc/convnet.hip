@@ -332,6 +332,26 @@ inline int gn_rows_per_block(int B, int HW) {
 }
 }  // namespace
 
+namespace {
+int launch_groupnorm_apply(const void* x, const float2* stats, const float* gamma, const float* beta, void* y, int B, int HW, int C, int cpg, int silu,
+                           hipStream_t st) {
+    const int cv8 = C / 8;
+    if (cv8 <= 256 && (cv8 & (cv8 - 1)) == 0) {                 // row-streaming form; 64 rows per thread unless the image is small
+        const int Ra = 256 / cv8;
+        int arows = 64 * Ra;
+        while (arows > 4 * Ra && (long)((HW + arows - 1) / arows) * B < 2048) arows >>= 1;      // keep >= 8 blocks per CU in flight
+        const dim3 grid((HW + arows - 1) / arows, B);
+        if (silu) hipLaunchKernelGGL(groupnorm_apply_rows<true>, grid, dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta, (bf16_t*)y, HW, C, cpg, arows);
+        else hipLaunchKernelGGL(groupnorm_apply_rows<false>, grid, dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta, (bf16_t*)y, HW, C, cpg, arows);
+        return launched("groupnorm: launch failed");
+    }
+    const long total = (long)B * HW * (C / 8);
+    hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta,
+                       (bf16_t*)y, total, HW, C, cpg, silu);
+    return launched("groupnorm: launch failed");
+}
+}  // namespace
+
 extern "C" size_t visrep_groupnorm_workspace_bytes(int B, int HW, int groups) {
     if (B <= 0 || HW <= 0 || groups <= 0) return 0;
     const int rows = gn_rows_per_block(B, HW), nblk = (HW + rows - 1) / rows;
@@ -357,20 +377,22 @@ extern "C" int visrep_groupnorm(const void* x, const float* gamma, const float* 
     const int BG = B * groups;
     hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 3) / 4), dim3(256), 0, st, (const float2*)partial, stats, BG, groups, nblk,
                        1.0f / ((float)HW * (float)cpg), eps);
-    const int cv8 = C / 8;
-    if (cv8 <= 256 && (cv8 & (cv8 - 1)) == 0) {                 // row-streaming form; 64 rows per thread unless the image is small
-        const int Ra = 256 / cv8;
-        int arows = 64 * Ra;
-        while (arows > 4 * Ra && (long)((HW + arows - 1) / arows) * B < 2048) arows >>= 1;      // keep >= 8 blocks per CU in flight
-        const dim3 grid((HW + arows - 1) / arows, B);
-        if (silu) hipLaunchKernelGGL(groupnorm_apply_rows<true>, grid, dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta, (bf16_t*)y, HW, C, cpg, arows);
-        else hipLaunchKernelGGL(groupnorm_apply_rows<false>, grid, dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta, (bf16_t*)y, HW, C, cpg, arows);
-        return launched("groupnorm: launch failed");
-    }
-    const long total = (long)B * HW * (C / 8);
-    hipLaunchKernelGGL(groupnorm_apply, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16_t*)x, (const float2*)stats, gamma, beta,
-                       (bf16_t*)y, total, HW, C, cpg, silu);
-    return launched("groupnorm: launch failed");
+    return launch_groupnorm_apply(x, stats, gamma, beta, y, B, HW, C, cpg, silu, st);
+}
+
+// GroupNorm whose per-(image, 64-row slot, group) partial sums came out of the producing convolution's epilogue (visrep_conv3x3_bf16_gn):
+// finalize + apply only - the tensor is not read for its statistics.  workspace: >= B * groups float2.
+extern "C" int visrep_groupnorm_from_partials(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups, float eps,
+                                              int silu, const void* partial, void* workspace, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm: empty problem");
+    if (C % groups || C % 8 || HW % 64) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm_from_partials: C % groups, C % 8, HW % 64 must be 0");
+    if (!x || !y || !partial || !workspace) return visrep_set_error(VISREP_ERR_ARG, "groupnorm_from_partials: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int cpg = C / groups, BG = B * groups, nblk = HW / 64;
+    float2* stats = (float2*)workspace;
+    hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 3) / 4), dim3(256), 0, st, (const float2*)partial, stats, BG, groups, nblk,
+                       1.0f / ((float)HW * (float)cpg), eps);
+    return launch_groupnorm_apply(x, stats, gamma, beta, y, B, HW, C, cpg, silu, st);
 }
 
 extern "C" int visrep_im2col3x3(const void* x, void* y, int B, int H, int W, int C, int stride, int pad_mode, int upsample, int ldy,

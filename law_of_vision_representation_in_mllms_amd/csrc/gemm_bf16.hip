@@ -29,7 +29,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // double buffer = 64 KB
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};   // source of padded (out-of-image) conv taps
 
-template <int EPI, bool CONV = false>
+template <int EPI, bool CONV = false, bool GN = false>        // GN (with CONV): the epilogue also emits GroupNorm partial sums (GemmArgs::gn_partial)
 __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
         gemm_epilogue_rowmajor<EPI, 4, 4>(q, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
         return;
     }
+    if constexpr (GN) { gemm_epilogue_rowmajor_gn<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg); return; }
     if (EPI == EPI_VT) gemm_epilogue_vt<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
     else gemm_epilogue_rowmajor<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
@@ -168,12 +169,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_vt(const float* __restrict_
     *reinterpret_cast<u32x2*>(p.C + (size_t)n * p.ldc + mp) = o;
 }
 
-template <int EPI, bool CONV = false>
+template <int EPI, bool CONV = false, bool GN = false>
 int launch(const GemmArgs& a, hipStream_t s) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     static VisrepLdsOptIn opt;                                      // per (kernel instantiation, device)
-    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_128<EPI, CONV>), LDS_BYTES);
-    hipLaunchKernelGGL((gemm_bf16_128<EPI, CONV>), dim3(ntm * ntn, a.kslice ? a.K / a.kslice : 1), dim3(256), LDS_BYTES, s, a);
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_128<EPI, CONV, GN>), LDS_BYTES);
+    hipLaunchKernelGGL((gemm_bf16_128<EPI, CONV, GN>), dim3(ntm * ntn, a.kslice ? a.K / a.kslice : 1), dim3(256), LDS_BYTES, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
 
@@ -301,6 +302,7 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
 #ifndef VISREP_NO_CONV5                                           // A/B builds (tools/): every convolution on the 128x128 kernel, as until round 4
         if (variant == 5 && visrep_gemm_v5_supports_conv(a) && (long)((a.M + 255) / 256) * (a.N / 256) >= 2L * visrep_cu_count()) return visrep_gemm_v5_dispatch(a, s);
 #endif
+        if (a.gn_partial) return a.epi == EPI_BIAS ? launch<EPI_BIAS, true, true>(a, s) : launch<EPI_RESID, true, true>(a, s);
         switch (a.epi) {
             case EPI_BIAS: return launch<EPI_BIAS, true>(a, s);
             case EPI_RESID: return launch<EPI_RESID, true>(a, s);
@@ -349,7 +351,7 @@ namespace {
 // blockIdx.y into fp32 planes in the caller's scratch (visrep_set_scratch) and reduce them in slice order with the epilogue
 // fused.  Returns 1 when the problem was handled this way, 0 when it was not eligible, < 0 on error.
 int try_split_k(const GemmArgs& a, hipStream_t s) {
-    if (!(a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0)) return 0;
+    if (!(a.epi != EPI_PATCH && a.K >= 1024 && (a.N & 3) == 0) || a.gn_partial) return 0;     // GroupNorm partials come from a GEMM epilogue only
     const VisrepScratch reg = visrep_scratch_for(s);               // the buffer of (this device, this stream), else the device-wide one
     void* const scratch = reg.ptr;
     const size_t scratch_bytes = reg.bytes;
@@ -425,6 +427,9 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.stat_rt && a.epi != EPI_RESID) return visrep_set_error(VISREP_ERR_ARG, "gemm: row statistics are an EPI_RESID feature");
     if (a.a_period > 0 && (a.conv || a.epi == EPI_RESID || a.epi == EPI_PATCH || a.a_stride < a.a_period || a.a_first < 0))
         return visrep_set_error(VISREP_ERR_ARG, "gemm: the A row map serves plain BIAS / ACT / VT / F32 epilogues only");
+    if (a.gn_partial && (!a.conv || (a.epi != EPI_BIAS && a.epi != EPI_RESID) || (a.gn_cpg != 4 && a.gn_cpg != 8 && a.gn_cpg != 16) || a.gn_hw <= 0 ||
+                         a.gn_hw % 128 || a.M % a.gn_hw || a.N % a.gn_cpg || a.N % 64))
+        return visrep_set_error(VISREP_ERR_ARG, "gemm: GroupNorm partials need a convolution, bias / residual epilogue, 4 | 8 | 16 channels per group, HW % 128 == 0");
     const int variant = t_visrep_gemm_variant;
     {
         const int sk = run_split_k(a, s);

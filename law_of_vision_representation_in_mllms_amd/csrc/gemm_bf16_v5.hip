@@ -149,6 +149,9 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page5[4] = {0u, 0u, 0u, 
 // symmetric or (0,1,0,1) padding, no upsampling): the X rows are output pixels, a lane's four row cursors point at the pixel's top-left tap
 // and carry a 9-bit "tap is inside the image" mask; per K-tile the tap's offset (ky W + kx) C + c0 is one scalar and a lane whose tap is
 // padding fetches the zero page instead.  W, the ring, the ledger and the epilogues are the plain GEMM's.
+// (A variant whose epilogue also emits GroupNorm partial sums - GemmArgs::gn_partial, as the 128x128 kernel's does - was built in round 4 and
+// dropped: with 128 accumulators live the eight running sums tip the allocator into ~200 spilled registers, K loop included; convolutions that
+// take this kernel keep the separate statistics pass, profiles/round4_sd15_kernel_stats.md.)
 template <int EPI, bool OWN_, bool CONV_ = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -408,7 +411,7 @@ bool visrep_gemm_v5_supports(const GemmArgs& a) {
 
 // implicit 3x3 convolution in the 256x256 kernel: whole column tiles, 64-channel K-tiles inside one tap, no upsampled source
 bool visrep_gemm_v5_supports_conv(const GemmArgs& a) {
-    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && (a.epi == EPI_BIAS || a.epi == EPI_RESID) &&
+    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && !a.gn_partial && (a.epi == EPI_BIAS || a.epi == EPI_RESID) &&
            (long)a.M / (a.cHo * a.cWo) * a.cH * a.cW * a.cC < (1L << 31) - (3L * a.cW + 3) * a.cC;     // 32-bit element offsets
 }
 

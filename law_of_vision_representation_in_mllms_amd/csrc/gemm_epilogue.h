@@ -85,9 +85,23 @@ template <typename ACC> struct AccGeom { static constexpr int QN = sizeof(ACC) /
 // AL (decided once per launch by the caller: ldc % 8 == 0, 16-byte aligned C and residual): 16-byte stores and residual loads - see WIDE / RWIDE.
 // Addresses: one 64-bit base per output row (this lane's first column), every store / residual load of the row at a COMPILE-TIME byte
 // offset from it (the store instructions' immediate field; the column loops are static_for so that the offsets are template arguments).
-template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, bool AL, typename ACC>
+// sum of v over the 16 lanes of a DPP row (lanes that differ in bits 0-3 = the 16 accumulator rows fr of one column quad): four rotate-adds
+VR_DEV float sum_over_fr(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+// HAS_GN (convolutions, EPI_BIAS / EPI_RESID): also emit the GroupNorm partial sums of this wave's rows (GemmArgs::gn_partial).
+template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, bool AL, bool HAS_GN, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int QN = AccGeom<ACC>::QN, RBLK = AccGeom<ACC>::RBLK, NC = NJ * QN;   // NC column groups of 4 per lane
+    static_assert(!HAS_GN || (QN == 1 && (NI * RBLK == 64 || NI * RBLK == 128)), "GroupNorm partials: 16x16 accumulators, 64 or 128 rows per wave");
+    float gs1[HAS_GN ? NC : 1], gs2[HAS_GN ? NC : 1];        // per column quad: sum / sum of squares over this lane's rows
+#pragma unroll
+    for (int c = 0; c < (HAS_GN ? NC : 1); ++c) { gs1[c] = 0.f; gs2[c] = 0.f; }
     // Output stores.  16x16 accumulators: the four lanes hg = 0..3 of a row hold 4 consecutive columns each of every 16-column block j, i.e.
     // 8-byte stores, 32 contiguous bytes per row and instruction.  The K = 1024 GEMMs spend 15-22 % of their time in this store stream
     // (profiles/round2_store_stream.md), which is issue-bound, not bandwidth-bound.  WIDE: one v_permlane16_swap per word between the lanes
@@ -220,6 +234,10 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
                         v0 += bf_lo(rv[ii][c][0]); v1 += bf_hi(rv[ii][c][0]); v2 += bf_lo(rv[ii][c][1]); v3 += bf_hi(rv[ii][c][1]);
                     }
                     if (EPI == EPI_PATCH) { v0 += pv[ii][c].x; v1 += pv[ii][c].y; v2 += pv[ii][c].z; v3 += pv[ii][c].w; }
+                    if (HAS_GN && ok[ii]) {
+                        gs1[HAS_GN ? c : 0] += (v0 + v1) + (v2 + v3);
+                        gs2[HAS_GN ? c : 0] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, gs2[HAS_GN ? c : 0]))));
+                    }
                     if (EPI == EPI_F32) {
                         if (ok[ii]) store_b128_at<((c / QN) * RBLK + (c % QN) * 8) * 4>(crow[ii], f32x4{v0, v1, v2, v3});
                     } else {
@@ -253,6 +271,35 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
             }
         });
     });
+    if (HAS_GN) {
+        const int g0 = mb + p.a_row0;                         // first row of this wave in the whole problem (a tail launch carries its offset)
+        if (mb < p.M) {                                       // uniform per wave; gn_hw % 128 == 0: all rows valid and inside one image
+            const int b = g0 / p.gn_hw, slot = (g0 - b * p.gn_hw) >> 6, nblk = p.gn_hw >> 6, G = p.N / p.gn_cpg;
+            float2* dst = p.gn_partial + ((size_t)b * nblk + slot) * G;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float s1 = sum_over_fr(gs1[HAS_GN ? c : 0]), s2 = sum_over_fr(gs2[HAS_GN ? c : 0]);
+                if (p.gn_cpg >= 8) {                          // uniform: a group spans the column quads of the lanes hg, hg ^ 1 (and hg ^ 2 for 16)
+                    const auto a1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
+                    const auto a2 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
+                    s1 = __builtin_bit_cast(float, (unsigned)a1[0]) + __builtin_bit_cast(float, (unsigned)a1[1]);
+                    s2 = __builtin_bit_cast(float, (unsigned)a2[0]) + __builtin_bit_cast(float, (unsigned)a2[1]);
+                }
+                if (p.gn_cpg >= 16) {
+                    const auto a1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
+                    const auto a2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
+                    s1 = __builtin_bit_cast(float, (unsigned)a1[0]) + __builtin_bit_cast(float, (unsigned)a1[1]);
+                    s2 = __builtin_bit_cast(float, (unsigned)a2[0]) + __builtin_bit_cast(float, (unsigned)a2[1]);
+                }
+                const int colq = nb + c * RBLK + hg * 4;       // first column of this lane's quad c
+                if (fr == 0 && (colq % p.gn_cpg) == 0) {
+                    const int g = colq / p.gn_cpg;
+                    dst[g] = float2{s1, s2};
+                    if (NI * RBLK == 128) dst[G + g] = float2{0.f, 0.f};       // this wave covers two 64-row slots: all of it in the first
+                }
+            }
+        }
+    }
 }
 
 template <int EPI, int NI, int NJ, int ACT, bool STATS, bool RW, typename ACC>
@@ -260,21 +307,21 @@ VR_DEV void gemm_epilogue_rowmajor_rw(const GemmArgs& p, const ACC (&acc)[NI][NJ
     const bool interior = mb + NI * AccGeom<ACC>::RBLK <= p.M;
     if (STATS && EPI == EPI_RESID && p.stat_partial) {       // residual GEMM that also emits the next LayerNorm's row statistics
         if (p.ls) {
-            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, true, RW>(p, acc, mb, nb, fr, hg);
-            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, true, RW>(p, acc, mb, nb, fr, hg);
+            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, true, RW, false>(p, acc, mb, nb, fr, hg);
+            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, true, RW, false>(p, acc, mb, nb, fr, hg);
         } else {
-            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, true, RW>(p, acc, mb, nb, fr, hg);
-            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, true, RW>(p, acc, mb, nb, fr, hg);
+            if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, true, RW, false>(p, acc, mb, nb, fr, hg);
+            else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, true, RW, false>(p, acc, mb, nb, fr, hg);
         }
     } else if (EPI == EPI_RESID && p.ls) {                   // LayerScale towers (DINOv2): its own path keeps the others lean
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, false, RW>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, false, RW>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, true, false, false, RW, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, true, false, false, RW, false>(p, acc, mb, nb, fr, hg);
     } else if ((EPI == EPI_BIAS || EPI == EPI_ACT) && p.ln_rt) {   // LayerNorm folded into this GEMM
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true, false, RW>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true, false, RW>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, true, false, RW, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, true, false, RW, false>(p, acc, mb, nb, fr, hg);
     } else {
-        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, false, RW>(p, acc, mb, nb, fr, hg);
-        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, false, RW>(p, acc, mb, nb, fr, hg);
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, false, false, false, false, RW, false>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT, true, false, false, false, RW, false>(p, acc, mb, nb, fr, hg);
     }
 }
 
@@ -286,6 +333,22 @@ VR_DEV void gemm_epilogue_rowmajor_act(const GemmArgs& p, const ACC (&acc)[NI][N
                     (EPI != EPI_RESID || (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0);
     if (al) gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, EPI != EPI_F32>(p, acc, mb, nb, fr, hg);
     else gemm_epilogue_rowmajor_rw<EPI, NI, NJ, ACT, STATS, false>(p, acc, mb, nb, fr, hg);
+}
+
+// the convolution kernels' epilogue when GemmArgs::gn_partial is set (plain bias / residual epilogue + GroupNorm partial sums)
+template <int EPI, int NI, int NJ, typename ACC>
+VR_DEV void gemm_epilogue_rowmajor_gn(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "GroupNorm partials come with the bias / residual epilogues");
+    const bool interior = mb + NI * AccGeom<ACC>::RBLK <= p.M;
+    const bool al = (NJ % 2) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+                    (EPI != EPI_RESID || (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0);
+    if (al) {
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT_NONE, false, false, false, false, true, true>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT_NONE, true, false, false, false, true, true>(p, acc, mb, nb, fr, hg);
+    } else {
+        if (interior) gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT_NONE, false, false, false, false, false, true>(p, acc, mb, nb, fr, hg);
+        else gemm_epilogue_rowmajor_impl<EPI, NI, NJ, ACT_NONE, true, false, false, false, false, true>(p, acc, mb, nb, fr, hg);
+    }
 }
 
 // STATS: only the kernel the dispatcher routes statistics-emitting residual GEMMs to (v2) compiles that epilogue

@@ -126,6 +126,41 @@ extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, co
     return visrep_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+// Rows and groups must fit the epilogue's slots, and the convolution must be one the 128x128 kernel runs: the 256x256 kernel (whole rounds of
+// its tiles, Cout % 256 == 0) has no registers left for the running sums and keeps the separate statistics pass.
+extern "C" int visrep_conv_gn_supported(int B, int HWo, int Cout, int groups) {
+    if (B <= 0 || HWo <= 0 || Cout <= 0 || groups <= 0 || Cout % groups) return 0;
+    const int cpg = Cout / groups;
+    if (!(HWo % 128 == 0 && Cout % 64 == 0 && (cpg == 4 || cpg == 8 || cpg == 16))) return 0;
+    if (Cout % 256 == 0 && ((long)B * HWo + 255) / 256 * (Cout / 256) >= 2L * visrep_cu_count()) return 0;
+    return 1;
+}
+
+extern "C" size_t visrep_conv_gn_partial_bytes(int B, int HWo, int groups) {
+    return (B > 0 && HWo > 0 && groups > 0) ? (size_t)B * (HWo / 64) * groups * sizeof(float2) : 0;
+}
+
+extern "C" int visrep_conv3x3_bf16_gn(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc,
+                                      int Cout, int stride, int pad_mode, int epilogue, const void* resid, void* gn_partial, int groups, void* stream) {
+    if (!x || !Wt || !out || !gn_partial) return visrep_set_error(VISREP_ERR_ARG, "conv3x3_gn: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3_gn: empty problem");
+    if (C % 64) return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3_gn: C must be a multiple of 64");
+    if ((stride != 1 && stride != 2) || (pad_mode != 0 && pad_mode != 1)) return visrep_set_error(VISREP_ERR_ARG, "conv3x3_gn: stride 1|2, pad_mode 0|1");
+    if (epilogue != VISREP_EPI_BIAS && epilogue != VISREP_EPI_RESID) return visrep_set_error(VISREP_ERR_ARG, "conv3x3_gn: epilogue must be BIAS or RESID");
+    if (epilogue == VISREP_EPI_RESID && !resid) return visrep_set_error(VISREP_ERR_ARG, "conv3x3_gn: EPI_RESID needs resid");
+    const int pad_total = pad_mode == 0 ? 2 : 1;
+    GemmArgs a{};
+    a.A = (const bf16_t*)x; a.W = (const bf16_t*)Wt; a.C = (bf16_t*)out; a.bias = bias; a.resid = (const bf16_t*)resid;
+    a.conv = 1; a.cH = H; a.cW = W; a.cC = C; a.cstride = stride; a.cpad = pad_mode == 0 ? 1 : 0; a.cup = 0;
+    a.cHo = (H + pad_total - 3) / stride + 1;
+    a.cWo = (W + pad_total - 3) / stride + 1;
+    if (!visrep_conv_gn_supported(B, a.cHo * a.cWo, Cout, groups))
+        return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3_gn: needs Ho Wo % 128 == 0, 4 | 8 | 16 channels per group and a shape the 128x128 kernel runs (see visrep_conv_gn_supported)");
+    a.M = B * a.cHo * a.cWo; a.N = Cout; a.K = 9 * C; a.lda = 8; a.ldw = ldw; a.ldc = ldc; a.epi = epilogue;
+    a.gn_partial = (float2*)gn_partial; a.gn_cpg = Cout / groups; a.gn_hw = a.cHo * a.cWo;
+    return visrep_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------------ ViT forward
 namespace {
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -44,6 +44,12 @@ struct GemmArgs {
     // implicit 3x3 convolution (v1 kernel, conv = 1): A is the channels-last activation [B, cH, cW, cC] and the A tile of
     // K-tile (tap, c0) is gathered on the fly: row m = (b, oy, ox) reads x[b, (oy*cstride+ky-cpad)>>cup, (ox*cstride+kx-cpad)>>cup, c0..]
     int conv, cH, cW, cC, cHo, cWo, cstride, cpad, cup;
+    // Convolution that also emits the GroupNorm statistics of its OUTPUT (the next ResnetBlock2D norm): per 64-row slot of an image and
+    // per group the sum and the sum of squares of the (fp32, unrounded) outputs -> gn_partial[((b * nblk + slot) * G + g)], nblk = gn_hw / 64,
+    // G = N / gn_cpg; groupnorm_finalize adds a (image, group)'s slots in order.  Needs gn_hw % 128 == 0 (a wave's 64 / 128 rows lie inside one
+    // image), gn_cpg in {4, 8, 16} (a group = one / two / four lanes' column quads of a 16-column block), EPI_BIAS | EPI_RESID, no split-K.
+    float2* gn_partial;
+    int gn_cpg, gn_hw;
     // EPI_F32X (variant 5 only): an fp32 GEMM on the bf16 matrix pipe.  A and W hold the bf16 PLANES of fp32 matrices side by side
     // (hi | mid [| lo]: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); two planes carry 16 significand bits, three carry 24):
     // A [M, nplanes * ksplit], W [N, nplanes * ksplit].  K = nprod * ksplit walks nprod (A plane, W plane) pairs, two bits per pair in

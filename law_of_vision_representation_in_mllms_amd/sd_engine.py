@@ -46,6 +46,23 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, 
     return y
 
 
+def groupnorm_from_partials(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, groups: int, eps: float, silu: bool,
+                            partial: torch.Tensor) -> torch.Tensor:
+    """GroupNorm(+SiLU) of x [B*HW, C] whose statistics the producing convolution left as partial sums (conv3x3(..., gn_groups=))."""
+    lib = _lib.require_gpu()
+    M, C = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty(B * groups * 8, dtype=torch.uint8, device=x.device)
+    rc = lib.visrep_groupnorm_from_partials(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), B, M // B, C, groups, float(eps), int(silu),
+                                            _lib.ptr(partial), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, "visrep_groupnorm_from_partials")
+    return y
+
+
+def conv_gn_supported(B: int, HWo: int, Cout: int, groups: int) -> bool:
+    return bool(_lib.load().visrep_conv_gn_supported(int(B), int(HWo), int(Cout), int(groups)))
+
+
 def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, ld: int, stride: int = 1, pad_mode: int = 0, upsample: bool = False):
     """x [B*H*W, C] -> ([B*Ho*Wo, ld] bf16, Ho, Wo)."""
     lib = _lib.require_gpu()
@@ -60,8 +77,10 @@ def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, ld: int, stride: int = 1,
 
 
 def conv3x3(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, stride: int = 1, pad_mode: int = 0, upsample: bool = False,
-            epi: int = _lib.EPI_BIAS, resid=None):
-    """Implicit-GEMM 3x3 convolution (visrep_conv3x3_bf16): x [B*H*W, C] (C % 64 == 0), w [Cout, 9*C] -> ([B*Ho*Wo, Cout], Ho, Wo)."""
+            epi: int = _lib.EPI_BIAS, resid=None, gn_groups: int = 0):
+    """Implicit-GEMM 3x3 convolution (visrep_conv3x3_bf16): x [B*H*W, C] (C % 64 == 0), w [Cout, 9*C] -> ([B*Ho*Wo, Cout], Ho, Wo).
+    gn_groups > 0 (visrep_conv3x3_bf16_gn; the shape must pass conv_gn_supported): returns ([..], Ho, Wo, partial) with the GroupNorm partial
+    sums of the output for groupnorm_from_partials()."""
     lib = _lib.require_gpu()
     C = x.shape[1]
     Hl, Wl = (H * 2, W * 2) if upsample else (H, W)
@@ -69,6 +88,14 @@ def conv3x3(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, stri
     Ho, Wo = (Hl + pad_total - 3) // stride + 1, (Wl + pad_total - 3) // stride + 1
     N = w.shape[0]
     out = torch.empty(B * Ho * Wo, N, dtype=torch.float32 if epi == _lib.EPI_F32 else torch.bfloat16, device=x.device)
+    if gn_groups:
+        if upsample:
+            raise ValueError("conv3x3: GroupNorm partials are not emitted from an upsampling convolution")
+        partial = torch.empty(lib.visrep_conv_gn_partial_bytes(B, Ho * Wo, gn_groups), dtype=torch.uint8, device=x.device)
+        rc = lib.visrep_conv3x3_bf16_gn(_lib.ptr(x), B, H, W, C, _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(out), out.stride(0), N, stride,
+                                        pad_mode, epi, _lib.ptr(resid), _lib.ptr(partial), gn_groups, _lib.stream_ptr())
+        _lib.check(rc, "visrep_conv3x3_bf16_gn")
+        return out, Ho, Wo, partial
     rc = lib.visrep_conv3x3_bf16(_lib.ptr(x), B, H, W, C, _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(out), out.stride(0), N, stride,
                                  pad_mode, int(upsample), epi, _lib.ptr(resid), _lib.stream_ptr())
     _lib.check(rc, "visrep_conv3x3_bf16")
@@ -157,6 +184,7 @@ class SdEngine:
         self.graph = graph
         self.implicit_conv = True
         self.vae_flash = os.environ.get("VISREP_VAE_FLASH", "1") != "0"      # 0: the materialised-score route (A/B, tools/)
+        self.fuse_gn_stats = os.environ.get("VISREP_GN_FUSE", "1") != "0"    # 0: every GroupNorm reads its input twice (A/B, tools/)
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
 
@@ -346,24 +374,40 @@ class SdEngine:
             self._ctx[b] = (gemm(ctx, self.P[f"{b}.attn2.k"].w), linear_vt(ctx, self.P[f"{b}.attn2.v"].w, None))
 
     # ---------------------------------------------------------------- building blocks (token-major)
-    def _conv(self, x, B, H, W, name, stride=1, pad_mode=0, upsample=False, epi=_lib.EPI_BIAS, resid=None):
+    def _conv(self, x, B, H, W, name, stride=1, pad_mode=0, upsample=False, epi=_lib.EPI_BIAS, resid=None, gn=0):
+        """gn = the group count of a GroupNorm that will normalise this convolution's output: when the shape allows, the convolution's epilogue
+        leaves that norm's partial sums (attached to the returned tensor object, consumed by self._gn)."""
         lin = self.P[name]
         if self.implicit_conv and x.shape[1] % 64 == 0:                    # gather inside the GEMM's A-operand DMA
+            if gn and self.fuse_gn_stats and not upsample and epi in (_lib.EPI_BIAS, _lib.EPI_RESID) and lin.w.shape[0] == lin.n:
+                pad_total = 2 if pad_mode == 0 else 1
+                Ho, Wo = (H + pad_total - 3) // stride + 1, (W + pad_total - 3) // stride + 1
+                if conv_gn_supported(B, Ho * Wo, lin.n, gn):
+                    out, Ho, Wo, partial = conv3x3(x, B, H, W, lin.w, lin.b, stride, pad_mode, False, epi, resid, gn_groups=gn)
+                    out._visrep_gn = (partial, gn)                       # rides on the tensor object: dies with it, never matches another tensor
+                    return out, Ho, Wo
             return conv3x3(x, B, H, W, lin.w, lin.b, stride, pad_mode, upsample, epi, resid)
         cols, Ho, Wo = im2col3x3(x, B, H, W, lin.w.shape[1], stride, pad_mode, upsample)       # 3 / 4-channel inputs (padded to 8)
         return gemm(cols, lin.w, lin.b, epi, resid=resid), Ho, Wo
 
+    def _gn(self, x, gamma, beta, B, groups, eps, silu):
+        """GroupNorm(+SiLU): from the producing convolution's partial sums when it left any for this tensor, else the full statistics pass."""
+        ent = getattr(x, "_visrep_gn", None)
+        if ent is not None and ent[1] == groups:
+            return groupnorm_from_partials(x, gamma, beta, B, groups, eps, silu, ent[0])
+        return groupnorm(x, gamma, beta, B, groups, eps, silu)
+
     def _resnet(self, x, B, H, W, p, groups, eps):
         g1, b1 = self.P[f"{p}.norm1"]
-        h = groupnorm(x, g1, b1, B, groups, eps, True)
-        h, _, _ = self._conv(h, B, H, W, f"{p}.conv1")
+        h = self._gn(x, g1, b1, B, groups, eps, True)
+        h, _, _ = self._conv(h, B, H, W, f"{p}.conv1", gn=groups)
         g2, b2 = self.P[f"{p}.norm2"]
-        h = groupnorm(h, g2, b2, B, groups, eps, True)
+        h = self._gn(h, g2, b2, B, groups, eps, True)
         sc = x
         if f"{p}.conv_shortcut" in self.P:
             s = self.P[f"{p}.conv_shortcut"]
             sc = gemm(x, s.w, s.b)
-        out, _, _ = self._conv(h, B, H, W, f"{p}.conv2", epi=_lib.EPI_RESID, resid=sc)
+        out, _, _ = self._conv(h, B, H, W, f"{p}.conv2", epi=_lib.EPI_RESID, resid=sc, gn=groups)
         return out
 
     def _transformer(self, x, B, HW, p, groups):
@@ -413,12 +457,12 @@ class SdEngine:
             for j in range(v.layers_per_block):
                 h = self._resnet(h, B, H, W, f"encoder.down_blocks.{i}.resnets.{j}", g, 1e-6)
             if i != len(v.block_out) - 1:
-                h, H, W = self._conv(h, B, H, W, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_mode=1)
+                h, H, W = self._conv(h, B, H, W, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_mode=1, gn=g)
         h = self._resnet(h, B, H, W, "encoder.mid_block.resnets.0", g, 1e-6)
         h = self._vae_attention(h, B, H * W)
         h = self._resnet(h, B, H, W, "encoder.mid_block.resnets.1", g, 1e-6)
         gn, bn = self.P["encoder.conv_norm_out"]
-        h = groupnorm(h, gn, bn, B, g, 1e-6, True)
+        h = self._gn(h, gn, bn, B, g, 1e-6, True)
         mom, _, _ = self._conv(h, B, H, W, "vae.moments", epi=_lib.EPI_F32)
         return mom, H, W
 
@@ -428,7 +472,7 @@ class SdEngine:
         a = "encoder.mid_block.attentions.0"
         P = self.P
         C = x.shape[1]
-        n = groupnorm(x, *P[f"{a}.group_norm"], B, self.spec.vae.groups, 1e-6, False)
+        n = self._gn(x, *P[f"{a}.group_norm"], B, self.spec.vae.groups, 1e-6, False)
         q = gemm(n, P[f"{a}.to_q"].w, P[f"{a}.to_q"].b)
         k = gemm(n, P[f"{a}.to_k"].w, P[f"{a}.to_k"].b)
         wv, bv = P[f"{a}.to_v"].w, P[f"{a}.to_v.bias"]

@@ -147,6 +147,54 @@ def test_conv3x3_in_the_256_kernel(B, H, W, Ci, Co, stride, pad_mode):
     assert rel_err(got_r, res.float().cpu() + tokens(want)) < 5e-3
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,pad_mode", [(2, 32, 32, 64, 128, 1, 0),        # 128-channel layers: 4 channels per group
+                                                        (3, 48, 32, 128, 256, 1, 0),       # 8 per group
+                                                        (2, 33, 65, 64, 512, 2, 1),        # 16 per group, stride 2 with (0,1,0,1) padding -> 16 x 32
+                                                        (9, 128, 120, 64, 128, 1, 0),      # 1080 tiles of 128 x 128
+                                                        (2, 64, 64, 128, 64, 1, 0)])       # one 64-column wave tile per block row (N edge)
+def test_conv3x3_emits_groupnorm_partials(B, H, W, Ci, Co, stride, pad_mode):
+    """visrep_conv3x3_bf16_gn: the convolution result is the plain call's (bitwise when both take the same route), and GroupNorm from its partial sums equals GroupNorm of the
+    stored tensor (statistics of the fp32 outputs vs of their bf16 roundings: far inside the bf16 output tolerance); BIAS and RESID."""
+    g = torch.Generator().manual_seed(H + W + Co)
+    G = 32 if Co >= 128 else 16
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = torch.randn(Co, generator=g) * 0.5 + 0.3
+    wp = bf(w.float().permute(0, 2, 3, 1).reshape(Co, 9 * Ci)).to(DEV)
+    xt = tokens(x).to(DEV)
+    gam, bet = (torch.randn(Co, generator=g) * 0.3 + 1).to(DEV), (torch.randn(Co, generator=g) * 0.2).to(DEV)
+    plain, Ho, Wo = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_BIAS)
+    assert SE.conv_gn_supported(B, Ho * Wo, Co, G) and not SE.conv_gn_supported(B, Ho * Wo + 64, Co, 32) and not SE.conv_gn_supported(B, Ho * Wo, 320, 32)
+    assert not SE.conv_gn_supported(16, 384 * 384, 256, 32)                 # the 256x256 kernel's shapes keep the separate statistics pass
+    out, _, _, part = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_BIAS, gn_groups=G)
+    # same kernel, same order of accumulation - unless the plain call splits K (few tiles, K >= 1024: partial sums in another order)
+    same = (lambda a, c: torch.equal(a, c)) if 9 * Ci < 1024 else (lambda a, c: (a.float() - c.float()).abs().max().item() < 2e-2)
+    assert same(out, plain)
+    for silu in (True, False):
+        want = SE.groupnorm(plain, gam, bet, B, G, 1e-6, silu)
+        got = SE.groupnorm_from_partials(out, gam, bet, B, G, 1e-6, silu, part)
+        assert (got.float() - want.float()).abs().max().item() < 4e-2 and rel_err(got, want.float().cpu()) < 3e-3
+    res = bf(torch.randn(B * Ho * Wo, Co, generator=g)).to(DEV)
+    plain_r, _, _ = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_RESID, resid=res)
+    out_r, _, _, part_r = SE.conv3x3(xt, B, H, W, wp, b.to(DEV), stride, pad_mode, False, _lib.EPI_RESID, resid=res, gn_groups=G)
+    assert same(out_r, plain_r)
+    want = SE.groupnorm(plain_r, gam, bet, B, G, 1e-6, True)
+    got = SE.groupnorm_from_partials(out_r, gam, bet, B, G, 1e-6, True, part_r)
+    assert (got.float() - want.float()).abs().max().item() < 4e-2 and rel_err(got, want.float().cpu()) < 3e-3
+    # against torch's GroupNorm of the fp32 convolution
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b, stride=stride) if pad_mode == 1 else F.conv2d(x.float(), w.float(), b, stride=stride, padding=1)
+    ref = F.silu(F.group_norm(ref, G, gam.cpu(), bet.cpu(), 1e-6))
+    got = SE.groupnorm_from_partials(out, gam, bet, B, G, 1e-6, True, part)
+    assert rel_err(got, tokens(ref)) < 1e-2
+
+
+def test_conv3x3_gn_rejects_unsupported_shapes():
+    x = torch.zeros(2 * 24 * 24, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(320, 576, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="conv_gn_supported"):
+        SE.conv3x3(x, 2, 24, 24, w, None, gn_groups=32)
+
+
 def test_conv3x3_rejects_narrow_channels():
     x = torch.zeros(64, 8, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="multiple of 64"):
