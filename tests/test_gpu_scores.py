@@ -211,7 +211,7 @@ def test_cscore_rejects_too_many_keypoints():
         cscore_ops.transfer(bank, torch.tensor([0]), torch.tensor([1]), torch.zeros(1, 40, dtype=torch.int32), torch.tensor([40]), 4)
 
 
-@pytest.mark.parametrize("P,C,split", [(16, 256, 0), (14, 192, 64), (6, 132, 0)])
+@pytest.mark.parametrize("P,C,split", [(16, 256, 0), (14, 192, 64), (6, 132, 0), (24, 128, 64), (9, 96, 0)])
 def test_packed_keypoint_tiles_equal_one_tile_per_pair(P, C, split):
     """the key points of several pairs that share a target image ride in one 32-row MFMA tile.  Same per-row arithmetic:
     the packed launch must reproduce the one-tile-per-pair launch BIT FOR BIT on an SPair-shaped pair list (targets reused ~7 times,
