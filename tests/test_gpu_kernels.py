@@ -305,7 +305,9 @@ def test_attention_image_aligned_rejects_other_shapes():
 
 
 @pytest.mark.parametrize("period,stride,first,groups,N,K,epi", [(576, 577, 1, 3, 128, 256, "vt"), (1, 577, 0, 7, 192, 128, "bias"), (64, 65, 1, 37, 1024, 1024, "vt"),
-                                                               (256, 257, 1, 5, 2048, 1024, "act"), (100, 130, 7, 11, 256, 192, "bias")])
+                                                               (256, 257, 1, 5, 2048, 1024, "act"), (100, 130, 7, 11, 256, 192, "bias"),
+                                                               (576, 577, 1, 257, 1024, 1024, "vt"),     # nine tile rounds + a 576-row tail launch (row offset, split-K)
+                                                               (576, 577, 1, 257, 1024, 256, "bias")])   # the same rows with a direct 128x128 tail
 def test_gemm_row_map(period, stride, first, groups, N, K, epi):
     """visrep_gemm_bf16_rows == the plain GEMM on the gathered rows, BITWISE (same kernels, same order of accumulation; only the A row
     addresses differ), with and without the folded LayerNorm (statistics indexed by physical row)."""
@@ -315,7 +317,8 @@ def test_gemm_row_map(period, stride, first, groups, N, K, epi):
     a = bf(torch.randn(phys, K, generator=g)).to(DEV)
     w = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
-    idx = torch.tensor([(r // period) * stride + r % period + first for r in range(rows)], device=DEV)
+    r_ = torch.arange(rows)
+    idx = ((r_ // period) * stride + r_ % period + first).to(DEV)
     gathered = a[idx].contiguous()
     if epi == "vt":
         got = engine.gemm_rows(a, period, stride, first, rows, w, bias, epilogue=_lib.EPI_VT)
