@@ -356,6 +356,33 @@ def main():
             sec = time_kernel(lambda: engine.mhsa(qk_act, vt, B, T, spec.heads, 0.0 if eng.q_prescaled else 0.125))
             which = "attn_fwd<1, pre-scaled Q>" if eng.q_prescaled else "attn_fwd<1>"
         kern["mhsa (577 tok, 16 heads)"] = {"ms": round(sec * 1e3, 4), "tflops": round(4.0 * B * T ** 2 * d / sec / 1e12, 1), "kernel": which}
+        # The same launches IN THE LAYER'S LAUNCH MIX: Q|K -> attention -> out -> fc1 -> fc2, repeated like the 23 layers of the forward, with a HIP
+        # event pair around every launch.  Twenty back-to-back launches of one matrix-bound kernel (the "ms" above) run 3-7 % slower than the same
+        # kernel inside the forward - rocprofv3's average over the forward's launches (profiles/round4_final_kernel_stats.md, `fwd`) sits with the
+        # in-mix figure, so that is the one the roofline object quotes; "ms" (back to back) stays beside it.
+        attn_fn = (lambda: engine.mhsa_cls(qk_act, vt, vcls, B, T, spec.heads)) if which.startswith("attn_fwd_cls") else \
+                  (lambda: engine.mhsa(qk_act, vt, B, T, spec.heads, 0.0 if eng.q_prescaled else 0.125))
+        mix = [("qk  (M x 2048 x 1024, bias)", qk), ("mhsa (577 tok, 16 heads)", attn_fn), ("out (M x 1024 x 1024, bias+residual)", out_proj),
+               ("fc1 (M x 4096 x 1024, bias+QuickGELU)", fc1), ("fc2 (M x 1024 x 4096, bias+residual)", fc2)]
+        flops = {n: f for n, (_, f) in shapes.items()}
+        flops["mhsa (577 tok, 16 heads)"] = 4.0 * B * T ** 2 * d
+        for _ in range(2):
+            for _, fn in mix:
+                fn()
+        torch.cuda.synchronize(dev)
+        MIX_REPS = 12
+        evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in mix] for _ in range(MIX_REPS)]
+        for r in range(MIX_REPS):
+            for i, (_, fn) in enumerate(mix):
+                evs[r][i][0].record()
+                fn()
+                evs[r][i][1].record()
+        torch.cuda.synchronize(dev)
+        for i, (name, _) in enumerate(mix):
+            msec = sum(evs[r][i][0].elapsed_time(evs[r][i][1]) for r in range(MIX_REPS)) / MIX_REPS
+            kern[name]["ms_in_layer_mix"] = round(msec, 4)
+            kern[name]["tflops_in_layer_mix"] = round(flops[name] / (msec * 1e-3) / 1e12, 1)
+        del evs
         top = kern["fc1 (M x 4096 x 1024, bias+QuickGELU)"]
         # the 256x256 kernel on its own: the rows its full rounds cover (the dispatcher hands the last <= 256 rows to a 128x128 launch
         # pair) - this is the launch rocprofv3 lists as gemm_bf16_256<1>, so the two averages can be compared directly
@@ -374,11 +401,15 @@ def main():
         except Exception as e:                                          # never let the extra line take the bench down
             head = {"error": str(e)[:200]}
         traffic, traffic_src = fc1_traffic(args.gemm_variant, B)
-        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
+        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1",
+                "achieved": top["tflops_in_layer_mix"], "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(top["tflops_in_layer_mix"] / PEAK_BF16_TFLOPS, 4),
+                "timing": "HIP event pair around each fc1 dispatch (head launch + its 128x128 tail pair) inside the layer's launch mix, 12 layers' worth; "
+                          "kernels.*.ms = 20 launches back to back",
+                "achieved_back_to_back": top["tflops"], "frac_back_to_back": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_provenance": traffic_src,
                 "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),
-                "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms"], "dominant_kernel_only": head,
+                "flop_per_launch": 2.0 * M * m * d, "ms_per_launch": top["ms_in_layer_mix"], "dominant_kernel_only": head,
                 "whole_forward": {"tflops": round(fl_img * value / world / 1e12, 1),
                                   "frac": round(fl_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                                   "gflop_per_image": round(fl_img / 1e9, 1)},
