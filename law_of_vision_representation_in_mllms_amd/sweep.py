@@ -51,12 +51,16 @@ class Setting:
 
 
 # order of policy/fit.py:20; the two CLIP stacks come first there too, which is what the A score needs (its references).  Diffusion towers run
-# 16 images per launch: SD1.5 at 768 px does 160 / 173 / 180 images/s at batch 4 / 8 / 16 (tools/sd_bench.py, 8.3 GiB peak at 16)
+# 16 images per launch: SD1.5 at 768 px does 160 / 173 / 180 images/s at batch 4 / 8 / 16 (tools/sd_bench.py, 8.3 GiB peak at 16).
+# ViT launch sizes are picked for the GEMMs' tile rounds (256 x 256 tiles on 256 CUs; the N = 1024 projections have 4 column tiles): 1,800
+# images at "128 per launch" are 15 launches of 120 = 4.23 rounds of the out / V GEMMs, i.e. 5 (85 % full); 113 -> 16 launches of 112 / 113 =
+# 3.95-3.98 rounds (99 %), and the Q|K / fc1 GEMMs land on 7.9 / 15.8 likewise.  257-token towers: 7 launches of 257 / 258 images = 4.03
+# rounds (the 8-tile remainder goes to the tail launch) instead of 8 x 225 = 3.53.
 SETTINGS = (
-    Setting("CLIP336", "clip336", (CLIP336,), 336, 128),
-    Setting("CLIP224", "clip224", (CLIP224,), 224, 256),
-    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 256),
-    Setting("DINOv2", "dino", (DINOV2,), 224, 256),
+    Setting("CLIP336", "clip336", (CLIP336,), 336, 113),
+    Setting("CLIP224", "clip224", (CLIP224,), 224, 258),
+    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 258),
+    Setting("DINOv2", "dino", (DINOV2,), 224, 258),
     Setting("SDim", "imsd", (IMSD,), 768, 16),
     Setting("SD1.5", "sd1.5", (SD15,), 768, 16),
     Setting("SDXL", "sdxl", (SDXL,), 512, 16),
@@ -64,8 +68,8 @@ SETTINGS = (
     Setting("SD3", "sd3", (SD3,), 512, 16),
     Setting("SD2.1", "sd2.1", (SD21,), 768, 16),
     Setting("SigLIP", "siglip", (SIGLIP,), 224, 256),
-    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 256),
-    Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 128),
+    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 258),
+    Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 113),
 )
 REFS = ("clip336", "clip224")
 # The dtype the reference runs each tower in on its C path (C_score/extract_feature.py:36-50,80-91: CLIP / OpenCLIP / DINOv2 are built with no
