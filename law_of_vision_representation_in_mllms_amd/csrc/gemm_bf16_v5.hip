@@ -175,6 +175,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         tw.ntm = ntm;
     }
     if (tw.count == 0) return;                                 // uniform per block: no barrier has been executed yet
+#ifdef V5_STAGGER_P                                             // A/B knob (tools/): block j of an XCD starts (j % P) x N sleeps of ~3.9 us late, so that the
+    {                                                           // CUs' output bursts do not coincide (profiles/round4_gemm.md section 6)
+        const int ph = (int)(blockIdx.x / 8) % V5_STAGGER_P;
+        for (int i = 0; i < ph * V5_STAGGER_N; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int nk = p.K / TK;
     const int S = tw.count * nk;                               // K-tiles in this block's stream
 
