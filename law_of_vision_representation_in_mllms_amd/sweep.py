@@ -51,7 +51,8 @@ class Setting:
 
 
 # order of policy/fit.py:20; the two CLIP stacks come first there too, which is what the A score needs (its references).  Diffusion towers run
-# 16 images per launch: SD1.5 at 768 px does 160 / 173 / 180 images/s at batch 4 / 8 / 16 (tools/sd_bench.py, 8.3 GiB peak at 16).
+# 32 images per launch: SD1.5 at 768 px does 211 / 209 / 217 / 215 images/s at batch 16 / 24 / 32 / 48 (tools/sd_bench.py, end of round 4: the
+# UNet's small kernels fill the chip better; 15.7 GiB peak at 32; round 1-3 code: 160 / 173 / 180 at batch 4 / 8 / 16).
 # ViT launch sizes are picked for the GEMMs' tile rounds (256 x 256 tiles on 256 CUs; the N = 1024 projections have 4 column tiles): 1,800
 # images at "128 per launch" are 15 launches of 120 = 4.23 rounds of the out / V GEMMs, i.e. 5 (85 % full); 113 -> 16 launches of 112 / 113 =
 # 3.95-3.98 rounds (99 %), and the Q|K / fc1 GEMMs land on 7.9 / 15.8 likewise.  257-token towers: 7 launches of 257 / 258 images = 4.03
@@ -61,12 +62,12 @@ SETTINGS = (
     Setting("CLIP224", "clip224", (CLIP224,), 224, 258),
     Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 258),
     Setting("DINOv2", "dino", (DINOV2,), 224, 258),
-    Setting("SDim", "imsd", (IMSD,), 768, 16),
-    Setting("SD1.5", "sd1.5", (SD15,), 768, 16),
-    Setting("SDXL", "sdxl", (SDXL,), 512, 16),
-    Setting("DiT", "dit", (DIT,), 512, 16),
-    Setting("SD3", "sd3", (SD3,), 512, 16),
-    Setting("SD2.1", "sd2.1", (SD21,), 768, 16),
+    Setting("SDim", "imsd", (IMSD,), 768, 32),
+    Setting("SD1.5", "sd1.5", (SD15,), 768, 32),
+    Setting("SDXL", "sdxl", (SDXL,), 512, 32),
+    Setting("DiT", "dit", (DIT,), 512, 32),
+    Setting("SD3", "sd3", (SD3,), 512, 32),
+    Setting("SD2.1", "sd2.1", (SD21,), 768, 32),
     Setting("SigLIP", "siglip", (SIGLIP,), 224, 256),
     Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 258),
     Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 113),

@@ -169,8 +169,8 @@ def test_shard_plan_keeps_launches_full_at_world_8():
             plan = S.c_launch_plan(spair, st.batch, world)
             per = -(-1800 // world)
             assert sum(plan) == per and max(plan) <= st.batch and max(plan) - min(plan) <= 1 and len(set(plan)) <= 2
-            if st.batch == 16:
-                assert min(plan) >= 15                                   # diffusion towers: 225 images -> 15 launches of 15
+            if st.batch == 32:
+                assert min(plan) >= 28                                   # diffusion towers: 225 images -> 8 launches of 28 / 29
             else:
                 assert min(plan) >= min(64, per)                         # ViT towers: >= 64 rows per launch
             shapes = S.launch_shapes(st, 100, spair, world - 1, world)
