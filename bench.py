@@ -169,9 +169,10 @@ def score_extras(dev, n_a=256, n_img=1800, n_pairs=12234):
     return out
 
 
-def fp32_tower_extra(dev, spec, weights, batch=64):
-    """The same tower in the reference's C-path precision (fp32: C_score/extract_feature.py:36-45), one batch of 64: the default route
-    (projections as split-bf16 GEMMs on the bf16 matrix pipe where the shapes allow) and the exact-fp32 MFMA route beside it."""
+def fp32_tower_extra(dev, spec, weights, batch=113):
+    """The same tower in the reference's C-path precision (fp32: C_score/extract_feature.py:36-45), one launch of the sweep's size (113 images =
+    one chunk: 3.98 rounds of the N = 1024 GEMMs' tiles; until round 4's second half: 64 images = 2.25 rounds): the default route (projections
+    as split-bf16 GEMMs on the bf16 matrix pipe where the shapes allow) and the exact-fp32 MFMA route beside it."""
     from law_of_vision_representation_in_mllms_amd import engine
     px = torch.randn(batch, 3, spec.image_size, spec.image_size, device=dev)
     T, d, m = spec.tokens, spec.d, spec.mlp

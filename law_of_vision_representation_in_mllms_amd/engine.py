@@ -179,7 +179,7 @@ class VitEngineF32:
     multiple of 4).
     forward() returns fp32 [B, tokens, d]; images are processed in chunks so that the fp32 score matrices stay below `max_ws_bytes`."""
 
-    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 4 << 30, gemm: str = "auto",
+    def __init__(self, spec: ViTSpec, weights: dict, device: Optional[torch.device] = None, max_ws_bytes: int = 8 << 30, gemm: str = "auto",
                  products: Optional[int] = None):
         """gemm: 'split' = projections and attention as split-bf16 products on the bf16 matrix pipe (fp32 values as bf16 planes, fp32
         accumulation, visrep_vit_forward_f32_split); 'native' = exact-fp32 MFMA (visrep_vit_forward_f32); 'auto' = split where the tower's
@@ -266,8 +266,12 @@ class VitEngineF32:
         raise KeyError(ptr)
 
     def chunk(self) -> int:
+        """Images per library call.  Bounded by the workspace budget, then picked for the GEMMs' tile rounds: the persistent 256 x 256 kernel
+        runs ceil(tiles / CUs) rounds unless the remainder is small enough for the tail launch (<= CUs / 4 tiles), and the N = d projections
+        have the fewest tiles per row block - 64 images of a 577-token tower are 2.25 rounds of them (3 run), 113 images 3.98 (4 run)."""
         per = self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), 1)
-        return max(1, min(64, self.max_ws_bytes // max(per, 1)))
+        cap = max(1, min(128, self.max_ws_bytes // max(per, 1)))
+        return best_chunk(self.spec.tokens, self.spec.d, cap)
 
     def workspace(self, B: int) -> torch.Tensor:
         ws = self._ws.get(B)
@@ -306,6 +310,25 @@ class VitEngineF32:
                                                          nb, n_layers, _lib.ptr(ws), _lib.stream_ptr())
                 _lib.check(rc, "visrep_vit_forward_f32")
         return out
+
+
+def best_chunk(tokens: int, d: int, cap: int, cus: int = 256) -> int:
+    """Largest image count <= cap whose [count * tokens, d] GEMM fills whole rounds of 256 x 256 tiles on `cus` CUs (a remainder of up to
+    cus / 16 tiles - a few row blocks - goes to the dispatcher's cheap tail launch) - else the count with the best fill."""
+    def fill(c):
+        tiles = -(-c * tokens // 256) * max(1, d // 256)
+        rounds, rem = divmod(tiles, cus)
+        if rounds >= 1 and rem * 16 <= cus:
+            return 1.0
+        return tiles / ((rounds + (1 if rem else 0)) * cus)
+    best, best_f = cap, -1.0
+    for c in range(cap, max(cap // 2, 1) - 1, -1):
+        f = fill(c)
+        if f >= 0.97:
+            return c
+        if f > best_f:
+            best, best_f = c, f
+    return best
 
 
 def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf16"):

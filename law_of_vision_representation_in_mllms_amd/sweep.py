@@ -53,15 +53,16 @@ class Setting:
 # order of policy/fit.py:20; the two CLIP stacks come first there too, which is what the A score needs (its references).  Diffusion towers run
 # 32 images per launch: SD1.5 at 768 px does 211 / 209 / 217 / 215 images/s at batch 16 / 24 / 32 / 48 (tools/sd_bench.py, end of round 4: the
 # UNet's small kernels fill the chip better; 15.7 GiB peak at 32; round 1-3 code: 160 / 173 / 180 at batch 4 / 8 / 16).
-# ViT launch sizes are picked for the GEMMs' tile rounds (256 x 256 tiles on 256 CUs; the N = 1024 projections have 4 column tiles): 1,800
-# images at "128 per launch" are 15 launches of 120 = 4.23 rounds of the out / V GEMMs, i.e. 5 (85 % full); 113 -> 16 launches of 112 / 113 =
-# 3.95-3.98 rounds (99 %), and the Q|K / fc1 GEMMs land on 7.9 / 15.8 likewise.  257-token towers: 7 launches of 257 / 258 images = 4.03
-# rounds (the 8-tile remainder goes to the tail launch) instead of 8 x 225 = 3.53.
+# ViT launch sizes are picked for the GEMMs' tile rounds (256 x 256 tiles on 256 CUs; the N = 1024 projections have 4 column tiles) and the
+# C leg issues FULL launches + one remainder (plan_launches): 113 images of a 577-token tower = 3.98 rounds of the out / V GEMMs (4 run; 128 or
+# an equalised 120 would be 4.5 / 4.23: 5 run), 7.9 / 15.8 of Q|K / fc1; 256 images of a 257-token tower = 4.02 rounds (the 4-tile remainder goes
+# to the tail launch; an equalised 225 would be 3.53).  The reference-precision engine cuts a launch into chunks by the same rule
+# (engine.best_chunk: 113 / 128 images).
 SETTINGS = (
     Setting("CLIP336", "clip336", (CLIP336,), 336, 113),
-    Setting("CLIP224", "clip224", (CLIP224,), 224, 258),
-    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 258),
-    Setting("DINOv2", "dino", (DINOV2,), 224, 258),
+    Setting("CLIP224", "clip224", (CLIP224,), 224, 256),
+    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 256),
+    Setting("DINOv2", "dino", (DINOV2,), 224, 256),
     Setting("SDim", "imsd", (IMSD,), 768, 32),
     Setting("SD1.5", "sd1.5", (SD15,), 768, 32),
     Setting("SDXL", "sdxl", (SDXL,), 512, 32),
@@ -69,7 +70,7 @@ SETTINGS = (
     Setting("SD3", "sd3", (SD3,), 512, 32),
     Setting("SD2.1", "sd2.1", (SD21,), 768, 32),
     Setting("SigLIP", "siglip", (SIGLIP,), 224, 256),
-    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 258),
+    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 256),
     Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 113),
 )
 REFS = ("clip336", "clip224")
@@ -302,13 +303,16 @@ def _c_args(P: int, window: int = 5):
                            MODEL="fused")
 
 
-def plan_launches(n: int, batch: int) -> List[int]:
-    """n images in ceil(n / batch) launches of (almost) equal size: at most two distinct shapes, differing by one, so that a rank's
-    share never ends in a near-empty launch (225 images at batch 16 -> 15 x 15, not 14 x 16 + 1) and every shape can be warmed
-    (HIP-graph captured) in setup."""
+def plan_launches(n: int, batch: int, equal: bool = True) -> List[int]:
+    """n images in ceil(n / batch) launches, at most two distinct shapes (every shape is warmed - HIP-graph captured - in setup).
+    equal (diffusion towers): (almost) equal sizes, differing by one, so that a rank's share never ends in a near-empty launch (225 images
+    at batch 32 -> 8 x 28 / 29, not 7 x 32 + 1).  Not equal (ViT towers): full launches + one remainder - their launch size is picked for
+    the GEMMs' tile rounds (SETTINGS), which an equalised 225 instead of 256 would undo (3.5 rounds of the N = 1024 projections: 4 run)."""
     if n <= 0:
         return []
     k = (n + batch - 1) // batch
+    if not equal:
+        return [batch] * (n // batch) + ([n % batch] if n % batch else [])
     return [n // k + (1 if j < n % k else 0) for j in range(k)]
 
 
@@ -336,9 +340,10 @@ def launch_shapes(setting: Setting, n_a_images: int, spair, rank: int, world: in
 
 
 def c_launch_plan(spair: Sequence[SpairCategory], batch: int, world: int) -> List[int]:
-    """Launch sizes of ONE rank's share of a setting's C images (the same on every rank: short ranks repeat their last image)."""
+    """Launch sizes of ONE rank's share of a setting's C images (the same on every rank: short ranks repeat their last image).
+    Launch batches above 32 are the ViT towers': full launches + a remainder (plan_launches)."""
     n_items = sum(c.n_images for c in spair)
-    return plan_launches((n_items + world - 1) // world, batch)
+    return plan_launches((n_items + world - 1) // world, batch, equal=batch <= 32)
 
 
 def c_exchange_plan(n_items: int, item_owner: Sequence[int], world: int, off: int, sz: int):
