@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every test gets a wall-clock bound (pytest-timeout, when installed): a rendezvous that never completes or a wedged subprocess fails
+    ONE test after five minutes instead of hanging the suite (the 2-rank gloo tests and the full-size GPU tests finish in well under a minute)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(300))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
