@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """SD1.5 feature tower at the reference's working point (768x768 input, up_ft_index 0, t=261 -> [B, 576, 1280]):
-images/s and per-stage times with HIP events.  Synthetic weights.  Usage: python tools/sd_bench.py [batch] [reps] [side]"""
+images/s and per-stage times with HIP events.  Synthetic weights.  Usage: python tools/sd_bench.py [batch] [reps] [side] [SD_SPECS key]"""
 import os
 import sys
 import time
@@ -15,13 +15,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 side = int(sys.argv[3]) if len(sys.argv) > 3 else 768
 dev = torch.device("cuda:0")
-sp = SW.SD_SPECS["runwayml/stable-diffusion-v1-5"]
+sp = SW.SD_SPECS[sys.argv[4] if len(sys.argv) > 4 else "runwayml/stable-diffusion-v1-5"]
 t0 = time.time()
 eng = SE.SdEngine(sp, SW.synthetic_unet(sp.unet, 21, 1), SW.synthetic_vae(sp.vae, 22), dev)
 print(f"weights + packing: {time.time() - t0:.1f}s", flush=True)
 rs = np.random.RandomState(0)
 img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32)).to(dev)
-pe = torch.from_numpy(rs.standard_normal((1, 77, 768)).astype(np.float32))
+pe = torch.from_numpy(rs.standard_normal((1, 77, sp.unet.cross_dim)).astype(np.float32))
 eng.set_prompt(pe)
 eng.set_timestep(261)
 
