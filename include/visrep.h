@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 400   /* round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures) */
+#define VISREP_VERSION 410   /* round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };

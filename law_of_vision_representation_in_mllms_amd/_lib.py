@@ -11,7 +11,7 @@ import threading
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VISREP_LIB") or os.path.join(_PKG, "libvisrep_hip.so")   # VISREP_LIB: diagnostic builds only
 
-ABI_VERSION = 400                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
+ABI_VERSION = 410                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
 BF16, F32 = 0, 1
 EPI_BIAS, EPI_ACT, EPI_RESID, EPI_VT, EPI_PATCH, EPI_F32 = range(6)
 ACT = {"none": 0, "quick_gelu": 1, "gelu": 2, "gelu_erf": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3}
