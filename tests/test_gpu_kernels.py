@@ -307,7 +307,8 @@ def test_attention_image_aligned_rejects_other_shapes():
 @pytest.mark.parametrize("period,stride,first,groups,N,K,epi", [(576, 577, 1, 3, 128, 256, "vt"), (1, 577, 0, 7, 192, 128, "bias"), (64, 65, 1, 37, 1024, 1024, "vt"),
                                                                (256, 257, 1, 5, 2048, 1024, "act"), (100, 130, 7, 11, 256, 192, "bias"),
                                                                (576, 577, 1, 257, 1024, 1024, "vt"),     # nine tile rounds + a 576-row tail launch (row offset, split-K)
-                                                               (576, 577, 1, 257, 1024, 256, "bias")])   # the same rows with a direct 128x128 tail
+                                                               (576, 577, 1, 257, 1024, 256, "bias"),    # the same rows with a direct 128x128 tail
+                                                               (64, 65, 1, 9, 256, 320, "f32")])         # fp32 output (K % 64 == 0 only: the 64-byte-row kernel)
 def test_gemm_row_map(period, stride, first, groups, N, K, epi):
     """visrep_gemm_bf16_rows == the plain GEMM on the gathered rows, BITWISE (same kernels, same order of accumulation; only the A row
     addresses differ), with and without the folded LayerNorm (statistics indexed by physical row)."""
@@ -320,6 +321,10 @@ def test_gemm_row_map(period, stride, first, groups, N, K, epi):
     r_ = torch.arange(rows)
     idx = ((r_ // period) * stride + r_ % period + first).to(DEV)
     gathered = a[idx].contiguous()
+    if epi == "f32":
+        got = engine.gemm_rows(a, period, stride, first, rows, w, bias, epilogue=_lib.EPI_F32)
+        assert got.dtype == torch.float32 and torch.equal(got, engine.gemm(gathered, w, bias, epilogue=_lib.EPI_F32))
+        return                                                               # (the LayerNorm fold below has no fp32-output form)
     if epi == "vt":
         got = engine.gemm_rows(a, period, stride, first, rows, w, bias, epilogue=_lib.EPI_VT)
         want = engine.linear_vt(gathered, w, bias)

@@ -272,3 +272,18 @@ def test_c_exchange_plan_sends_every_row_once_to_its_owner():
             off += sz
         assert seen == set(range(len(items)))                       # every image's maps reach their owner, once
         assert rows_on_fabric <= len(items) and (world == 1) == (rows_on_fabric == 0)
+
+
+def test_reference_precision_chunks_fill_whole_tile_rounds():
+    """engine.best_chunk: the image count per library call of the reference-precision engine is the largest one under the workspace cap whose
+    [count * tokens, 1024] GEMM runs whole rounds of 256 x 256 tiles on 256 CUs (plus at most 16 remainder tiles for the tail launch)."""
+    from law_of_vision_representation_in_mllms_amd.engine import best_chunk
+
+    def rounds(c, T, d=1024):
+        tiles = -(-c * T // 256) * (d // 256)
+        return divmod(tiles, 256)
+    c = best_chunk(577, 1024, 128)
+    assert 113 <= c <= 128 and rounds(c, 577)[1] <= 16 and rounds(c, 577)[0] == 4          # 64 images (the old chunk) = 2.25 rounds: 3 run
+    assert best_chunk(257, 1024, 128) == 128 and rounds(128, 257) == (2, 4)
+    assert best_chunk(257, 1024, 64) == 64 and rounds(64, 257) == (1, 4)
+    assert 1 <= best_chunk(577, 1024, 1) <= 1 and best_chunk(50, 768, 7) == 7                 # tiny caps: whatever fits
