@@ -287,3 +287,21 @@ def test_reference_precision_chunks_fill_whole_tile_rounds():
     assert best_chunk(257, 1024, 128) == 128 and rounds(128, 257) == (2, 4)
     assert best_chunk(257, 1024, 64) == 64 and rounds(64, 257) == (1, 4)
     assert 1 <= best_chunk(577, 1024, 1) <= 1 and best_chunk(50, 768, 7) == 7                 # tiny caps: whatever fits
+
+
+def test_resident_pixels_are_the_same_images():
+    """sweep.ResidentPixels (the default image source: drawn in setup, index_select in the timed legs) returns exactly synthetic_pixels' images,
+    whatever was prefetched, in whatever order and batch shape; c_item_ids lists the ids c_score_of asks for."""
+    src = S.ResidentPixels("cpu", torch.float32)
+    src.prefetch([5, 100003, 7, 5], 12)
+    src.prefetch([9, 7], 12)                                                 # grows the store, keeps the rows
+    src.prefetch([1, 2], 20)
+    for ids, size in (([7, 5, 9], 12), ([100003], 12), ([2, 1, 2], 20), ([5, 6], 12), ([3], 16)):       # the last two: not (all) prefetched
+        assert torch.equal(src(ids, size), S.synthetic_pixels(ids, size, "cpu", torch.float32))
+    spair = S.synthetic_spair(60, 90)
+    for world in (1, 3):
+        got = [S.c_item_ids(spair, r, world) for r in range(world)]
+        n = sum(c.n_images for c in spair)
+        assert all(len(g) == -(-n // world) for g in got)
+        flat = sorted({i for g in got for i in g})
+        assert flat == sorted(ci * 100000 + i for ci, c in enumerate(spair) for i in range(c.n_images))
