@@ -316,6 +316,7 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
     if (variant == 5 && visrep_gemm_v5_supports(a)) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
+        b.dbg_buf = g_visrep_gemm_dbg_buf;
         return visrep_gemm_v5_dispatch(b, s);
     }
 #ifdef VISREP_EXPERIMENTS

@@ -328,7 +328,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int kt = 0, ti = 0;
+#ifdef V5_TILE_TIMING                                       // diagnostic build (-DV5_TILE_TIMING, tools/gemm_tile_timing.py): cycle stamps at the tile boundaries of block 0
+        const bool timing = p.dbg_buf && blockIdx.x == 0 && wn == 0;      // wave 0 (group 0) and wave 4 (group 1)
+        unsigned long long t_loop = 0, t_epi = 0, t_mark = 0;
+#endif
         if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
+#ifdef V5_TILE_TIMING
+        t_mark = __builtin_readcyclecounter();
+#endif
         for (int s = 0; s < S; ++s) {
             const unsigned sx = lds0 + (unsigned)((2 * s) % NSLOT) * XW_BYTES, sw = lds0 + (unsigned)((2 * s + 1) % NSLOT) * XW_BYTES;
             bf16x8 xf[8], wf[4];
@@ -372,6 +379,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 kt = 0;
                 int m0, n0; tw.decode(ti, m0, n0); ++ti;
                 const int mb = m0 + grp * 128, nb = n0 + wn * 64;
+#ifdef V5_TILE_TIMING
+                { const unsigned long long t = __builtin_readcyclecounter(); t_loop += t - t_mark; t_mark = t; }      // K loop of this tile (incl. its waits)
+#endif
                 if (V5_EPI_EARLY && G == 0) barrier();          // this iteration's closing barrier, taken before the epilogue (see V5_EPI_EARLY)
                 if constexpr (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, hi);
                 else if constexpr (EPI == EPI_F32X) gemm_epilogue_f32x<8, 4>(p, acc, mb, nb, fr, hi);
@@ -381,11 +391,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (!(V5_EPI_EARLY && G == 0)) barrier();
+#ifdef V5_TILE_TIMING
+                { const unsigned long long t = __builtin_readcyclecounter(); t_epi += t - t_mark; t_mark = t; }       // barrier(s) + epilogue of this tile
+#endif
             } else {
                 barrier();
             }
         }
         if (G == 0) barrier();                                 // group 1 executed one extra barrier up front
+#ifdef V5_TILE_TIMING
+        if (timing && lane == 0) { p.dbg_buf[G * 8 + 0] = t_loop; p.dbg_buf[G * 8 + 1] = t_epi; p.dbg_buf[G * 8 + 2] = (unsigned long long)tw.count; }
+#endif
     };
     if (grp == 0) body(std::integral_constant<int, 0>{});
     else body(std::integral_constant<int, 1>{});

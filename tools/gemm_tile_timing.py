@@ -1,0 +1,35 @@
+"""Where a tile round of the persistent 256x256 GEMM goes (diagnostic build: build.build_variant_lib('tiletiming', ['-DV5_TILE_TIMING'], only=['gemm_bf16_v5.hip']), VISREP_LIB=.../libvisrep_hip_tiletiming.so;
+the K loop itself is the production one):
+shader-clock stamps of block 0's wave 0 (group 0) and wave 4 (group 1) at the tile boundaries - the K loop of a tile (first fragment read to the
+counted wait behind its last MFMA segment) and the rest (closing barrier(s) + epilogue + accumulator reset), averaged over the block's tiles."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from law_of_vision_representation_in_mllms_amd import _lib, engine
+dev = "cuda:0"
+lib = _lib.load()
+buf = torch.zeros(16, dtype=torch.int64, device=dev)
+lib.visrep_debug_gemm_timing_buffer(_lib.ptr(buf))
+M = 147456
+for (N, K, epi, tag) in ((4096, 1024, "act", "fc1"), (2048, 1024, "bias", "Q|K"), (1024, 1024, "resid", "out"), (1024, 4096, "resid", "fc2"), (1024, 1024, "vt", "V^T")):
+    a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    o = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    def run():
+        if epi == "act": engine.gemm(a, w, bias, _lib.EPI_ACT, act="quick_gelu", out=o)
+        elif epi == "bias": engine.gemm(a, w, bias, _lib.EPI_BIAS, out=o)
+        elif epi == "resid": engine.gemm(a, w, bias, _lib.EPI_RESID, resid=o, out=o)
+        else: engine.linear_vt(a, w, bias)
+    for _ in range(3):
+        buf.zero_(); run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    buf.zero_(); run(); torch.cuda.synchronize()
+    t = buf.cpu().tolist()
+    for g in range(2):
+        loop, epi_c, n = t[g * 8], t[g * 8 + 1], max(t[g * 8 + 2], 1)
+        tot = loop + epi_c
+        print(f"{tag:4s} group {g}: {n} tiles  K loop {loop / n:8.0f} cyc ({loop / n / (K // 64):6.0f} per K-tile)  boundary {epi_c / n:8.0f} cyc = {100 * epi_c / max(tot, 1):4.1f} % of the block's time;  launch {ms:.4f} ms", flush=True)
