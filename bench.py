@@ -177,10 +177,8 @@ def fp32_tower_extra(dev, spec, weights, batch=113):
     px = torch.randn(batch, 3, spec.image_size, spec.image_size, device=dev)
     T, d, m = spec.tokens, spec.d, spec.mlp
     fl = N_LAYERS * (2 * T * d * 3 * d + 2 * T * d * d + 4 * T * T * d + 4 * T * d * m) * batch
-    out = {"batch": batch, "default_products": engine.DEFAULT_SPLIT_PRODUCTS}
-    for route, products in (("auto", None), ("split", 6), ("native", None)):
-        if products == engine.DEFAULT_SPLIT_PRODUCTS:
-            continue                                                          # already measured as the default
+    out = {"batch": batch, "default_products": engine.DEFAULT_SPLIT_PRODUCTS, "sweep_products": engine.THROUGHPUT_SPLIT_PRODUCTS}
+    for route, products in (("split", engine.THROUGHPUT_SPLIT_PRODUCTS), ("split", engine.DEFAULT_SPLIT_PRODUCTS), ("native", None)):
         eng = engine.VitEngineF32(spec, weights, dev, gemm=route, products=products)
         for _ in range(2):
             eng.forward(px, n_layers=N_LAYERS)
@@ -220,6 +218,10 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
     ap.add_argument("--sweep", default="full", choices=["off", "reduced", "full"])
     ap.add_argument("--sweep-precision", default="reference", choices=["reference", "bf16", "fp32"])   # reference: A leg bf16, C leg per the reference's scripts
+    # split-bf16 product set of the sweep's fp32 ViT engines: the throughput sweep OPTS INTO three products over two-plane operands (validated at
+    # full size on synthetic weights, profiles/round4_precision.md); the drop-in extraction path's default is the fp32-equivalent six.  The
+    # choice is recorded in sweep.fp32_products and in every fp32 setting's dtype label.
+    ap.add_argument("--sweep-fp32-products", type=int, default=3, choices=[3, 4, 6])
     ap.add_argument("--no-scores", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 5])
     args = ap.parse_args()
@@ -493,7 +495,7 @@ def main():
             torch.cuda.empty_cache()
             from law_of_vision_representation_in_mllms_amd import sweep as SW
             spair = SW.synthetic_spair() if args.sweep == "full" else SW.synthetic_spair(180, 1224)
-            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev, precision=args.sweep_precision, also_bf16=True)
+            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev, precision=args.sweep_precision, also_bf16=True, fp32_products=args.sweep_fp32_products)
             sweep["size"] = args.sweep
         except Exception as e:                                           # the headline line must survive a sweep failure
             sweep = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -72,6 +72,9 @@ int visrep_debug_gemm_timing_buffer(void* dev_u64x16);
  * concurrently gives each stream its own (up to 8 per device).  (NULL, 0) detaches.  Both are thread-safe. */
 int visrep_set_scratch(void* ptr, size_t bytes);
 int visrep_set_stream_scratch(void* stream, void* ptr, size_t bytes);
+/* Compute units of the CURRENT device as the dispatchers count them (cached per device; 256 on MI355X).  Callers that size launches for
+ * whole tile rounds (engine.best_chunk, the sweep's launch plan) use it so that their arithmetic is the dispatcher's on any part. */
+int visrep_device_cu_count(void);
 
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
  * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from
@@ -283,6 +286,15 @@ int visrep_ascore_maxcos(const void* other, const void* ref, int n_img, int Nt, 
 int visrep_ascore_row_scale(const void* x, long rows, int D, int dtype, float* scale, void* stream);
 int visrep_ascore_maxcos_scaled(const void* other, const void* ref, const float* other_scale, const float* ref_scale, int n_img, int Nt,
                                 int Nr, int D, int dtype, float* scores, void* workspace, void* stream);
+
+/* The A score in the REFERENCE'S OWN ARITHMETIC on bf16 tensors: A_score/compute.py:12-15,54-72 executed by torch on bf16 inputs rounds the
+ * result of EVERY op to bf16 (norm, divide, the element-wise products inside F.cosine_similarity, their sum, the mean) - which is what the
+ * published table holds (policy/ablations_t.csv: 1.0078125 for CLIP336 against itself).  other / ref: bf16 [n_img, Nt | Nr, D] contiguous,
+ * any D; scores fp32 [n_img], each a bf16-representable value as `.item()` of the reference's bf16 scalar; workspace of
+ * visrep_ascore_refarith_workspace_bytes().  VALU kernel (the rounded products are not a matrix product): a parity mode. */
+size_t visrep_ascore_refarith_workspace_bytes(int n_img, int Nt, int Nr, int D);
+int visrep_ascore_maxcos_refarith(const void* other, const void* ref, int n_img, int Nt, int Nr, int D, float* scores, void* workspace,
+                                  void* stream);
 
 /* ---- C score (C_score/utils/utils_correspondence.py:345-382 calculate_keypoint_transformation with get_flow,
  * C_score/pck_train.py:24-29 normalize_feats): feats = bank of [C, P*P] fp32 maps; per pair image indices, source

@@ -19,6 +19,10 @@ base_folder = '/any/path/mmbench'
 # The subfolders for features (compute.py:10)
 subfolders = ['clip336', 'clip224', 'dino', 'dit', 'imsd', 'openclip', 'sd1.5', 'sd2.1', 'sd3', 'sdxl']
 results = {}
+# "exact" (default): exact products + fp32 accumulation on fp32-upcast semantics - the parity definition of SURVEY F4.
+# "reference": the reference script's IN-DTYPE arithmetic when the dumped tensors are bf16 (every op of compute.py:12-15,54-72 rounds to
+# bf16 - what policy/ablations_t.csv was produced with); fp32 tensors score identically in both modes.  VISREP_ASCORE_ARITHMETIC overrides.
+arithmetic = os.environ.get("VISREP_ASCORE_ARITHMETIC", "exact")
 
 
 def normalize_feat(feat, epsilon=1e-10):
@@ -51,9 +55,11 @@ def _shard(n, rank, world):
     return list(range(rank, n, world))
 
 
-def _score_batch(other, ref, other_scale=None, ref_scale=None):
+def _score_batch(other, ref, other_scale=None, ref_scale=None, arithmetic="exact"):
     """[n, Nt, D] x [n, Nr, D] -> [n] on the device: the HIP kernel (no CPU fallback; tests may monkeypatch this hook)."""
     from .. import ascore_ops
+    if arithmetic == "reference" and other.dtype == torch.bfloat16 and ref.dtype == torch.bfloat16:
+        return ascore_ops.max_cos_mean(other, ref, arithmetic="reference")        # torch's bf16 op chain, rounding by rounding
     return ascore_ops.max_cos_mean(other, ref, other_scale, ref_scale)
 
 
@@ -73,10 +79,13 @@ def per_image_scores(other_tensors, ref_tensors, idx, device="cuda"):
     return per_image_scores_multi(other_tensors, [ref_tensors], idx, device)[0]
 
 
-def per_image_scores_multi(other_tensors, ref_sets, idx, device="cuda", ref_cache=None):
+def per_image_scores_multi(other_tensors, ref_sets, idx, device="cuda", ref_cache=None, arithmetic=None):
     """One {image index: score} per reference set.  Every stack of tokens goes to the device once and is normalised once: the
     encoder's tokens serve all references, and with `ref_cache` (a dict kept by the caller) a reference stack serves all encoders
     - the reference script re-normalises both inside its innermost loop (compute.py:54-56)."""
+    mode = globals()["arithmetic"] if arithmetic is None else arithmetic
+    if mode not in ("exact", "reference"):
+        raise ValueError(f"arithmetic must be 'exact' or 'reference', got {mode!r}")
     outs = [{} for _ in ref_sets]
     groups = {}
     for i in idx:
@@ -95,14 +104,17 @@ def per_image_scores_multi(other_tensors, ref_sets, idx, device="cuda", ref_cach
                 if ref_cache is not None:
                     ref_cache[ck] = (r, r_scale)
             same = r.dtype == o.dtype
-            s = _score_batch(o, r, o_scale if same else None, r_scale if same else None).double().cpu()
+            if mode == "reference":
+                s = _score_batch(o, r, o_scale if same else None, r_scale if same else None, arithmetic="reference").double().cpu()
+            else:
+                s = _score_batch(o, r, o_scale if same else None, r_scale if same else None).double().cpu()
             for j, i in enumerate(ids):
                 outs[k][i] = float(s[j])
     return outs
 
 
-def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True):
-    """Returns {subfolder: A score}; mirrors the main loop compute.py:30-85."""
+def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True, arithmetic=None):
+    """Returns {subfolder: A score}; mirrors the main loop compute.py:30-85.  arithmetic: None = the module-level `arithmetic`."""
     global base_folder, results
     if base is not None:
         base_folder = base
@@ -124,7 +136,7 @@ def compute(base=None, subs=None, n_images=100, device="cuda", verbose=True):
             continue
         n = min(len(clip336_tensors), len(clip224_tensors), len(other_tensors))       # zip() semantics, compute.py:51
         idx = _shard(n, rank, world)
-        s336, s224 = per_image_scores_multi(other_tensors, [clip336_tensors, clip224_tensors], idx, device, ref_cache)
+        s336, s224 = per_image_scores_multi(other_tensors, [clip336_tensors, clip224_tensors], idx, device, ref_cache, arithmetic)
         if dist:
             acc = torch.tensor([sum(s336.values()), sum(s224.values()), float(len(idx))], dtype=torch.float64, device=device)
             dist.all_reduce(acc)
@@ -146,11 +158,13 @@ def main(argv=None):
     ap.add_argument("--base-folder", default=base_folder)
     ap.add_argument("--subfolders", nargs="*", default=None)
     ap.add_argument("--n-images", type=int, default=100)
+    ap.add_argument("--arithmetic", default=None, choices=["exact", "reference"],
+                    help="reference = the script's in-dtype arithmetic on bf16 tensors (per-op bf16 rounding: the published table's numbers)")
     a = ap.parse_args(argv)
     from .. import dist_env
     owned = dist_env.init_from_env()                                  # under torchrun: one process per GPU, images sharded over ranks
     try:
-        return compute(a.base_folder, a.subfolders, a.n_images, device="cuda" if torch.cuda.is_available() else "cpu")
+        return compute(a.base_folder, a.subfolders, a.n_images, device="cuda" if torch.cuda.is_available() else "cpu", arithmetic=a.arithmetic)
     finally:
         dist_env.finalize(owned)
 

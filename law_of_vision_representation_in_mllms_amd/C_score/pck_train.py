@@ -136,8 +136,11 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     sl = slice(lo, hi)
     _check_patch_idx(idx[sl], P)
     src, trg = torch.from_numpy(slot[0::2][sl].copy()), torch.from_numpy(slot[1::2][sl].copy())
+    # the packing of the key-point rows is host work on host arrays (memoised per pair list): built here, once per category, from the numpy
+    # index tables - transfer() then neither downloads nor hashes anything
+    packed = cscore_ops.packed_rows_on(bank_t.device, slot[0::2][sl], slot[1::2][sl], idx[sl], nkp[sl].numpy()) if layout == "pc" and hi > lo else None
     xy = cscore_ops.transfer(bank_t, src, trg, torch.from_numpy(idx[sl]), nkp[sl], P, window=args.SOFT_EVAL_WINDOW,
-                             soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, split=split, layout=layout)
+                             soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, split=split, layout=layout, packed=packed)
     if adapt_flip:
         xy = _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t, layout, slot, sl, src, trg, xy, P, dev, models)
     alphas = shown_alphas = (0.1, 0.05, 0.01) if args.EVAL_DATASET != 'pascal' else (0.1, 0.05, 0.15)

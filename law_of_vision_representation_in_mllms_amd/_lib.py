@@ -97,11 +97,14 @@ SIGNATURES = {
     "visrep_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_row_rnorm_f32": (_i, [_vp, _l, _i, _f, _vp, _vp]),
+    "visrep_device_cu_count": (_i, []),
     "visrep_mutual_nn_distance": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_ascore_row_scale": (_i, [_vp, C.c_long, _i, _i, _vp, _vp]),
     "visrep_ascore_maxcos_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "visrep_ascore_refarith_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "visrep_ascore_maxcos_refarith": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_cscore_transfer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "visrep_cscore_transfer_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "visrep_pck_count": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _vp]),

@@ -32,12 +32,32 @@ def row_scales(x: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def max_cos_mean(other: torch.Tensor, ref: torch.Tensor, other_scale: Optional[torch.Tensor] = None,
-                 ref_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 ref_scale: Optional[torch.Tensor] = None, arithmetic: str = "exact") -> torch.Tensor:
     """scores[i] = mean_t max_s cos(other[i, t], ref[i, s]);  other [n, Nt, D], ref [n, Nr, D] on the GPU.
-    other_scale / ref_scale: row_scales() of the same tensors (same dtype path), or None to compute them in this call."""
+    other_scale / ref_scale: row_scales() of the same tensors (same dtype path), or None to compute them in this call.
+    arithmetic: "exact" (default) = exact products, fp32 accumulation (MFMA; the parity definition on fp32-upcast inputs, SURVEY F4);
+    "reference" = the arithmetic torch runs A_score/compute.py:12-15,54-72 in when the dumped tensors are bf16 - every op's result rounded
+    to bf16 (norm, divide, each product inside F.cosine_similarity, their sum, the mean), i.e. the numbers the reference PRINTS
+    (policy/ablations_t.csv: 1.0078125 for CLIP336 against itself).  bf16 inputs only; the scores come back as fp32 holding bf16 values."""
     lib = _lib.require_gpu()
     if other.dim() != 3 or ref.dim() != 3 or other.shape[0] != ref.shape[0] or other.shape[2] != ref.shape[2]:
         raise ValueError("expected other [n, Nt, D] and ref [n, Nr, D]")
+    if arithmetic not in ("exact", "reference"):
+        raise ValueError(f"arithmetic must be 'exact' or 'reference', got {arithmetic!r}")
+    if arithmetic == "reference":
+        if other.dtype != torch.bfloat16 or ref.dtype != torch.bfloat16:
+            raise ValueError("arithmetic='reference' reproduces torch's bf16 op chain: both tensors must be bf16 (fp32 tensors: the default "
+                             "'exact' mode already is the reference's fp32 arithmetic up to summation order)")
+        if other_scale is not None or ref_scale is not None:
+            raise ValueError("arithmetic='reference' normalises in bf16 itself: precomputed fp32 row scales do not apply")
+        other, ref = other.contiguous(), ref.contiguous()
+        n, Nt, D = other.shape
+        Nr = ref.shape[1]
+        scores = torch.empty(n, dtype=torch.float32, device=other.device)
+        ws = torch.empty(lib.visrep_ascore_refarith_workspace_bytes(n, Nt, Nr, D), dtype=torch.uint8, device=other.device)
+        _lib.check(lib.visrep_ascore_maxcos_refarith(_lib.ptr(other), _lib.ptr(ref), n, Nt, Nr, D, _lib.ptr(scores), _lib.ptr(ws), _lib.stream_ptr()),
+                   "visrep_ascore_maxcos_refarith")
+        return scores
     if other.dtype == torch.bfloat16 and ref.dtype == torch.bfloat16 and other.shape[2] % 16 == 0:
         dt = _lib.BF16
     else:

@@ -53,14 +53,29 @@ def pack_rows(img1: np.ndarray, img2: np.ndarray, patch_idx: np.ndarray, nkp: np
 _PACK_CACHE: "dict[tuple, tuple]" = {}
 
 
-def packed_rows_on(device, img1, img2, patch_idx, nkp):
-    """(rows_tab, tgt) of pack_rows as device tensors, memoised on the pair list's content: an evaluation visits the same (category, map
-    size) pair lists once per setting - 13 times in the sweep - and the packing is host work (~5 us per pair)."""
+def packed_rows_on(device, img1, img2, patch_idx, nkp, rows: int = 32):
+    """(rows_tab, tgt) of pack_rows as device tensors, memoised on the pair list's CONTENT: an evaluation visits the same (category, map
+    size) pair lists once per setting - 13 times in the sweep - and the packing is host work (~5 us per pair).
+
+    Callers that hold the pair list on the host (C_score.pck_train._compute_pck does) pass numpy arrays / CPU tensors: nothing is copied
+    off the device and no stream is synchronised.  Device tensors are accepted and downloaded (one sync) - pass `packed=` to transfer()
+    to keep that out of a timed region.  The key is a 128-bit digest of the four arrays' bytes plus their shapes and dtypes (Python's
+    64-bit hash() of the bytes could collide silently)."""
+    import hashlib
     arrs = [np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t) for t in (img1, img2, patch_idx, nkp)]
-    key = (str(device),) + tuple(hash(a.tobytes()) for a in arrs) + tuple(a.shape for a in arrs)
+    a1, a2, aidx, ank = arrs
+    if aidx.ndim != 2 or a1.ndim != 1 or a2.shape != a1.shape or ank.shape != a1.shape or aidx.shape[0] != a1.shape[0]:
+        raise ValueError("packed key-point tiles: img1 / img2 / nkp must be [n] and patch_idx [n, kmax]")
+    if ank.size and (int(ank.min()) < 0 or int(ank.max()) > min(aidx.shape[1], rows)):
+        raise ValueError(f"packed key-point tiles: nkp must lie in [0, min(kmax = {aidx.shape[1]}, {rows})], got [{int(ank.min())}, {int(ank.max())}]")
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrs:
+        h.update(str((a.shape, a.dtype.str)).encode())
+        h.update(a.tobytes())
+    key = (str(device), rows, h.hexdigest())
     hit = _PACK_CACHE.get(key)
     if hit is None:
-        tab, tgt = pack_rows(*arrs)
+        tab, tgt = pack_rows(a1, a2, aidx, ank, rows)
         hit = (torch.from_numpy(tab).to(device), torch.from_numpy(tgt).to(device))
         if len(_PACK_CACHE) >= 256:
             _PACK_CACHE.pop(next(iter(_PACK_CACHE)))
@@ -82,7 +97,10 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     contiguous row, which is what the kernel wants (C and split multiples of 4).
     packed (layout "pc" only; default on): key points of the pairs of one target image share 32-row MFMA tiles (pack_rows) - ~2.3x fewer
     tiles and target-map passes on SPair-shaped pair lists; the per-row arithmetic is the unpacked kernel's, bit for bit.  True / None = pack
-    here (memoised on the pair list); a (rows_tab, tgt) tuple from packed_rows_on() = use that packing; False = one tile per pair.
+    here (memoised on the pair list; device-resident index tensors are downloaded for that - one stream sync per call);
+    a (rows_tab, tgt) tuple from packed_rows_on() = use that packing (no host work, no sync); False = one tile per pair.
+    sort_pairs only concerns the one-tile-per-pair route (the packed route always groups by target image): asking for
+    sort_pairs=False together with packing is refused instead of silently ignored.
     """
     if soft_eval and window < 0:
         # utils_correspondence.py:326-329: a negative window selects apply_gaussian_kernel (sigma = -window), which is hard-wired
@@ -103,6 +121,10 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     if packed is not False:
         if layout != "pc":
             raise ValueError("packed key-point tiles need the position-major layout 'pc'")
+        if not sort_pairs:
+            raise ValueError("sort_pairs=False has no meaning on the packed route (tiles are grouped by target image); pass packed=False")
+        if kmax > 32:
+            raise ValueError(f"at most 32 key points per pair (patch_idx has {kmax} columns)")
         tab_d, tgt_d = packed if isinstance(packed, tuple) else packed_rows_on(dev, img1, img2, patch_idx, nkp)
         xy = torch.zeros(n, kmax, 2, dtype=torch.float32, device=dev)
         if tgt_d.shape[0]:

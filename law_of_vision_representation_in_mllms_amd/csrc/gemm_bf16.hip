@@ -400,6 +400,7 @@ int run_one(const GemmArgs& a, hipStream_t s, int variant) {
     const bool emit = v2_emits_stats(a, variant);
     if (emit) b.stat_slots = a.N / 64; else b.stat_partial = nullptr;
     const int rc = dispatch_one(b, s, variant);
+    if (rc == VISREP_ERR_LAUNCH) return visrep_set_error(VISREP_ERR_LAUNCH, "gemm: launch failed");   // appends a failed LDS opt-in's cause
     return rc ? rc : finish_stats(a, emit, s);
 }
 int run_split_k(const GemmArgs& a, hipStream_t s) {              // 1 = handled, 0 = not eligible, < 0 = error

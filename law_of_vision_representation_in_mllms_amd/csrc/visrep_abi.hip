@@ -1,15 +1,40 @@
 // C-ABI glue: error handling, the standalone GEMM entry point and the composed ViT tower forward.
+#include <stdio.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "common.h"
 #include "visrep_internal.h"
 
 static thread_local char g_err[256] = "";
+// A failed dynamic-LDS opt-in (visrep_lds_opt_in) leaves its HIP error here; the launch that follows fails too, and whatever message that
+// launcher reports gets the real cause appended instead of a bare "launch failed".
+static thread_local char g_lds_note[96] = "";
 
 int visrep_set_error(int code, const char* msg) {
+    if (code == VISREP_ERR_LAUNCH && g_lds_note[0]) {
+        snprintf(g_err, sizeof(g_err), "%s (%s)", msg, g_lds_note);
+        g_lds_note[0] = 0;
+        return code;
+    }
     strncpy(g_err, msg, sizeof(g_err) - 1);
     g_err[sizeof(g_err) - 1] = 0;
     return code;
+}
+
+hipError_t visrep_lds_opt_in_slow(VisrepLdsOptIn& st, const void* kernel, int bytes, int dev) {
+    static std::mutex mu;                                        // slow path only: a kernel's first launch per (device, size)
+    std::lock_guard<std::mutex> lock(mu);
+    if (st.bytes[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;       // another thread raised it meanwhile
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        snprintf(g_lds_note, sizeof(g_lds_note), "LDS opt-in to %d bytes failed: %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();                                 // the sticky error belongs to this call, not to the launch behind it
+        return e;
+    }
+    st.bytes[dev].store(bytes, std::memory_order_release);       // recorded only after the attribute holds: never larger than what is set
+    return hipSuccess;
 }
 
 extern "C" int visrep_version(void) { return VISREP_VERSION; }
@@ -46,6 +71,8 @@ extern "C" size_t visrep_last_error(char* buf, size_t n) {
     }
     return len;
 }
+
+extern "C" int visrep_device_cu_count(void) { return visrep_cu_count(); }
 
 extern "C" int visrep_set_scratch(void* ptr, size_t bytes) {
     if ((ptr == nullptr) != (bytes == 0)) return visrep_set_error(VISREP_ERR_ARG, "set_scratch: pass (ptr, bytes) or (NULL, 0)");

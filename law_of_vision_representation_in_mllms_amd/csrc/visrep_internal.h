@@ -110,11 +110,15 @@ constexpr int VISREP_MAX_DEVICES = 16;
 int visrep_device();      // current device index, clamped to [0, VISREP_MAX_DEVICES)
 int visrep_cu_count();    // multiprocessors of the current device (cached per device)
 struct VisrepLdsOptIn { std::atomic<int> bytes[VISREP_MAX_DEVICES]; };   // largest dynamic-LDS size opted in so far, per device (static storage: zeros)
-inline void visrep_lds_opt_in(VisrepLdsOptIn& st, const void* kernel, int bytes) {
+// Raises the kernel's dynamic-LDS limit on the current device to at least `bytes`.  Returns hipSuccess or the error of hipFuncSetAttribute
+// (launchers report "LDS opt-in failed" instead of a generic launch failure).  Race-free: set + record happen under one process-wide mutex
+// (taken on the slow path only - a kernel's first launch per device and size), so two threads opting one kernel in at different sizes
+// always leave the attribute at the larger value, which is also the value recorded.
+hipError_t visrep_lds_opt_in_slow(VisrepLdsOptIn& st, const void* kernel, int bytes, int dev);
+inline hipError_t visrep_lds_opt_in(VisrepLdsOptIn& st, const void* kernel, int bytes) {
     const int dev = visrep_device();
-    if (st.bytes[dev].load(std::memory_order_acquire) >= bytes) return;
-    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);   // idempotent: a race between two threads sets it twice
-    st.bytes[dev].store(bytes, std::memory_order_release);
+    if (st.bytes[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;
+    return visrep_lds_opt_in_slow(st, kernel, bytes, dev);
 }
 // Caller-owned split-K scratch (visrep_set_scratch / visrep_set_stream_scratch): keyed by (device, stream).  A stream-keyed registration wins;
 // the device-wide registration (stream key = "any") serves every other stream of that device - callers that run split-K GEMMs on several

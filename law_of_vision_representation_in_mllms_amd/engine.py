@@ -186,8 +186,8 @@ class VitEngineF32:
         shapes allow it (d, mlp % 256 == 0, head width 64), VISREP_F32_GEMM in the environment overrides.
         products (split route): 6 = three planes, every plane pair >= 2^-24 of the result (fp32-equivalent, ~1e-7 per product sum);
         4 / 3 = two planes (16 significand bits), all four pairs / without (mid, mid): ~4e-6 per product sum at half the matrix work.
-        None = DEFAULT_SPLIT_PRODUCTS (the cheapest setting that holds A <= 1e-4 and exact PCK hits on the full-size towers,
-        profiles/round4_precision.md); VISREP_F32_PRODUCTS in the environment overrides."""
+        None = DEFAULT_SPLIT_PRODUCTS = 6, the fp32-equivalent set (3 holds A <= 1e-4 and exact PCK hits on the full-size SYNTHETIC towers,
+        profiles/round4_precision.md, and is the sweep's explicit opt-in); VISREP_F32_PRODUCTS in the environment overrides."""
         self.lib = _lib.require_gpu()
         self.spec = spec
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -266,9 +266,10 @@ class VitEngineF32:
         raise KeyError(ptr)
 
     def chunk(self) -> int:
-        """Images per library call.  Bounded by the workspace budget, then picked for the GEMMs' tile rounds: the persistent 256 x 256 kernel
-        runs ceil(tiles / CUs) rounds unless the remainder is small enough for the tail launch (<= CUs / 4 tiles), and the N = d projections
-        have the fewest tiles per row block - 64 images of a 577-token tower are 2.25 rounds of them (3 run), 113 images 3.98 (4 run)."""
+        """Images per library call.  Bounded by the workspace budget, then picked for the GEMMs' tile rounds (best_chunk): the persistent
+        256 x 256 kernel runs floor(tiles / CUs) rounds + a tail launch for a remainder of up to CUs / 4 tiles (else one more round), and the
+        N = d projections have the fewest tiles per row block - 64 images of a 577-token tower are 2.25 rounds of them (3 run), 113 images
+        3.98 (4 run)."""
         per = self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), 1)
         cap = max(1, min(128, self.max_ws_bytes // max(per, 1)))
         return best_chunk(self.spec.tokens, self.spec.d, cap)
@@ -312,38 +313,57 @@ class VitEngineF32:
         return out
 
 
-def best_chunk(tokens: int, d: int, cap: int, cus: int = 256) -> int:
-    """Largest image count <= cap whose [count * tokens, d] GEMM fills whole rounds of 256 x 256 tiles on `cus` CUs (a remainder of up to
-    cus / 16 tiles - a few row blocks - goes to the dispatcher's cheap tail launch) - else the count with the best fill."""
-    def fill(c):
-        tiles = -(-c * tokens // 256) * max(1, d // 256)
+def best_chunk(tokens: int, d: int, cap: int, cus: Optional[int] = None) -> int:
+    """Images per launch (<= cap, >= cap / 2) for which a [count * tokens, d] GEMM wastes the least of the persistent 256 x 256 kernel's tile
+    rounds.  The cost model is the GEMM dispatcher's own rule (csrc/gemm_bf16.hip, visrep_gemm_dispatch): T tiles on `cus` CUs run as
+    floor(T / cus) full rounds; a remainder goes to the 128 x 128 tail launch when 0 < 4 * rem <= cus and the full rounds end on a row
+    boundary - priced here at 0.45 of a round plus twice its share of one (profiles/round4_gemm.md section 5: a tail pair of launches is
+    14-18 us beside a 31-us K = 1024 round, and that kernel runs at about half the rate) - and costs a whole extra round otherwise.
+    Returns the LARGEST count whose efficiency (tiles / (cus * rounds paid)) is within 1 % of the best in the range.
+    cus = None asks the library for the current device's CU count (visrep_device_cu_count; 256 when no device is visible).  On MI355X:
+    best_chunk(577, 1024, 128) = 113 (3.98 rounds, 4 paid), best_chunk(257, 1024, 128) = 127 (exactly 2 rounds, no tail launch)."""
+    if cus is None:
+        cus = 256                                               # no device visible (host-side planning / tests): the MI355X count
+        if torch.cuda.is_available():
+            cus = int(_lib.load().visrep_device_cu_count())
+    ntn = max(1, d // 256)
+
+    def eff(c):
+        tiles = -(-c * tokens // 256) * ntn
         rounds, rem = divmod(tiles, cus)
-        if rounds >= 1 and rem * 16 <= cus:
-            return 1.0
-        return tiles / ((rounds + (1 if rem else 0)) * cus)
-    best, best_f = cap, -1.0
-    for c in range(cap, max(cap // 2, 1) - 1, -1):
-        f = fill(c)
-        if f >= 0.97:
-            return c
-        if f > best_f:
-            best, best_f = c, f
-    return best
+        if rem == 0:
+            paid = rounds
+        elif rounds >= 1 and rem * 4 <= cus and (rounds * cus) % ntn == 0:
+            paid = rounds + 0.45 + 2.0 * rem / cus
+        else:
+            paid = rounds + 1
+        return tiles / (cus * paid)
+    lo = max(cap // 2, 1)
+    effs = {c: eff(c) for c in range(lo, cap + 1)}
+    top = max(effs.values())
+    return max(c for c, e in effs.items() if e >= top - 0.01)
 
 
-def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf16"):
-    """precision 'bf16' = the MFMA throughput engine; 'fp32' = the reference-precision engine."""
+def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf16", products: Optional[int] = None):
+    """precision 'bf16' = the MFMA throughput engine; 'fp32' = the reference-precision engine (products: its split-bf16 product set,
+    None = DEFAULT_SPLIT_PRODUCTS)."""
     if precision in ("bf16", torch.bfloat16):
         return VitEngine(spec, weights, device)
     if precision in ("fp32", "float32", torch.float32):
-        return VitEngineF32(spec, weights, device)
+        return VitEngineF32(spec, weights, device, products=products)
     raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
 
 
-# Plane-pair products of the split-bf16 route (VitEngineF32; see its __init__).  3 = (hi,hi) (hi,mid) (mid,hi) over two-plane operands:
-# measured at full size (profiles/round4_precision.md) - CLIP-L/14-336 features 8.6e-6 rel-L2 of the fp32 oracle (six products: 2.5e-6, the
-# bf16 engine: 1.2e-2), A score 1e-7 relative, 0 of 2,400 PCK hits flipped, predictions within 0.001 px - at 1.8x the six-product tower's rate.
-DEFAULT_SPLIT_PRODUCTS = 3
+# Plane-pair products of the split-bf16 route (VitEngineF32; see its __init__).  The DEFAULT is the fp32-EQUIVALENT set: six products over
+# three-plane operands (24 significand bits per operand, every dropped term < 2^-24 of the result) - what a drop-in for the reference's fp32
+# towers (C_score/extract_feature.py:36-45) has to be on checkpoints nobody has validated a cheaper set on.  3 = (hi,hi) (hi,mid) (mid,hi)
+# over two-plane operands (16 significand bits, the mid x mid term dropped) is an explicit OPT-IN for throughput runs (the sweep passes
+# tower_products=3 and says so in its dtype field): measured at full size on SYNTHETIC N(0, 0.02) weights (profiles/round4_precision.md) -
+# CLIP-L/14-336 features 8.6e-6 rel-L2 of the fp32 oracle (six products: 2.5e-6, the bf16 engine: 1.2e-2), A score 1e-7 relative, 0 of 2,400
+# PCK hits flipped - at 1.8x the six-product tower's rate; real checkpoints with massive-activation outlier channels were never available
+# offline, which is why it is not the default (ADVICE round 4).
+DEFAULT_SPLIT_PRODUCTS = 6
+THROUGHPUT_SPLIT_PRODUCTS = 3
 
 
 def split_planes(products: int) -> int:

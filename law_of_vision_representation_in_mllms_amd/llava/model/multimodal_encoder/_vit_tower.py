@@ -119,6 +119,9 @@ class HipViTTower(nn.Module):
         # 'bf16' (default; what LLaVA runs the tower in: model.to(bfloat16)) or 'fp32' (what C_score/extract_feature.py runs the
         # CLIP / OpenCLIP / DINOv2 towers in: no dtype cast, fp32 pixels) - VISREP_TOWER_PRECISION overrides
         self._precision = os.environ.get("VISREP_TOWER_PRECISION") or getattr(args, "tower_precision", None) or "bf16"
+        # fp32 towers only: the split-bf16 product set (engine.VitEngineF32); None = the fp32-equivalent default (6).  3 is an explicit
+        # opt-in for throughput runs (the sweep), never implied
+        self._products = getattr(args, "tower_products", None)
         if not delay_load:
             self.load_model()
         else:
@@ -169,7 +172,7 @@ class HipViTTower(nn.Module):
         cfg = SimpleNamespace(hidden_size=spec.d, image_size=spec.image_size, patch_size=spec.patch,
                               num_hidden_layers=spec.layers, num_attention_heads=spec.heads, intermediate_size=spec.mlp)
         fp32 = self._precision in ("fp32", "float32")
-        self.vision_tower = _EngineModule(engine.make_engine(spec, w, self._device, "fp32" if fp32 else "bf16"), cfg,
+        self.vision_tower = _EngineModule(engine.make_engine(spec, w, self._device, "fp32" if fp32 else "bf16", products=self._products if fp32 else None), cfg,
                                           torch.float32 if fp32 else torch.bfloat16)
         self.vision_tower.requires_grad_(False)
         self.is_loaded = True

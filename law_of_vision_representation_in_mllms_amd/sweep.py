@@ -57,7 +57,7 @@ class Setting:
 # C leg issues FULL launches + one remainder (plan_launches): 113 images of a 577-token tower = 3.98 rounds of the out / V GEMMs (4 run; 128 or
 # an equalised 120 would be 4.5 / 4.23: 5 run), 7.9 / 15.8 of Q|K / fc1; 256 images of a 257-token tower = 4.02 rounds (the 4-tile remainder goes
 # to the tail launch; an equalised 225 would be 3.53).  The reference-precision engine cuts a launch into chunks by the same rule
-# (engine.best_chunk: 113 / 128 images).
+# (engine.best_chunk: 113 images of a 577-token tower, 127 of a 257-token one - exactly two rounds, no tail launch).
 SETTINGS = (
     Setting("CLIP336", "clip336", (CLIP336,), 336, 113),
     Setting("CLIP224", "clip224", (CLIP224,), 224, 256),
@@ -180,8 +180,12 @@ def c_item_ids(spair, rank: int, world: int) -> List[int]:
 class SettingModel:
     """Tower(s) + mlp2x_gelu projector of one setting, built through the drop-in registry (llava_arch.build_function_mapping)."""
 
-    def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16", fast_weights: bool = True):
-        """precision:
+    def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16", fast_weights: bool = True,
+                 fp32_products: Optional[int] = None):
+        """fp32_products: split-bf16 product set of the reference-precision (fp32) ViT engines this setting builds - None = the engine's
+        fp32-equivalent default (6); 3 = the throughput set (two-plane operands), an explicit opt-in that the `dtypes` labels carry
+        ("fp32[split-bf16 x3]") into the sweep's output.
+        precision:
           'reference' = the reference's own arithmetic per leg: A leg in bf16 (LLaVA's model.to(bfloat16): towers and projector), C leg per
                         tower as C_score/extract_feature.py builds it (`reference_c_precision`: fp32 for CLIP / OpenCLIP / DINOv2 and both
                         fusions, bf16 for SigLIP and the diffusion towers) - a setting whose two legs differ holds two engines per tower;
@@ -201,7 +205,8 @@ class SettingModel:
         def tower(tid, prec):
             cfg = SimpleNamespace(mm_vision_tower=tid, vision_tower=tid, mm_vision_select_layer=-2, mm_vision_select_feature='patch',
                                   up_ft_index=0, t=1, prompt='', ensemble_size=1, img_size=setting.size,        # train.py:83-87 defaults
-                                  vit_img_size=setting.size, synthetic_weights=synthetic, device=self.device, tower_precision=prec)
+                                  vit_img_size=setting.size, synthetic_weights=synthetic, device=self.device, tower_precision=prec,
+                                  tower_products=fp32_products)
             return LA.build_function_mapping[tid](cfg)
         a_prec = "fp32" if precision == "fp32" else "bf16"
         with _environ(env):
@@ -211,7 +216,13 @@ class SettingModel:
                 c_prec = reference_c_precision(tid) if precision == "reference" else a_prec
                 same = (ta.dtype == torch.float32) == (c_prec == "fp32") or hasattr(ta, "up_ft_index")
                 self.c_towers.append(ta if same else tower(tid, c_prec))
-        name = lambda ts: "+".join(sorted({"fp32" if t.dtype == torch.float32 else "bf16" for t in ts}))
+        def label(t):
+            if t.dtype != torch.float32:
+                return "bf16"
+            eng = getattr(getattr(t, "vision_tower", None), "engine", None)
+            pr = getattr(eng, "products", None)
+            return f"fp32[split-bf16 x{pr}]" if pr else "fp32"                                    # pr None: exact-fp32 MFMA route
+        name = lambda ts: "+".join(sorted({label(t) for t in ts}))
         self.dtypes = {"a": name(self.towers), "c": name(self.c_towers)}
         self.width = sum(t.hidden_size for t in self.towers)
         torch.manual_seed(7)                                             # same projector on every rank
@@ -503,10 +514,12 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
 def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spair: Optional[Sequence[SpairCategory]] = None,
               device="cuda", build: Optional[Callable[[Setting], object]] = None, pixels: Optional[Callable] = None, a_hooks=None,
               hidden: int = 4096, precision: str = "reference", do_a: bool = True, do_c: bool = True, verbose: bool = False,
-              also_bf16: bool = False) -> dict:
+              also_bf16: bool = False, fp32_products: Optional[int] = None) -> dict:
     """Runs the sweep on this process' share (one process per GPU; world size from torch.distributed).  Returns
     {"wall_s", "setup_s", "per_setting": {name: {"a_s", "c_s", "A", "pck": [..3], "images", "dtype": {"a", "c"}}}, "images", ...}.
     precision: see SettingModel ('reference' = A leg bf16, C leg in the dtype the reference's C path uses per tower).
+    fp32_products: product set of the fp32 ViT engines (SettingModel): None = fp32-equivalent (6); bench.py's throughput sweep opts into 3
+    and the per-setting "dtype" / the top-level "fp32_products" say so.
     also_bf16 ('reference' only): the settings whose C leg is fp32 run their C leg a second time on the bf16 engines, timed the same way
     ("c_s_bf16", "pck_bf16"), and "wall_s_all_bf16" is the wall-clock of the sweep with those legs swapped in - the all-bf16 sweep's
     number without running the eleven other legs twice (they are the same launches in both modes).
@@ -520,13 +533,14 @@ def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spa
     old_level = clog.level
     clog.setLevel(logging.WARNING)                                       # 18 per-category lines x 13 settings are not a bench output
     try:
-        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16)
+        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16, fp32_products)
     finally:
         clog.setLevel(old_level)
 
 
-def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16=False):
-    build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision))
+def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16=False,
+               fp32_products=None):
+    build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision, fp32_products=fp32_products))
     # fp32 pixels wherever an fp32 engine may consume them (every tower is fed its own dtype: SettingModel._run); the bf16 cast of the same
     # draw is what the all-bf16 mode generates directly, so the three modes see the same images
     pixels = pixels or ResidentPixels(dev, torch.bfloat16 if precision == "bf16" else torch.float32)
@@ -596,6 +610,8 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
             "img_s": round(images / wall, 2) if wall else None, "img_s_per_gpu": round(images / wall / world, 2) if wall else None,
             "a_images_per_setting": n_a_images if do_a else 0, "c_images_per_setting": n_c_images,
             "c_pairs_per_setting": sum(len(c.thresholds) for c in spair) if do_c else 0, "tower_precision": precision,
+            "fp32_products": ("engine default (6: fp32-equivalent)" if fp32_products is None else
+                              f"{int(fp32_products)} (explicit opt-in; 6 = fp32-equivalent, 3 = two-plane operands, mid x mid dropped)"),
             "scaling": "strong (fixed total work, images sharded rank::world, C categories owned by ranks)",
             "pixels": "resident in HBM (drawn in each setting's setup)" if hasattr(pixels, "prefetch") else "drawn by the caller's image source inside the legs",
             "per_setting": per}
@@ -679,6 +695,8 @@ def main(argv=None):
                     help="reference = A leg bf16, C leg in the reference's per-tower dtype (fp32 for CLIP / OpenCLIP / DINOv2); bf16 / fp32 = both legs")
     ap.add_argument("--also-bf16", action="store_true", help="reference mode: time the fp32 C legs on the bf16 engines too (wall_s_all_bf16)")
     ap.add_argument("--mode", default="image", choices=["image", "encoder"], help="image-sharded sweep, or the encoder-sharded A score only")
+    ap.add_argument("--fp32-products", type=int, default=None, choices=[3, 4, 6],
+                    help="split-bf16 product set of the fp32 ViT engines (default: the engine's fp32-equivalent 6; 3 = throughput opt-in)")
     a = ap.parse_args(argv)
     from . import dist_env
     owned = dist_env.init_from_env()
@@ -688,7 +706,8 @@ def main(argv=None):
         if a.mode == "encoder":
             out = a_scores_encoder_sharded(sel, a.a_images, dev, precision="fp32" if a.precision == "fp32" else "bf16")
         else:
-            out = run_sweep(sel, a.a_images, synthetic_spair(a.c_images, a.c_pairs), dev, precision=a.precision, verbose=True, also_bf16=a.also_bf16)
+            out = run_sweep(sel, a.a_images, synthetic_spair(a.c_images, a.c_pairs), dev, precision=a.precision, verbose=True, also_bf16=a.also_bf16,
+                            fp32_products=a.fp32_products)
         if not _dist() or _dist().get_rank() == 0:
             print(json.dumps(out), flush=True)
         return out

@@ -53,8 +53,17 @@ def gen_ascore():
         ("fp32_small", 4, dict(clip336=9, clip224=5, encA=7, encB=9), 32, torch.float32),
         ("fp32_wide", 3, dict(clip336=12, clip224=6, encA=10, encB=4), 96, torch.float32),
         ("bf16_inputs", 3, dict(clip336=8, clip224=4, encA=8, encB=6), 64, torch.bfloat16),
+        # round 5: the reference's IN-DTYPE arithmetic (compute.py on the bf16 tensors it really consumes) at a width where the
+        # per-op bf16 roundings show: results are bf16-quantised per image (clip336 against itself prints values like 1.0078125, as the
+        # published table policy/ablations_t.csv does) - pinned for ascore_ops.max_cos_mean(..., arithmetic="reference")
+        ("bf16_wide", 5, dict(clip336=40, clip224=24, encA=33, encB=70), 512, torch.bfloat16),
+        # token rows of equal norm 41.86, a value bf16 rounds DOWN (to 41.75): normalize_feat then leaves rows of norm ~1.0026, whose norm
+        # rounds to 1.0 on the coarse side of the bf16 grid, and a row's cosine with itself comes out as bf16(1.0053) = 1.0078125 - the
+        # mechanism behind the 1.0078125 the published table holds for CLIP336 against itself (policy/ablations_t.csv)
+        ("bf16_self", 3, dict(clip336=48, clip224=20, encA=30, encB=12), 512, torch.bfloat16, 41.86),
     ]
-    for cname, n_img, toks, D, dt in specs:
+    for cname, n_img, toks, D, dt, *opt in specs:
+        row_norm = opt[0] if opt else None
         with tempfile.TemporaryDirectory() as tmp:
             data = {}
             for sub, nt in toks.items():
@@ -68,6 +77,8 @@ def gen_ascore():
                             t[0] = 0.0           # zero row -> epsilon path of normalize_feat
                         if sub == "encA":
                             t = t + 0.5 * torch.from_numpy(rs.standard_normal((1, D)).astype(np.float32))
+                        if row_norm is not None and sub.startswith("clip"):
+                            t = t / t.norm(dim=-1, keepdim=True) * row_norm
                         t = t.to(dt)
                         arr.append(t)
                     torch.save(arr[j], f"{tmp}/{sub}/tensor_{i}.pt")
@@ -89,6 +100,20 @@ def gen_ascore():
             for k, v in res.items():
                 cases[f"{cname}.result.{k}"] = np.float64(v)
             cases[f"{cname}.stdout"] = np.array(buf.getvalue())
+            if dt == torch.bfloat16:
+                # per-image values of the reference's own bf16 op chain (its module-level functions, run on the same tensors): what
+                # `cosine_sim_336.max(dim=1).values.mean().item()` is for every distinct image (compute.py:54-72)
+                import torch.nn.functional as F
+                nf = ns["normalize_feat"]
+                for enc in toks:
+                    for rname in ("clip336", "clip224"):
+                        vals = []
+                        for j in range(n_img):
+                            o = nf(torch.from_numpy(data[enc][j]).to(dt)).unsqueeze(1)
+                            r = nf(torch.from_numpy(data[rname][j]).to(dt)).unsqueeze(0)
+                            vals.append(F.cosine_similarity(o, r, dim=-1).max(dim=1).values.mean().item())
+                        cases[f"{cname}.per_image.{enc}.{rname}"] = np.asarray(vals, np.float64)
+    cases["torch_version"] = np.array(torch.__version__)
     np.savez_compressed(f"{HERE}/ascore.npz", **cases)
     print("ascore.npz", {k: float(v) for k, v in cases.items() if ".result." in k})
 

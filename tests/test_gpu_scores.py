@@ -33,6 +33,73 @@ def test_ascore_golden(case):
         assert abs(got - want) <= tol * abs(want), (enc, got, want)
 
 
+@pytest.mark.parametrize("case", ["bf16_inputs", "bf16_wide", "bf16_self"])
+def test_ascore_golden_reference_arithmetic(case):
+    """arithmetic="reference": the numbers A_score/compute.py PRINTS when the dumped tensors are bf16 (every op rounded to bf16, SURVEY F4 /
+    VERDICT r4 missing 3).  Per-image values against the reference's own op chain (bit for bit up to one bf16 step on at most one image -
+    the fp32 summation order inside a sum may differ), printed averages at 1e-4; clip336 against itself = 1.0078125 in `bf16_self`."""
+    z = np.load(f"{G}/ascore.npz")
+    n = z[f"{case}.clip336"].shape[0]
+    bf = lambda k: torch.from_numpy(z[k]).to(torch.bfloat16).to(DEV)
+    per = {}
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        for ref in ("clip336", "clip224"):
+            got = ascore_ops.max_cos_mean(bf(f"{case}.{enc}"), bf(f"{case}.{ref}"), arithmetic="reference").double().cpu().numpy()
+            want = z[f"{case}.per_image.{enc}.{ref}"]
+            assert np.all(got == got.astype(np.float32)) and np.all(torch.from_numpy(got).to(torch.bfloat16).double().numpy() == got)   # bf16 values
+            assert (got != want).sum() <= 1 and np.abs(got - want).max() <= 2.0 ** -7 * np.abs(want).max(), (enc, ref, got, want)
+            per[enc, ref] = got
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        got = (sum(per[enc, "clip336"][i % n] for i in range(100)) / 100 + sum(per[enc, "clip224"][i % n] for i in range(100)) / 100) / 2
+        want = float(z[f"{case}.result.{enc}"])
+        assert abs(got - want) <= 1e-4 * abs(want), (enc, got, want)
+    if case == "bf16_self":
+        assert np.all(per["clip336", "clip336"] == 1.0078125)       # policy/ablations_t.csv, row CLIP336, column mmbench_en_mm_align336
+    with pytest.raises(ValueError):
+        ascore_ops.max_cos_mean(bf(f"{case}.encA").float(), bf(f"{case}.clip336").float(), arithmetic="reference")
+
+
+@pytest.mark.parametrize("n,Nt,Nr,D", [(2, 100, 70, 1024), (1, 130, 65, 4096), (3, 17, 9, 40)])
+def test_ascore_reference_arithmetic_vs_oracle(n, Nt, Nr, D):
+    """The VALU kernel against the per-op-rounding oracle on ragged shapes (tile edges in both directions, D % 64 != 0), a zero row (both
+    epsilon clamps decide) and rows with an outlier channel."""
+    g = torch.Generator().manual_seed(Nt + 3 * Nr + D)
+    shared = torch.randn(n, 1, D, generator=g)
+    o = torch.randn(n, Nt, D, generator=g) + 0.7 * shared
+    r = torch.randn(n, Nr, D, generator=g) + 0.7 * shared
+    o[0, 3] = 0
+    o[:, :, 5] *= 30
+    r[:, :, 5] *= 30
+    o, r = o.to(torch.bfloat16), r.to(torch.bfloat16)
+    got = ascore_ops.max_cos_mean(o.to(DEV), r.to(DEV), arithmetic="reference").cpu().numpy()
+    want = np.array([OA.max_cos_mean_reference_arithmetic(o[i], r[i]) for i in range(n)], np.float32)
+    assert np.abs(got - want).max() <= 2.0 ** -7 * np.abs(want).max() and (got != want).sum() <= 1, (got, want)
+
+
+def test_ascore_dropin_reference_arithmetic_prints_the_reference_lines(tmp_path, capsys):
+    """A_score.compute with arithmetic="reference" on bf16 tensor files: the printed lines equal the reference script's own output
+    (tests/golden/ascore.npz `bf16_wide.stdout`) to 1e-4 - the default ("exact") arithmetic is only within 1e-2 of them."""
+    from law_of_vision_representation_in_mllms_amd.A_score import compute as AC
+    z = np.load(f"{G}/ascore.npz")
+    case = "bf16_wide"
+    n = z[f"{case}.clip336"].shape[0]
+    for sub in ("clip336", "clip224", "encA", "encB"):
+        os.makedirs(tmp_path / sub)
+        for i in range(1, 101):
+            torch.save(torch.from_numpy(z[f"{case}.{sub}"][(i - 1) % n]).to(torch.bfloat16), tmp_path / sub / f"tensor_{i}.pt")
+    res = AC.compute(str(tmp_path), ["clip336", "clip224", "encA", "encB"], device=DEV, arithmetic="reference")
+    out = capsys.readouterr().out
+    want_lines = str(z[f"{case}.stdout"]).strip().splitlines()
+    got_lines = [l for l in out.strip().splitlines() if l.startswith("Average cosine similarity")]
+    assert len(got_lines) == len(want_lines) == 4
+    for gl, wl in zip(got_lines, want_lines):
+        assert gl.rsplit(":", 1)[0] == wl.rsplit(":", 1)[0]
+        g_, w_ = float(gl.rsplit(":", 1)[1]), float(wl.rsplit(":", 1)[1])
+        assert abs(g_ - w_) <= 1e-4 * abs(w_), (gl, wl)
+    exact = AC.compute(str(tmp_path), ["encA"], device=DEV, verbose=False, arithmetic="exact")["encA"]
+    assert abs(exact - res["encA"]) <= 1e-2 * abs(exact)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Nt,Nr,D", [(576, 576, 4096), (196, 256, 4096), (256, 576, 1024), (70, 33, 256)])
 def test_ascore_vs_oracle(dtype, Nt, Nr, D):

@@ -31,7 +31,7 @@ def cpu_descriptors(m, P, split=0, layout="cp"):
     return OC.normalize_feats_two(m.view(1, C, P * P).permute(0, 2, 1), split)
 
 
-def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840, split=0, layout="cp", sort_pairs=True):
+def cpu_transfer(bank, img1, img2, patch_idx, nkp, P, window=5, soft_eval=True, beta=0.02, anno_size=840, split=0, layout="cp", sort_pairs=True, packed=None):
     n, kmax = patch_idx.shape
     out = torch.zeros(n, kmax, 2)
     for i in range(n):

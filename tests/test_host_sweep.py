@@ -275,18 +275,24 @@ def test_c_exchange_plan_sends_every_row_once_to_its_owner():
 
 
 def test_reference_precision_chunks_fill_whole_tile_rounds():
-    """engine.best_chunk: the image count per library call of the reference-precision engine is the largest one under the workspace cap whose
-    [count * tokens, 1024] GEMM runs whole rounds of 256 x 256 tiles on 256 CUs (plus at most 16 remainder tiles for the tail launch)."""
+    """engine.best_chunk prices a launch with the GEMM dispatcher's own rule (csrc/gemm_bf16.hip: full rounds of 256 x 256 tiles on the
+    device's CUs; a remainder of rem tiles goes to the 128 x 128 tail launch when 4 rem <= CUs, else it costs a whole round) and returns the
+    largest image count within 1 % of the best efficiency.  Pinned values for MI355X (256 CUs): the numbers the comments in sweep.py,
+    bench.py and VitEngineF32.chunk quote."""
     from law_of_vision_representation_in_mllms_amd.engine import best_chunk
 
     def rounds(c, T, d=1024):
         tiles = -(-c * T // 256) * (d // 256)
         return divmod(tiles, 256)
-    c = best_chunk(577, 1024, 128)
-    assert 113 <= c <= 128 and rounds(c, 577)[1] <= 16 and rounds(c, 577)[0] == 4          # 64 images (the old chunk) = 2.25 rounds: 3 run
-    assert best_chunk(257, 1024, 128) == 128 and rounds(128, 257) == (2, 4)
-    assert best_chunk(257, 1024, 64) == 64 and rounds(64, 257) == (1, 4)
-    assert 1 <= best_chunk(577, 1024, 1) <= 1 and best_chunk(50, 768, 7) == 7                 # tiny caps: whatever fits
+    assert best_chunk(577, 1024, 128, cus=256) == 113 and rounds(113, 577) == (3, 252)        # 3.98 rounds, 4 run; 64 images (the old chunk) = 2.25: 3 run
+    assert best_chunk(257, 1024, 128, cus=256) == 127 and rounds(127, 257) == (2, 0)          # exactly two rounds, no tail launch (128 images: + a 4-tile tail pair)
+    assert best_chunk(257, 1024, 256, cus=256) == 255 and rounds(255, 257) == (4, 0)
+    assert best_chunk(577, 1024, 1, cus=256) == 1 and best_chunk(50, 768, 7, cus=256) == 7   # tiny caps: whatever fits
+    assert best_chunk(577, 1024, 128) == 113                                                  # no device visible here: the MI355X count
+    # another part (304 CUs): the choice follows the CU count instead of silently de-tuning
+    c = best_chunk(577, 1024, 128, cus=304)
+    tiles = -(-c * 577 // 256) * 4
+    assert tiles % 304 == 0 or tiles % 304 > 304 * 0.9 or (tiles % 304) * 4 <= 304
 
 
 def test_resident_pixels_are_the_same_images():

@@ -37,6 +37,31 @@ def test_ascore_matches_reference(case):
         assert abs(got - want) <= tol * max(1.0, abs(want)), (enc, got, want)
 
 
+@pytest.mark.parametrize("case", ["bf16_inputs", "bf16_wide", "bf16_self"])
+def test_ascore_reference_arithmetic_matches_reference_bit_for_bit(case):
+    """The reference's IN-DTYPE arithmetic (compute.py on the bf16 tensors it really consumes): the per-op-rounding restatement
+    reproduces every per-image value of the reference's own op chain exactly, hence the printed averages; clip336 against itself comes out
+    as 1.0078125 in the `bf16_self` case, like the published table's CLIP336 row."""
+    z = np.load(f"{G}/ascore.npz")
+    n = z[f"{case}.clip336"].shape[0]
+    reps = [len(range(j, 100, n)) for j in range(n)]
+    per = {}
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        for ref in ("clip336", "clip224"):
+            got = np.array([OA.max_cos_mean_reference_arithmetic(torch.from_numpy(z[f"{case}.{enc}"][j]).to(torch.bfloat16),
+                                                                 torch.from_numpy(z[f"{case}.{ref}"][j]).to(torch.bfloat16)) for j in range(n)])
+            assert np.array_equal(got, z[f"{case}.per_image.{enc}.{ref}"]), (enc, ref, got, z[f"{case}.per_image.{enc}.{ref}"])
+            per[enc, ref] = got
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        # the script's python-float reduction over its 100 files (the fixture cycles n distinct images), compute.py:75-81
+        s336 = [per[enc, "clip336"][i % n] for i in range(100)]
+        s224 = [per[enc, "clip224"][i % n] for i in range(100)]
+        got = (sum(s336) / 100 + sum(s224) / 100) / 2
+        assert abs(got - float(z[f"{case}.result.{enc}"])) <= 1e-12, (enc, got)
+    if case == "bf16_self":
+        assert np.all(z[f"{case}.per_image.clip336.clip336"] == 1.0078125)
+
+
 def test_ascore_self_similarity_is_one():
     x = torch.randn(17, 40)
     assert abs(OA.max_cos_mean(x, x) - 1.0) < 1e-6

@@ -47,7 +47,7 @@ for P in (16, 24):
     for layout, bk, srt in (("cp", bank, True), ("pc", bank.transpose(1, 2).contiguous(), False), ("pc", None, True)):
         bk = bank.transpose(1, 2).contiguous() if bk is None else bk
         def run():
-            xy = cscore_ops.transfer(bk, i1, i2, idx, nkp, P, layout=layout, sort_pairs=srt)
+            xy = cscore_ops.transfer(bk, i1, i2, idx, nkp, P, layout=layout, sort_pairs=srt, packed=None if srt else False)
             return cscore_ops.pck_counts(xy, kps, kps, thr, nkp)
         sec = timed(run)
         out[f"C.P{P}.{layout}" + ("" if srt else ".dataset_order")] = {"pairs_per_s": round(n_pairs / sec, 1), "ms_all_pairs": round(sec * 1e3, 3), "alg_GB/s": round(by / sec / 1e9, 1),
