@@ -62,6 +62,32 @@ int visrep_debug_gemm_ablation(int mask);
 /* Diagnostic builds (-DVISREP_GEMM_ABLATE) only: device buffer of 16 uint64 receiving per-segment cycle sums of variant 2
  * (wave 0 and wave 4 of block 0); ignored by production builds. */
 int visrep_debug_gemm_timing_buffer(void* dev_u64x16);
+/* Routing counters of the CALLING THREAD: how many launches each kernel family received since the last reset (host-side integers,
+ * incremented by the dispatchers; HIP-graph replays do not pass through a dispatcher and are not counted).  Tests use them to assert
+ * that a shape takes the route it was tuned for - e.g. that the 768-px diffusion tower's 256- / 512-channel convolutions run in the
+ * persistent 256x256 kernel and its 128-channel ones in the 128x128 kernel with GroupNorm partials.  out: VISREP_ROUTE_COUNT longs
+ * (NULL: only reset); reset != 0 clears the counters after the copy.  Returns VISREP_ROUTE_COUNT. */
+enum {
+    VISREP_ROUTE_GEMM_256 = 0,       /* persistent 256x256 kernel (variants 2 / 5), plain GEMM: head launch or whole problem */
+    VISREP_ROUTE_GEMM_128 = 1,       /* 128x128 kernel, plain GEMM (N % 256 != 0, few tiles, variant 1) */
+    VISREP_ROUTE_GEMM_TAIL = 2,      /* rows of a partial last tile round split off to the 128x128 kernel */
+    VISREP_ROUTE_SPLITK = 3,         /* deterministic split-K pair (partials + reduce), GEMM or convolution */
+    VISREP_ROUTE_CONV_256 = 4,       /* implicit 3x3 convolution in the persistent 256x256 kernel */
+    VISREP_ROUTE_CONV_128 = 5,       /* implicit 3x3 convolution in the 128x128 kernel */
+    VISREP_ROUTE_CONV_128_GN = 6,    /* ... that also emits GroupNorm partial sums */
+    VISREP_ROUTE_ATTN = 7,           /* attn_fwd<ND> (head width 64 / 128 / 192) */
+    VISREP_ROUTE_ATTN_WIDE = 8,      /* attn_fwd_wide (head width 512) */
+    VISREP_ROUTE_ATTN_CLS = 9,       /* attn_fwd_cls (image-aligned CLS towers) */
+    VISREP_ROUTE_COUNT = 10
+};
+int visrep_debug_routes(long* out, int reset);
+/* Matrix-pipe ceiling of THIS device under THIS process' conditions: `iters` bursts of 32 dependent-free v_mfma_f32_16x16x32_bf16 per wave,
+ * 8 waves per CU, every CU, operands in registers (pseudo-random bf16 with |x| in [0.25, 4) when random != 0, small constants otherwise), no memory
+ * traffic.  FLOP per launch = CUs * 8 * iters * 32 * 16384 (returned through *flop when non-NULL); the caller times the launch on
+ * `stream`.  bench.py quotes the result beside the 2.5 PFLOP/s nominal peak: on random data the chip's power management holds a pure
+ * MFMA stream near 1.9-2.0 PFLOP/s (DVFS), which is the practical roof every fraction on the line can also be read against.
+ * sink: >= 4 bytes of device memory (never written in practice). */
+int visrep_debug_mfma_probe(int iters, int random, void* sink, double* flop, void* stream);
 
 /* ---- optional device scratch owned by the caller (e.g. one torch tensor kept alive for the process).  With it,
  * visrep_gemm_bf16 splits the K loop of problems that have few output tiles but a deep reduction (the diffusion towers'

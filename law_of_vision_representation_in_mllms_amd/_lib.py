@@ -98,6 +98,8 @@ SIGNATURES = {
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_row_rnorm_f32": (_i, [_vp, _l, _i, _f, _vp, _vp]),
     "visrep_device_cu_count": (_i, []),
+    "visrep_debug_routes": (_i, [C.POINTER(C.c_long), _i]),
+    "visrep_debug_mfma_probe": (_i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "visrep_mutual_nn_distance": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -148,6 +150,17 @@ def load(build_if_missing: bool = True):
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+ROUTES = ("gemm_256", "gemm_128", "gemm_tail", "splitk", "conv_256", "conv_128", "conv_128_gn", "attn", "attn_wide", "attn_cls")
+
+
+def routes(reset: bool = False) -> dict:
+    """This thread's launch counters per kernel family (visrep_debug_routes): {name: count}."""
+    buf = (C.c_long * len(ROUTES))()
+    n = load().visrep_debug_routes(buf, int(reset))
+    assert n == len(ROUTES), "ROUTES is out of step with VISREP_ROUTE_COUNT"
+    return dict(zip(ROUTES, list(buf)))
 
 
 def last_error() -> str:

@@ -720,6 +720,7 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
         w.sc = scale * 1.4426950408889634f;
         static VisrepLdsOptIn optw;
         visrep_lds_opt_in(optw, (const void*)attn_fwd_wide<8, 4>, 16 * TILE_B);
+        visrep_count_route(VISREP_ROUTE_ATTN_WIDE);
         hipLaunchKernelGGL((attn_fwd_wide<8, 4>), dim3(2 * ((Tq + 127) / 128) * H * B), dim3(256), (size_t)16 * TILE_B, (hipStream_t)stream, w);
         return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "attention: launch failed");
     }
@@ -747,6 +748,7 @@ extern "C" int visrep_attention_fwd(const void* q, int ldq, const void* k, int l
     }
 #endif
     hipStream_t st = (hipStream_t)stream;
+    visrep_count_route(VISREP_ROUTE_ATTN);
     if (nd == 1 && ps) hipLaunchKernelGGL((attn_fwd<1, true>), grid, block, lds, st, a);
     else if (nd == 1) hipLaunchKernelGGL(attn_fwd<1>, grid, block, lds, st, a);
     else if (nd == 2) hipLaunchKernelGGL(attn_fwd<2>, grid, block, lds, st, a);
@@ -772,6 +774,7 @@ extern "C" int visrep_mhsa_cls_fwd(const void* qk, int ldqk, const void* vt, int
     AttnClsArgs a;
     a.q = (const bf16_t*)qk; a.k = (const bf16_t*)qk + (size_t)H * 64; a.vt = (const bf16_t*)vt; a.vcls = (const bf16_t*)vcls; a.out = (bf16_t*)out;
     a.B = B; a.T = T; a.H = H; a.ldq = ldqk; a.ldk = ldqk; a.ldvt = ldvt; a.ldvc = ldvc; a.ldo = ldo;
+    visrep_count_route(VISREP_ROUTE_ATTN_CLS);
     hipLaunchKernelGGL(attn_fwd_cls, dim3(((T + 127) / 128) * H * B), dim3(256), (size_t)4 * TILE_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mhsa_cls: launch failed");
 }

@@ -300,8 +300,12 @@ namespace {
 int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
     if (a.conv) {                                              // implicit 3x3 convolution: the 256x256 kernel when whole rounds of its tiles exist
 #ifndef VISREP_NO_CONV5                                           // A/B builds (tools/): every convolution on the 128x128 kernel, as until round 4
-        if (variant == 5 && visrep_gemm_v5_supports_conv(a) && (long)((a.M + 255) / 256) * (a.N / 256) >= 2L * visrep_cu_count()) return visrep_gemm_v5_dispatch(a, s);
+        if (variant == 5 && visrep_gemm_v5_supports_conv(a) && (long)((a.M + 255) / 256) * (a.N / 256) >= 2L * visrep_cu_count()) {
+            visrep_count_route(VISREP_ROUTE_CONV_256);
+            return visrep_gemm_v5_dispatch(a, s);
+        }
 #endif
+        visrep_count_route(a.gn_partial ? VISREP_ROUTE_CONV_128_GN : VISREP_ROUTE_CONV_128);
         if (a.gn_partial) return a.epi == EPI_BIAS ? launch<EPI_BIAS, true, true>(a, s) : launch<EPI_RESID, true, true>(a, s);
         switch (a.epi) {
             case EPI_BIAS: return launch<EPI_BIAS, true>(a, s);
@@ -317,6 +321,7 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
         b.dbg_buf = g_visrep_gemm_dbg_buf;
+        visrep_count_route(VISREP_ROUTE_GEMM_256);
         return visrep_gemm_v5_dispatch(b, s);
     }
 #ifdef VISREP_EXPERIMENTS
@@ -330,8 +335,10 @@ int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
         GemmArgs b = a;
         b.dbg = g_visrep_gemm_dbg;
         b.dbg_buf = g_visrep_gemm_dbg_buf;
+        visrep_count_route(VISREP_ROUTE_GEMM_256);
         return visrep_gemm_v2_dispatch(b, s);
     }
+    visrep_count_route(VISREP_ROUTE_GEMM_128);
     switch (a.epi) {
         case EPI_BIAS: return launch<EPI_BIAS>(a, s);
         case EPI_ACT: return launch<EPI_ACT>(a, s);
@@ -371,6 +378,7 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
     part.ldc = a.N;
     part.epi = EPI_F32; part.bias = nullptr; part.resid = nullptr; part.ls = nullptr; part.ln_rt = nullptr; part.ln_s = nullptr;
     part.kslice = a.K / S;
+    visrep_count_route(VISREP_ROUTE_SPLITK);
     const int rc = a.conv ? launch<EPI_F32, true>(part, s) : launch<EPI_F32>(part, s);
     if (rc) return rc;
     if (a.epi == EPI_VT) {
@@ -460,6 +468,7 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
                 if (a.stat_rt) tail.stat_rt = a.stat_rt + m1;
                 const int rc = run_one(head, s, variant);
                 if (rc) return rc;
+                visrep_count_route(VISREP_ROUTE_GEMM_TAIL);
                 const int sk = run_split_k(tail, s);                     // the tail has few tiles: split its K loop when it pays
                 return sk ? (sk < 0 ? sk : 0) : run_one(tail, s, 1);
             }

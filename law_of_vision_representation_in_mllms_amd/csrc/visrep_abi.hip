@@ -39,6 +39,60 @@ hipError_t visrep_lds_opt_in_slow(VisrepLdsOptIn& st, const void* kernel, int by
 
 extern "C" int visrep_version(void) { return VISREP_VERSION; }
 
+thread_local long t_visrep_routes[VISREP_ROUTE_COUNT] = {};
+
+extern "C" int visrep_debug_routes(long* out, int reset) {
+    for (int i = 0; i < VISREP_ROUTE_COUNT; ++i) {
+        if (out) out[i] = t_visrep_routes[i];
+        if (reset) t_visrep_routes[i] = 0;
+    }
+    return VISREP_ROUTE_COUNT;
+}
+
+namespace {
+// visrep_debug_mfma_probe: a free-running MFMA stream (tools/probes/mfma_probe.hip, variant V0 / 16x16x32), operands in registers
+__global__ __launch_bounds__(512, 2) void mfma_probe_kernel(float* sink, int iters, int rnd) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a[4], b[4];
+    unsigned st = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u) ^ 0x9e3779b9u;
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            if (rnd) {      // sign | biased exponent 0x7d..0x80 | random mantissa: |x| in [0.25, 4) - activations-sized values, every bit toggling
+                st = st * 1664525u + 1013904223u; unsigned r = st >> 8;
+                a[i][e] = (short)(((r & 1) << 15) | ((0x7d + ((r >> 1) & 3)) << 7) | ((r >> 3) & 0x7f));
+                st = st * 1664525u + 1013904223u; r = st >> 8;
+                b[i][e] = (short)(((r & 1) << 15) | ((0x7d + ((r >> 1) & 3)) << 7) | ((r >> 3) & 0x7f));
+            } else {
+                a[i][e] = (short)(e == 0 ? lane + i : e);
+                b[i][e] = (short)(e == 0 ? lane * 3 + i : e);
+            }
+        }
+    f32x4 acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+        if ((it & 63) == 63) {                                   // keep the sums finite and the accumulator bits moving: restart from a small value
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] *= 1e-3f;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += acc[i][1];
+    if (s == 123.456f) sink[0] = s;                              // keeps the accumulators live; never true in practice
+}
+}  // namespace
+
+extern "C" int visrep_debug_mfma_probe(int iters, int random, void* sink, double* flop, void* stream) {
+    if (iters <= 0 || !sink) return visrep_set_error(VISREP_ERR_ARG, "mfma_probe: iters > 0 and a device sink are required");
+    const int ncu = visrep_cu_count();
+    if (flop) *flop = (double)ncu * 8.0 * iters * 32.0 * 16384.0;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(ncu), dim3(512), 0, (hipStream_t)stream, (float*)sink, iters, random);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mfma_probe: launch failed");
+}
+
 extern "C" int visrep_set_gemm_variant(int variant) {            // per-thread (see visrep_internal.h); returns the previous value
 #ifdef VISREP_EXPERIMENTS
     const bool ok = variant >= 1 && variant <= 5;

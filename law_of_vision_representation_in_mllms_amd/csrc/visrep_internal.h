@@ -93,6 +93,10 @@ int visrep_attention_ab_launch(const void* q, int ldq, const void* k, int ldk, c
                                int B, int Tq, int Tk, int H, int kv_shared, int causal, float scale, hipStream_t st);
 extern thread_local int t_visrep_attn_variant;
 int visrep_set_error(int code, const char* msg);
+// Which kernel family a call was routed to - per-THREAD launch counters read by visrep_debug_routes() (tests assert that a shape takes the
+// route it was tuned for; two integer adds per launch, no device work).  Indices are VISREP_ROUTE_* of include/visrep.h.
+extern thread_local long t_visrep_routes[VISREP_ROUTE_COUNT];
+inline void visrep_count_route(int r) { ++t_visrep_routes[r]; }
 // split-bf16 product sets (GemmArgs::tab_a / tab_w, attn_f32_split_kernel): products in {3, 4, 6}; planes needed = 2, 2, 3
 inline int visrep_split_planes(int products) { return products == 6 ? 3 : 2; }
 inline bool visrep_split_tables(int products, unsigned& tab_a, unsigned& tab_w) {

@@ -703,6 +703,54 @@ def test_sd15_full_depth_256px_parity(monkeypatch):
     assert e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)
 
 
+def test_sd15_768px_sweep_launch_shape_parity_and_routes(monkeypatch):
+    """SD1.5 at the shape the sweep LAUNCHES - 768-px images, 16 per launch - against the fp32 CPU oracle on one of the
+    images (the other 15 are arbitrary), bounded by the oracle's own bf16 run; and the routes the dispatcher picks only at this shape are
+    asserted, not assumed: the VAE's 256- / 512-channel 3x3 convolutions in the persistent 256x256 kernel (`conv_256`), its 128-channel
+    768^2 / 384^2 layers in the 128x128 kernel with GroupNorm partial sums from the epilogue (`conv_128_gn`), the 12^2 / 24^2 UNet
+    convolutions through deterministic split-K, the VAE's mid-block attention in the wide-head flash kernel, head / tail splits with a row
+    offset (`gemm_tail`).  The eager forward is measured (a HIP-graph replay does not pass the dispatcher); the replayed graph must give
+    the same features bit for bit."""
+    from types import SimpleNamespace
+    from law_of_vision_representation_in_mllms_amd import _lib
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import builder as B
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    NB, PX = 16, 768
+    args = SimpleNamespace(vision_tower='runwayml/stable-diffusion-v1-5', up_ft_index=0, t=261, prompt="a photo of a cat",
+                           ensemble_size=1, img_size=PX)
+    feat = B.build_diffusion_vision_tower(args).vision_tower
+    sp = feat.spec
+    rs = np.random.RandomState(31)
+    imgs = torch.from_numpy(rs.uniform(-1, 1, (NB, 3, PX, PX)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((NB, 4, PX // 8, PX // 8)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((NB, 4, PX // 8, PX // 8)).astype(np.float32))
+    pe = feat.encode_prompt(args.prompt)
+    eng = feat._engine(0)                                                                                             # the SdEngine behind SDFeaturizer.forward(up_ft_index=0)
+    eng.graph = False
+    _lib.routes(reset=True)
+    got = eng.forward(imgs, pe, t=261, ensemble_size=1, post_noise=post, ddim_noise=ddim)                             # [16, 576, 1280], eager
+    r = _lib.routes(reset=True)
+    print(f"routes of one eager SD1.5 forward at {PX} px x {NB}: {r}")
+    assert got.shape == (NB, 576, 1280) and torch.isfinite(got.float()).all()
+    # what the sweep's launch shape is tuned for (profiles/round4_sd15_kernel_stats.md): asserted per route
+    assert r["conv_256"] >= 16, r            # VAE 256- / 512-channel layers at 384^2 / 192^2 / 96^2: whole rounds of 256x256 tiles
+    assert r["conv_128_gn"] >= 4, r          # VAE 128-channel layers at 768^2 (+ the 384^2 downsample): statistics from the epilogue
+    assert r["attn_wide"] == 1, r            # the VAE's 512-wide single head: one flash launch for the batch
+    assert r["splitk"] >= 4, r               # 12^2 / 24^2 UNet convolutions and projections: few tiles, deep K
+    assert r["gemm_tail"] + r["conv_256"] + r["gemm_256"] > 0 and r["attn"] >= 8, r
+    eng.graph = True
+    again = eng.forward(imgs, pe, t=261, ensemble_size=1, post_noise=post, ddim_noise=ddim)                           # warm-up + capture + replay
+    assert torch.equal(again, got)
+    k = 5                                                                                                            # the checked image: not the first of the launch
+    wu = {kk: v for kk, v in feat._wu.items() if not kk.startswith(("up_blocks.1", "up_blocks.2", "up_blocks.3"))}
+    want = OD.sd_features(sp, wu, feat._wv, imgs[k:k + 1], pe.float().cpu(), post[k:k + 1], ddim[k:k + 1], t=261)     # [1, 576, 1280]
+    ref_bf16 = OD.sd_features(sp, wu, feat._wv, imgs[k:k + 1], pe.float().cpu(), post[k:k + 1], ddim[k:k + 1], t=261, dtype=torch.bfloat16)
+    e_hip, e_ref = rel_err(got[k:k + 1], want), rel_err(ref_bf16, want)
+    print(f"SD1.5 @768 px, image {k} of a 16-image launch: HIP {e_hip:.3e}  oracle bf16 {e_ref:.3e}  routes {r}")
+    assert e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)
+
+
 def test_vae_mid_block_attention_at_9216_tokens():
     """the 768-px VAE's mid-block attention (96 x 96 = 9,216 latent pixels, ONE head of width 512: fp32 score GEMM ->
     softmax_rows -> role-swapped V^T GEMM -> P V GEMM, per image through HBM) was only ever compared at 1,024 tokens.  Here at the real token
