@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 410   /* round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
+#define VISREP_VERSION 500   /* round 5: device CU count, routing counters, MFMA probe, A-score reference arithmetic, host twins (new exports only).  410 = round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
@@ -344,6 +344,23 @@ int visrep_cscore_transfer_packed(const float* feats, const int* rows_tab, const
  * fp64 [n_pairs], alphas3 = HOST pointer to 3 floats; counts int32 [n_pairs,4] = hits@a0,a1,a2, n_visible. */
 int visrep_pck_count(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp, int n_pairs,
                      int kmax, const float* alphas3, int* counts, void* stream);
+
+/* ==== HOST twins ("`*_cpu` twins with identical signatures minus stream back config 1"; BASELINE configs[0]: the CLIP-L/14 tower
+ * on 32 images, CPU fp32, plumbing without a GPU).  Plain C++ on host threads, fp32, HOST pointers, `threads` <= 0 = min(hardware threads, 32).
+ * An independent implementation (csrc/host_twins.hip): it shares no code with the device kernels and never runs unless the caller asks for
+ * device "cpu" explicitly - the device entry points above still fail without a GPU.  Same semantics as their device counterparts:
+ *   visrep_vit_forward_cpu: fp32 weights in the visrep_vit_weights struct (matrices fp32 [out, in], patch_w [d, kpad]; sqkv / s1 ignored),
+ *   pixels fp32 [B, 3, S, S], hidden fp32 [B, tokens, d] = hidden_states[n_layers];
+ *   visrep_ascore_maxcos_cpu: fp32 [n_img, Nt | Nr, D] -> scores fp32 [n_img];
+ *   visrep_cscore_transfer_cpu / visrep_pck_count_cpu: arguments of visrep_cscore_transfer / visrep_pck_count. */
+int visrep_vit_forward_cpu(const visrep_vit_config* cfg, const visrep_vit_weights* w, const float* pixels, float* hidden, int B, int n_layers,
+                           int threads);
+int visrep_ascore_maxcos_cpu(const float* other, const float* ref, int n_img, int Nt, int Nr, int D, float* scores, int threads);
+int visrep_cscore_transfer_cpu(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp, const float* lin,
+                               float* xy, int n_pairs, int kmax, int P, int C, int split, int window, int soft_eval, float beta,
+                               float anno_stride, float anno_half, int layout, int threads);
+int visrep_pck_count_cpu(const float* xy, const float* kps1, const float* kps2, const double* thresholds, const int* nkp, int n_pairs, int kmax,
+                         const float* alphas3, int* counts);
 
 /* ==== Convolutional-tower primitives (Stable-Diffusion feature towers) ==================================
  * All activations are channels-last token matrices: [B*H*W, C] bf16.  A 3x3 convolution = visrep_im2col3x3 +

@@ -58,6 +58,8 @@ def _shard(n, rank, world):
 def _score_batch(other, ref, other_scale=None, ref_scale=None, arithmetic="exact"):
     """[n, Nt, D] x [n, Nr, D] -> [n] on the device: the HIP kernel (no CPU fallback; tests may monkeypatch this hook)."""
     from .. import ascore_ops
+    if other.device.type == "cpu":                # only reachable through an EXPLICIT device="cpu" (compute(device=), --device cpu): the host twin
+        return ascore_ops.max_cos_mean_cpu(other, ref)
     if arithmetic == "reference" and other.dtype == torch.bfloat16 and ref.dtype == torch.bfloat16:
         return ascore_ops.max_cos_mean(other, ref, arithmetic="reference")        # torch's bf16 op chain, rounding by rounding
     return ascore_ops.max_cos_mean(other, ref, other_scale, ref_scale)
@@ -67,6 +69,8 @@ def _row_scales(x):
     """Per-row normalisation factors of a token stack, computed once and handed to every _score_batch call that uses the stack
     (hook: a stand-in that returns None makes _score_batch compute them itself)."""
     from .. import ascore_ops
+    if x.device.type == "cpu":                    # host twin (explicit device="cpu"): it normalises inside the call
+        return None
     return ascore_ops.row_scales(x)
 
 
@@ -158,13 +162,15 @@ def main(argv=None):
     ap.add_argument("--base-folder", default=base_folder)
     ap.add_argument("--subfolders", nargs="*", default=None)
     ap.add_argument("--n-images", type=int, default=100)
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cuda = the HIP kernels (fails without a GPU: there is no fallback); cpu = the host twin (plain C++ fp32, explicit opt-in)")
     ap.add_argument("--arithmetic", default=None, choices=["exact", "reference"],
                     help="reference = the script's in-dtype arithmetic on bf16 tensors (per-op bf16 rounding: the published table's numbers)")
     a = ap.parse_args(argv)
     from .. import dist_env
     owned = dist_env.init_from_env()                                  # under torchrun: one process per GPU, images sharded over ranks
     try:
-        return compute(a.base_folder, a.subfolders, a.n_images, device="cuda" if torch.cuda.is_available() else "cpu", arithmetic=a.arithmetic)
+        return compute(a.base_folder, a.subfolders, a.n_images, device=a.device, arithmetic=a.arithmetic)
     finally:
         dist_env.finalize(owned)
 

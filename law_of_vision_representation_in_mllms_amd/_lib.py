@@ -11,7 +11,7 @@ import threading
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VISREP_LIB") or os.path.join(_PKG, "libvisrep_hip.so")   # VISREP_LIB: diagnostic builds only
 
-ABI_VERSION = 410                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
+ABI_VERSION = 500                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
 BF16, F32 = 0, 1
 EPI_BIAS, EPI_ACT, EPI_RESID, EPI_VT, EPI_PATCH, EPI_F32 = range(6)
 ACT = {"none": 0, "quick_gelu": 1, "gelu": 2, "gelu_erf": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3}
@@ -107,6 +107,10 @@ SIGNATURES = {
     "visrep_ascore_maxcos_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "visrep_ascore_refarith_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "visrep_ascore_maxcos_refarith": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "visrep_vit_forward_cpu": (_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), _vp, _vp, _i, _i, _i]),
+    "visrep_ascore_maxcos_cpu": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "visrep_cscore_transfer_cpu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i]),
+    "visrep_pck_count_cpu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp]),
     "visrep_cscore_transfer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp]),
     "visrep_cscore_transfer_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "visrep_pck_count": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _vp]),

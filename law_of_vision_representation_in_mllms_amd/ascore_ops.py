@@ -76,3 +76,20 @@ def max_cos_mean(other: torch.Tensor, ref: torch.Tensor, other_scale: Optional[t
                                          _lib.ptr(scores), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, "visrep_ascore_maxcos_scaled")
     return scores
+
+
+@torch.no_grad()
+def max_cos_mean_cpu(other: torch.Tensor, ref: torch.Tensor, threads: int = 0) -> torch.Tensor:
+    """The A score's per-image term on HOST cores (visrep_ascore_maxcos_cpu: plain C++ fp32, csrc/host_twins.hip) - the `*_cpu` twin of
+    SURVEY §8b for boxes without a GPU.  Explicit entry point only: max_cos_mean() never falls back to it.  CPU tensors in (any float
+    dtype, upcast to fp32 = the parity definition of SURVEY F4), fp32 [n] out."""
+    lib = _lib.load()
+    if other.dim() != 3 or ref.dim() != 3 or other.shape[0] != ref.shape[0] or other.shape[2] != ref.shape[2]:
+        raise ValueError("expected other [n, Nt, D] and ref [n, Nr, D]")
+    if other.device.type != "cpu" or ref.device.type != "cpu":
+        raise ValueError("max_cos_mean_cpu takes CPU tensors (the device path is max_cos_mean)")
+    o, r = other.float().contiguous(), ref.float().contiguous()
+    n, Nt, D = o.shape
+    scores = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.visrep_ascore_maxcos_cpu(_lib.ptr(o), _lib.ptr(r), n, Nt, r.shape[1], D, _lib.ptr(scores), int(threads)), "visrep_ascore_maxcos_cpu")
+    return scores

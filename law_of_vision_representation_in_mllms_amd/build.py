@@ -24,7 +24,7 @@ OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
 # the product library: GEMM v1 (128x128: tails, split-K, N % 256 != 0, implicit convolution), v2 (K % 64 != 0), v5 (default), attn_fwd
 SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v5.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip", "ascore_ref.hip",
-           "cscore.hip", "f32ops.hip", "jpeg_decode.hip", "visrep_abi.hip"]
+           "cscore.hip", "f32ops.hip", "jpeg_decode.hip", "host_twins.hip", "visrep_abi.hip"]
 # measured dead ends kept for the record (GEMM v3 / v4, attn_fwd_ab): compiled only into the tools-only library
 # libvisrep_hip_exp.so (build_experiments_lib, -DVISREP_EXPERIMENTS), never into what ships
 EXPERIMENT_SOURCES = ["gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "attention_ab.hip"]

@@ -203,3 +203,48 @@ def mutual_nn_distance(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tenso
         _lib.check(lib.visrep_mutual_nn_distance(_lib.ptr(gram), _lib.ptr(r1), _lib.ptr(r2), m, PP, float(eps), C.c_void_p(out.data_ptr() + 4 * s), _lib.stream_ptr()),
                    "visrep_mutual_nn_distance")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ host twins (explicit device "cpu" only)
+@torch.no_grad()
+def transfer_cpu(bank: torch.Tensor, img1, img2, patch_idx, nkp, P: int, window: int = 5, soft_eval: bool = True, beta: float = 0.02,
+                 anno_size: int = 840, split: int = 0, layout: str = "cp", threads: int = 0) -> torch.Tensor:
+    """transfer() on HOST cores (visrep_cscore_transfer_cpu, csrc/host_twins.hip: plain C++ fp32) - the `*_cpu` twin of SURVEY §8b.  CPU
+    tensors in, xy fp32 [n, kmax, 2] out; same arguments and semantics as transfer(); never used as a fallback."""
+    if soft_eval and window < 0:
+        raise NotImplementedError("SOFT_EVAL_WINDOW < 0 (Gaussian-kernel soft-argmax, 60x60 maps only in the reference) is not built")
+    lib = _lib.load()
+    if layout not in ("cp", "pc"):
+        raise ValueError("layout must be 'cp' ([n, C, P*P]) or 'pc' ([n, P*P, C])")
+    if bank.device.type != "cpu" or bank.dtype != torch.float32 or bank.dim() != 3 or bank.shape[2 if layout == "cp" else 1] != P * P:
+        raise ValueError("bank must be a CPU fp32 tensor [n_images, C, P*P] (layout 'cp') or [n_images, P*P, C] (layout 'pc')")
+    C_ = bank.shape[1 if layout == "cp" else 2]
+    bank = bank.contiguous()
+    i32 = lambda t: torch.as_tensor(t).to(device="cpu", dtype=torch.int32).contiguous()
+    img1, img2, patch_idx, nkp = i32(img1), i32(img2), i32(patch_idx), i32(nkp)
+    n, kmax = patch_idx.shape
+    stride = anno_size / P
+    lin = torch.tensor(np.linspace(-1, 1, P)).float()
+    xy = torch.zeros(n, kmax, 2, dtype=torch.float32)
+    rc = lib.visrep_cscore_transfer_cpu(_lib.ptr(bank), _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(patch_idx), _lib.ptr(nkp), _lib.ptr(lin), _lib.ptr(xy),
+                                        n, kmax, P, C_, int(split), int(window), int(soft_eval), float(beta), float(stride), float(stride // 2),
+                                        0 if layout == "cp" else 1, int(threads))
+    _lib.check(rc, "visrep_cscore_transfer_cpu")
+    return xy
+
+
+@torch.no_grad()
+def pck_counts_cpu(xy: torch.Tensor, kps1: torch.Tensor, kps2: torch.Tensor, thresholds: torch.Tensor, nkp: torch.Tensor,
+                   alphas=(0.1, 0.05, 0.01)) -> torch.Tensor:
+    """pck_counts() on the host (visrep_pck_count_cpu): counts int32 [n, 4] = hits@alpha0..2, n_visible."""
+    lib = _lib.load()
+    n, kmax, _ = xy.shape
+    f32 = lambda t: t.to(device="cpu", dtype=torch.float32).contiguous()
+    xy, kps1, kps2 = f32(xy), f32(kps1), f32(kps2)
+    thr = thresholds.to(device="cpu", dtype=torch.float64).contiguous()
+    nk = nkp.to(device="cpu", dtype=torch.int32).contiguous()
+    counts = torch.zeros(n, 4, dtype=torch.int32)
+    a = (C.c_float * 3)(*[float(np.float32(x)) for x in alphas])
+    _lib.check(lib.visrep_pck_count_cpu(_lib.ptr(xy), _lib.ptr(kps1), _lib.ptr(kps2), _lib.ptr(thr), _lib.ptr(nk), n, kmax, a, _lib.ptr(counts)),
+               "visrep_pck_count_cpu")
+    return counts

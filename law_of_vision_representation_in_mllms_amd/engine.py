@@ -344,9 +344,70 @@ def best_chunk(tokens: int, d: int, cap: int, cus: Optional[int] = None) -> int:
     return max(c for c, e in effs.items() if e >= top - 0.01)
 
 
+class VitEngineCPU:
+    """The same tower on HOST cores (visrep_vit_forward_cpu, csrc/host_twins.hip): plain C++ fp32 on host threads.  BASELINE configs[0]
+    ("vision_tower feature-extract on 32 COCO images, CPU float32 - plumbing, no GPU") and SURVEY §8b's `*_cpu` twins.  Built ONLY when the
+    caller asks for device "cpu" explicitly (make_engine(..., device="cpu"); a tower config with device="cpu") - the GPU engines never fall
+    back to it.  forward() takes and returns CPU fp32 tensors."""
+
+    def __init__(self, spec: ViTSpec, weights: dict, threads: Optional[int] = None):
+        self.lib = _lib.load()
+        self.spec = spec
+        self.device = torch.device("cpu")
+        self.threads = int(threads) if threads else 0
+        self._keep = []
+
+        def f32(t):
+            if t is None:
+                return None
+            x = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            self._keep.append(x)
+            return x
+        if weights["pos"].shape[0] != spec.tokens:
+            raise ValueError(f"position embedding has {weights['pos'].shape[0]} rows, spec wants {spec.tokens}")
+        self.kpad = 3 * spec.patch * spec.patch
+        self._patch_w = f32(weights["patch_w"].reshape(spec.d, -1)[:, : self.kpad])
+        self._vecs = {k: f32(weights.get(k)) for k in ("patch_b", "cls", "pos", "pre_ln_g", "pre_ln_b")}
+        n = len(weights["layers"])
+        self.n_layers = n
+        self._layers = (_lib.VitLayer * max(n, 1))()
+        for i, L in enumerate(weights["layers"]):
+            ent = self._layers[i]
+            for k in ("wqkv", "wo", "w1", "w2", "ln1_g", "ln1_b", "bqkv", "bo", "ls1", "ln2_g", "ln2_b", "b1", "b2", "ls2"):
+                v = f32(L.get(k))
+                setattr(ent, k, 0 if v is None else v.data_ptr())
+            ent.sqkv = 0
+            ent.s1 = 0
+        self._w = _lib.VitWeights()
+        self._w.patch_w = self._patch_w.data_ptr()
+        for k, v in self._vecs.items():
+            setattr(self._w, k, 0 if v is None else v.data_ptr())
+        self._w.layers = C.cast(self._layers, C.POINTER(_lib.VitLayer))
+        self._cfg = _lib.VitConfig(spec.image_size, spec.patch, spec.d, spec.heads, spec.mlp, n, spec.tokens,
+                                   int(spec.has_cls), int(spec.pre_ln), _lib.ACT[spec.act], self.kpad, float(spec.eps))
+
+    @torch.no_grad()
+    def forward(self, pixels: torch.Tensor, n_layers: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        s = self.spec
+        if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != s.image_size or pixels.shape[3] != s.image_size:
+            raise ValueError(f"Input image size {tuple(pixels.shape)} doesn't match tower ({s.image_size}*{s.image_size}).")
+        n_layers = self.n_layers if n_layers is None else n_layers
+        if not 0 <= n_layers <= self.n_layers:
+            raise ValueError("n_layers out of range")
+        px = pixels.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        B = px.shape[0]
+        if out is None:
+            out = torch.empty(B, s.tokens, s.d, dtype=torch.float32)
+        rc = self.lib.visrep_vit_forward_cpu(C.byref(self._cfg), C.byref(self._w), _lib.ptr(px), _lib.ptr(out), B, n_layers, self.threads)
+        _lib.check(rc, "visrep_vit_forward_cpu")
+        return out
+
+
 def make_engine(spec: ViTSpec, weights: dict, device=None, precision: str = "bf16", products: Optional[int] = None):
     """precision 'bf16' = the MFMA throughput engine; 'fp32' = the reference-precision engine (products: its split-bf16 product set,
-    None = DEFAULT_SPLIT_PRODUCTS)."""
+    None = DEFAULT_SPLIT_PRODUCTS).  device "cpu" - and only an explicit "cpu" - builds the host twin (fp32, whatever `precision` says)."""
+    if device is not None and torch.device(device).type == "cpu":
+        return VitEngineCPU(spec, weights)
     if precision in ("bf16", torch.bfloat16):
         return VitEngine(spec, weights, device)
     if precision in ("fp32", "float32", torch.float32):

@@ -172,8 +172,10 @@ class HipViTTower(nn.Module):
         cfg = SimpleNamespace(hidden_size=spec.d, image_size=spec.image_size, patch_size=spec.patch,
                               num_hidden_layers=spec.layers, num_attention_heads=spec.heads, intermediate_size=spec.mlp)
         fp32 = self._precision in ("fp32", "float32")
-        self.vision_tower = _EngineModule(engine.make_engine(spec, w, self._device, "fp32" if fp32 else "bf16", products=self._products if fp32 else None), cfg,
-                                          torch.float32 if fp32 else torch.bfloat16)
+        eng = engine.make_engine(spec, w, self._device, "fp32" if fp32 else "bf16", products=self._products if fp32 else None)
+        if isinstance(eng, engine.VitEngineCPU):                            # args.device = "cpu": the host twin (explicit opt-in; BASELINE configs[0])
+            fp32 = True
+        self.vision_tower = _EngineModule(eng, cfg, torch.float32 if fp32 else torch.bfloat16)
         self.vision_tower.requires_grad_(False)
         self.is_loaded = True
 

@@ -606,6 +606,21 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
         raise ValueError("the A score needs the clip336 and clip224 settings in the sweep (A_score/compute.py:31-35)")
     images = sum(v["images"] for v in per.values())
     extra = {"wall_s_all_bf16": round(wall + wall_swap, 3)} if also_bf16 and precision == "reference" and do_c else {}
+    # every rank's setup time (engine construction + HIP-graph capture + resident pixels): outside the timed legs, inside anyone's wall-clock
+    setup_ranks = [round(setup, 3)]
+    d = _dist()
+    if d is not None and world > 1:
+        allr = [None] * world
+        d.all_gather_object(allr, round(setup, 3))
+        setup_ranks = [float(x) for x in allr]
+    a_total = sum(v.get("a_s", 0.0) for v in per.values())
+    c_total = sum(v.get("c_s", 0.0) for v in per.values())
+    # one table-ready row per run: `bench.py --gpus N` at N = 1, 2, 4, 8 gives the north star's scaling line (images/s of the whole sweep,
+    # per-leg seconds) without post-processing - the driver computes the efficiency from the rows
+    scaling_row = {"n_gpus": world, "wall_s": round(wall, 3), "img_s": round(images / wall, 2) if wall else None,
+                   "a_leg_s": round(a_total, 3), "c_leg_s": round(c_total, 3),
+                   "c_leg_s_by_setting": {k: v.get("c_s") for k, v in per.items() if "c_s" in v},
+                   "setup_s_max_over_ranks": max(setup_ranks), "setup_s_per_rank": setup_ranks, "images": images}
     return {"wall_s": round(wall, 3), **extra, "setup_s": round(setup, 3), "world": world, "settings": len(per), "images": images,
             "img_s": round(images / wall, 2) if wall else None, "img_s_per_gpu": round(images / wall / world, 2) if wall else None,
             "a_images_per_setting": n_a_images if do_a else 0, "c_images_per_setting": n_c_images,
@@ -614,7 +629,7 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
                               f"{int(fp32_products)} (explicit opt-in; 6 = fp32-equivalent, 3 = two-plane operands, mid x mid dropped)"),
             "scaling": "strong (fixed total work, images sharded rank::world, C categories owned by ranks)",
             "pixels": "resident in HBM (drawn in each setting's setup)" if hasattr(pixels, "prefetch") else "drawn by the caller's image source inside the legs",
-            "per_setting": per}
+            "scaling_row": scaling_row, "per_setting": per}
 
 
 # ------------------------------------------------------------------------------------------------ encoder-sharded A score (configs[2])

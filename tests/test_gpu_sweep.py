@@ -98,7 +98,9 @@ def test_reduced_sweep_matches_the_oracle_chain(tiny_registry, precision):
     for st in SETTINGS:
         ent, (A, pck) = out["per_setting"][st.name], want[st.name]
         c_fp32 = precision == "fp32" or (precision == "reference" and st.name != "SigLIP")
-        assert ent["dtype"] == {"a": "fp32" if precision == "fp32" else "bf16", "c": "fp32" if c_fp32 else "bf16"}, st.name
+        # fp32 legs are labelled with their route: "fp32" (exact-fp32 MFMA) or "fp32[split-bf16 xN]" (N plane-pair products)
+        kind = lambda lab: "+".join(sorted({x.split("[")[0] for x in lab.split("+")}))
+        assert {k: kind(v) for k, v in ent["dtype"].items()} == {"a": "fp32" if precision == "fp32" else "bf16", "c": "fp32" if c_fp32 else "bf16"}, st.name
         if precision == "fp32":
             assert abs(ent["A"] - A) <= 1e-4 * abs(A), (st.name, ent["A"], A)          # the north-star bar, images -> score
         else:
@@ -110,6 +112,40 @@ def test_reduced_sweep_matches_the_oracle_chain(tiny_registry, precision):
         if precision == "reference":
             assert ("c_s_bf16" in ent) == (st.name != "SigLIP")                        # the bf16 twin of every fp32 C leg, timed beside it
     assert ("wall_s_all_bf16" in out) == (precision == "reference")
+
+
+@pytest.mark.parametrize("world", [4, 3])
+def test_c_leg_exchange_with_device_buffers_at_world_4(monkeypatch, world):
+    """the C leg's owner-addressed all_to_all_single with REAL device buffers at world > 2.  RCCL refuses two ranks on one
+    GPU and gloo has no device all-to-all, so the ranks run as threads of this process (tests/_thread_dist.ThreadDist: rendezvous + device
+    copies with the production split tables); everything else is sweep.c_score_of as the launcher runs it - shard plan, launch plan, send /
+    receive splits, bank rows, asynchronous completion under the next launch, rank-owned categories, all_gather_object of the results.
+    The tower is an ELEMENTWISE function of the pixels (bit-identical whatever the launch's batch), so every rank's result must equal the
+    single-process run exactly, and every map crosses the fabric at most once."""
+    from _thread_dist import ThreadDist
+    from law_of_vision_representation_in_mllms_amd.C_score import pck_train as PT
+    P, C_ = 6, 64
+    spair = S.synthetic_spair(46, 120)                                   # 18 categories, uneven image counts
+
+    class Tower:
+        setting = S.Setting("Elementwise", "ew", ("ew",), 12, 5)        # launches of 5: several exchanges per rank, a remainder launch
+        split = 0
+
+        @staticmethod
+        def tokens(px):                                                  # [B, 3, 12, 12] -> [B, 36, 64] bf16: sin of (pooled pixel x frequency)
+            m = px.float().reshape(px.shape[0], 3, P, 2, P, 2).mean((1, 3, 5)).reshape(px.shape[0], P * P, 1)
+            f = torch.arange(1, C_ + 1, device=px.device, dtype=torch.float32).view(1, 1, C_)
+            return torch.sin(m * f * 3.0 + f).to(torch.bfloat16)
+    pixels = lambda ids, size: S.synthetic_pixels(ids, size, DEV, torch.float32)
+    want = S.c_score_of(Tower, spair, pixels, torch.device(DEV), 0, 1)
+    td = ThreadDist(world)
+    monkeypatch.setattr(S, "_dist", lambda: td)
+    monkeypatch.setattr(PT, "_dist", lambda: td)
+    got = td.run(lambda r: S.c_score_of(Tower, spair, pixels, torch.device(DEV), r, world))
+    for r in range(world):
+        assert list(got[r]) == list(want), (r, got[r], want)            # every rank: the single-process numbers, exactly
+    n_items = sum(c.n_images for c in spair)
+    assert 0 < td.bytes_on_fabric <= n_items * P * P * C_ * 2           # bf16 rows, each at most once
 
 
 def test_encoder_sharded_a_score_equals_image_sharded_on_device(tiny_registry):

@@ -1,0 +1,151 @@
+"""The HOST twins (csrc/host_twins.hip; SURVEY §8b `*_cpu`, BASELINE configs[0] "CPU float32, plumbing, no GPU") against the
+reference-produced golden vectors - on the CPU box, no GPU involved.  They are an independent C++ implementation reached only through
+an explicit device="cpu"; the oracle appears here only as the checker for the one case the goldens do not hold (two-encoder maps)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from law_of_vision_representation_in_mllms_amd import ascore_ops, cscore_ops, engine
+from law_of_vision_representation_in_mllms_amd import vit_weights as VW
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("tag", ["clip_quick", "clip_gelu", "dinov2_native", "dinov2_interp", "siglip"])
+def test_vit_tower_cpu_matches_the_reference_towers(tag):
+    """visrep_vit_forward_cpu on the tiny CLIP (quick_gelu, gelu) / DINOv2 (native + interpolated grid) / SigLIP configurations whose
+    outputs the REFERENCE tower classes produced (tests/golden/vit_tiny.npz: head width 32, patch 7): hidden_states[-2] to 2e-5."""
+    z = np.load(f"{G}/vit_tiny.npz")
+    spec = eval(str(z[f"{tag}.spec"]), {"ViTSpec": VW.ViTSpec})
+    w = VW.unflatten({k[len(tag) + 3:]: z[k] for k in z.files if k.startswith(f"{tag}.w.")})
+    px = torch.from_numpy(z[f"{tag}.pixels"])
+    want = torch.from_numpy(z[f"{tag}.feat"])
+    eng = engine.make_engine(spec, w, device="cpu")
+    assert isinstance(eng, engine.VitEngineCPU)
+    got = eng.forward(px, n_layers=len(w["layers"]) - 1)                                  # hidden_states[-2]
+    if spec.family != "siglip":
+        got = got[:, 1:]                                                                  # feature_select 'patch'
+    assert got.dtype == torch.float32 and got.shape == want.shape, tag
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (tag, (got - want).abs().max().item())
+    again = engine.VitEngineCPU(spec, w, threads=1).forward(px, n_layers=len(w["layers"]) - 1)
+    assert torch.equal(again[:, 1:] if spec.family != "siglip" else again, got)           # thread count does not change a bit
+
+
+def test_clip_l14_224_tower_plumbing_on_cpu():
+    """BASELINE configs[0] in miniature: the drop-in registry builds a CLIP tower with device="cpu" and runs images through the reference's
+    tower protocol (forward -> [B, 256, 1024] for L/14 at 224; here 2 of 24 layers of the real width on one image to keep the suite fast)."""
+    from dataclasses import replace
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import builder as B
+    name = "openai/clip-vit-large-patch14"
+    small = replace(VW.SPECS[name], layers=3)
+    old = VW.SPECS[name]
+    VW.SPECS[name] = small
+    try:
+        cfg = SimpleNamespace(mm_vision_tower=name, mm_vision_select_layer=-2, mm_vision_select_feature="patch", synthetic_weights=True, device="cpu")
+        tower = B.build_vision_tower(cfg)
+        assert tower.is_loaded and tower.device.type == "cpu" and tower.dtype == torch.float32 and tower.hidden_size == 1024 and tower.num_patches == 256
+        out = tower(torch.randn(1, 3, 224, 224))
+        assert out.shape == (1, 256, 1024) and out.dtype == torch.float32 and torch.isfinite(out).all()
+        from oracle import vit as OV
+        w = tower.vision_tower.engine
+        # the checker: the oracle on the same packed weights (weights_at_resolution is the identity at the native 224)
+        base = small
+        wts = VW.synthetic_weights(base, seed=1)
+        px = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+        want = OV.tower_features(base, wts, px, -2, "patch")
+        got = tower(px)
+        assert ((got - want).norm() / want.norm()).item() < 1e-5
+    finally:
+        VW.SPECS[name] = old
+
+
+@pytest.mark.parametrize("case", ["fp32_small", "fp32_wide"])
+def test_ascore_cpu_matches_the_reference_script(case):
+    z = np.load(f"{G}/ascore.npz")
+    r336, r224 = torch.from_numpy(z[f"{case}.clip336"]), torch.from_numpy(z[f"{case}.clip224"])
+    n = r336.shape[0]
+    reps = np.array([len(range(j, 100, n)) for j in range(n)], dtype=np.float64)
+    for enc in ("clip336", "clip224", "encA", "encB"):
+        oth = torch.from_numpy(z[f"{case}.{enc}"])
+        s336 = ascore_ops.max_cos_mean_cpu(oth, r336).double().numpy()
+        s224 = ascore_ops.max_cos_mean_cpu(oth, r224).double().numpy()
+        got = ((s336 * reps).sum() / 100 + (s224 * reps).sum() / 100) / 2
+        want = float(z[f"{case}.result.{enc}"])
+        assert abs(got - want) <= 1e-5 * abs(want), (enc, got, want)
+    with pytest.raises(ValueError):
+        ascore_ops.max_cos_mean_cpu(torch.zeros(1, 3, 8), torch.zeros(2, 3, 8))
+
+
+def test_ascore_dropin_script_on_cpu(tmp_path, capsys):
+    """A_score.compute(device="cpu"): the printed lines of the reference script (golden stdout) from tensor files, no GPU."""
+    from law_of_vision_representation_in_mllms_amd.A_score import compute as AC
+    z = np.load(f"{G}/ascore.npz")
+    case = "fp32_small"
+    n = z[f"{case}.clip336"].shape[0]
+    for sub in ("clip336", "clip224", "encA", "encB"):
+        os.makedirs(tmp_path / sub)
+        for i in range(1, 101):
+            torch.save(torch.from_numpy(z[f"{case}.{sub}"][(i - 1) % n]), tmp_path / sub / f"tensor_{i}.pt")
+    res = AC.compute(str(tmp_path), ["clip336", "clip224", "encA", "encB"], device="cpu")
+    lines = [l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("Average cosine similarity")]
+    want = str(z[f"{case}.stdout"]).strip().splitlines()
+    assert len(lines) == 4
+    for gl, wl in zip(lines, want):
+        assert gl.rsplit(":", 1)[0] == wl.rsplit(":", 1)[0]
+        assert abs(float(gl.rsplit(":", 1)[1]) - float(wl.rsplit(":", 1)[1])) <= 1e-5 * abs(float(wl.rsplit(":", 1)[1]))
+    assert set(res) == {"clip336", "clip224", "encA", "encB"}
+
+
+def test_cscore_transfer_cpu_matches_the_reference():
+    """visrep_cscore_transfer_cpu on every case of tests/golden/cscore_transfer.npz (calculate_keypoint_transformation itself: P in {6, 14,
+    16, 24}, windows 0 / 2 / 5, all-negative similarities (F6), corner clamps, hard argmax): <= 5e-3 px in the 840-px frame; both layouts."""
+    from test_oracle_golden import _case_names
+    z = np.load(f"{G}/cscore_transfer.npz")
+    for name in _case_names(z, ".xy"):
+        P, C_, K, soft, win = z[f"{name}.meta"].tolist()
+        f1, f2 = torch.from_numpy(z[f"{name}.f1"]), torch.from_numpy(z[f"{name}.f2"])          # [1, C, P, P]
+        bank = torch.cat([f1, f2]).reshape(2, C_, P * P).float()
+        idx = torch.from_numpy(z[f"{name}.patch_idx"].astype(np.int32))[None]
+        for layout, bk in (("cp", bank), ("pc", bank.transpose(1, 2).contiguous())):
+            xy = cscore_ops.transfer_cpu(bk, [0], [1], idx, [K], P, window=int(win), soft_eval=bool(soft), layout=layout)[0, :K].numpy()
+            np.testing.assert_allclose(xy, z[f"{name}.xy"], rtol=0, atol=5e-3, err_msg=f"{name} {layout}")
+
+
+def test_cscore_two_encoder_split_and_pck_counts_cpu():
+    """split > 0 (pck_train_two.py:24-36: per-encoder L2, concat, L2 again) against the oracle's normalize_feats_two chain; hit counts of
+    visrep_pck_count_cpu against a direct numpy restatement of pck_train.py:149-163."""
+    from oracle import cscore as OC
+    rs = np.random.RandomState(4)
+    P, C1, C2, K = 8, 12, 20, 7
+    maps = torch.from_numpy(rs.standard_normal((2, C1 + C2, P * P)).astype(np.float32))
+    kps = torch.zeros(K, 3)
+    kps[:, :2] = torch.from_numpy(rs.uniform(0, 839, (K, 2)).astype(np.float32))
+    kps[:, 2] = 1
+    idx = OC.kpts_to_patch_idx(kps, P)
+    d = lambda m: OC.normalize_feats_two(m.t()[None], C1)
+    want = OC.keypoint_transfer(d(maps[0]), d(maps[1]), idx, P)
+    got = cscore_ops.transfer_cpu(maps, [0], [1], torch.from_numpy(idx.astype(np.int32))[None], [K], P, split=C1)[0]
+    assert (got - want).abs().max().item() < 5e-3
+    k1 = kps.clone()[None]
+    k2 = kps.clone()[None]
+    k2[0, :, :2] += torch.from_numpy(rs.uniform(-60, 60, (K, 2)).astype(np.float32))
+    k2[0, 2, 2] = 0                                                     # an invisible key point
+    thr = torch.tensor([300.0], dtype=torch.float64)
+    counts = cscore_ops.pck_counts_cpu(got[None], k1, k2, thr, torch.tensor([K]))[0].tolist()
+    vis = (k1[0, :, 2] * k2[0, :, 2] > 0).numpy()
+    err = np.linalg.norm((k2[0, :, :2] - got).numpy()[vis], axis=1).astype(np.float32)
+    want_counts = [int((err.astype(np.float64) < np.float64(np.float32(a)) * 300.0).sum()) for a in (0.1, 0.05, 0.01)] + [int(vis.sum())]
+    assert counts == want_counts
+
+
+def test_device_paths_still_refuse_to_run_without_a_gpu():
+    """The twins are opt-in: the device entry points keep failing loudly on a box without a GPU."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ascore_ops.max_cos_mean(torch.zeros(1, 4, 16), torch.zeros(1, 4, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.make_engine(VW.tiny_spec("clip"), VW.synthetic_weights(VW.tiny_spec("clip"), seed=1))      # device None = the GPU engine
