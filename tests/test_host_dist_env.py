@@ -27,7 +27,7 @@ def _ascore_worker(rank, world, tmp, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from law_of_vision_representation_in_mllms_amd.A_score import compute as AC
     AC._score_batch, AC._row_scales = _oracle_batch, _no_scales
-    res = AC.main(["--base-folder", tmp, "--subfolders", "encA", "encB", "--n-images", "6"])
+    res = AC.main(["--base-folder", tmp, "--subfolders", "encA", "encB", "--n-images", "6", "--device", "cpu"])   # stand-in score hooks: device-agnostic
     q.put((rank, res, torch.distributed.is_initialized()))
 
 
