@@ -25,9 +25,16 @@ LIB = os.path.join(PKG, "libvisrep_hip.so")
 # the product library: GEMM v1 (128x128: tails, split-K, N % 256 != 0, implicit convolution), v2 (K % 64 != 0), v5 (default), attn_fwd
 SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v5.hip", "attention.hip", "rowops.hip", "convnet.hip", "ascore.hip", "ascore_ref.hip",
            "cscore.hip", "f32ops.hip", "jpeg_decode.hip", "host_twins.hip", "visrep_abi.hip"]
-# measured dead ends kept for the record (GEMM v3 / v4, attn_fwd_ab): compiled only into the tools-only library
-# libvisrep_hip_exp.so (build_experiments_lib, -DVISREP_EXPERIMENTS), never into what ships
+# measured dead ends (GEMM v3 / v4, attn_fwd_ab): since round 5 they live as a patch (tools/experiments/dead_end_kernels_r2_r3.patch adds the three
+# files back); with it applied, build_experiments_lib() compiles them into the tools-only libvisrep_hip_exp.so (-DVISREP_EXPERIMENTS) - never
+# into what ships
 EXPERIMENT_SOURCES = ["gemm_bf16_v3.hip", "gemm_bf16_v4.hip", "attention_ab.hip"]
+
+
+def _need_experiment_sources():
+    missing = [f for f in EXPERIMENT_SOURCES if not os.path.exists(os.path.join(CSRC, f))]
+    if missing:
+        raise RuntimeError(f"experiment sources {missing} are not in the tree: `git apply tools/experiments/dead_end_kernels_r2_r3.patch` first")
 HEADERS = ["common.h", "gemm_epilogue.h", "visrep_internal.h", os.path.join("..", "..", "include", "visrep.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
@@ -147,6 +154,7 @@ def build_attn_ablation_lib(mask: int) -> str:
 def build_variant_lib(name: str, defines, only=None, experiments: bool = False) -> str:
     """Diagnostic build with extra -D flags (tools/ only): libvisrep_hip_<name>.so, loaded through VISREP_LIB."""
     if experiments:
+        _need_experiment_sources()
         return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), ["-DVISREP_EXPERIMENTS"] + list(defines), name, sources=SOURCES + EXPERIMENT_SOURCES)
     return _build(os.path.join(PKG, f"libvisrep_hip_{name}.so"), list(defines), name, only=only)
 
@@ -154,6 +162,7 @@ def build_variant_lib(name: str, defines, only=None, experiments: bool = False) 
 def build_experiments_lib() -> str:
     """libvisrep_hip_exp.so = the product sources + GEMM v3 / v4 + attn_fwd_ab with -DVISREP_EXPERIMENTS (tools/ only, loaded through
     VISREP_LIB): the variants the round-2 / round-3 profiles measured and rejected stay reproducible without shipping."""
+    _need_experiment_sources()
     return _build(os.path.join(PKG, "libvisrep_hip_exp.so"), ["-DVISREP_EXPERIMENTS"], "exp", sources=SOURCES + EXPERIMENT_SOURCES)
 
 

@@ -127,8 +127,9 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
             raise ValueError(f"at most 32 key points per pair (patch_idx has {kmax} columns)")
         tab_d, tgt_d = packed if isinstance(packed, tuple) else packed_rows_on(dev, img1, img2, patch_idx, nkp)
         xy = torch.zeros(n, kmax, 2, dtype=torch.float32, device=dev)
+        lin = lin_table(P, dev)          # a NAMED tensor: a temporary would return its block to the allocator before the launch is enqueued
         if tgt_d.shape[0]:
-            rc = lib.visrep_cscore_transfer_packed(_lib.ptr(bank), _lib.ptr(tab_d), _lib.ptr(tgt_d), _lib.ptr(lin_table(P, dev)), _lib.ptr(xy), int(tgt_d.shape[0]), kmax,
+            rc = lib.visrep_cscore_transfer_packed(_lib.ptr(bank), _lib.ptr(tab_d), _lib.ptr(tgt_d), _lib.ptr(lin), _lib.ptr(xy), int(tgt_d.shape[0]), kmax,
                                                    P, C_, int(split), int(window), int(soft_eval), float(beta), float(stride), float(stride // 2),
                                                    _lib.stream_ptr())
             _lib.check(rc, "visrep_cscore_transfer_packed")
@@ -143,8 +144,9 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     if order is not None:
         img1, img2, patch_idx, nkp = (t.index_select(0, order).contiguous() for t in (img1, img2, patch_idx, nkp))
     xy = torch.zeros(n, kmax, 2, dtype=torch.float32, device=dev)
+    lin = lin_table(P, dev)
     rc = lib.visrep_cscore_transfer(_lib.ptr(bank), _lib.ptr(img1), _lib.ptr(img2), _lib.ptr(patch_idx), _lib.ptr(nkp),
-                                    _lib.ptr(lin_table(P, dev)), _lib.ptr(xy), n, kmax, P, C_, int(split), int(window), int(soft_eval),
+                                    _lib.ptr(lin), _lib.ptr(xy), n, kmax, P, C_, int(split), int(window), int(soft_eval),
                                     float(beta), float(stride), float(stride // 2), 0 if layout == "cp" else 1, _lib.stream_ptr())
     _lib.check(rc, "visrep_cscore_transfer")
     if order is not None:
@@ -167,7 +169,8 @@ def pck_counts(xy: torch.Tensor, kps1: torch.Tensor, kps2: torch.Tensor, thresho
     nkp = nkp.to(device=dev, dtype=torch.int32).contiguous()
     counts = torch.zeros(n, 4, dtype=torch.int32, device=dev)
     a = (C.c_float * 3)(*[float(np.float32(x)) for x in alphas])
-    rc = lib.visrep_pck_count(_lib.ptr(xy.contiguous()), _lib.ptr(kps1), _lib.ptr(kps2), _lib.ptr(thr), _lib.ptr(nkp), n, kmax, a,
+    xy = xy.contiguous()
+    rc = lib.visrep_pck_count(_lib.ptr(xy), _lib.ptr(kps1), _lib.ptr(kps2), _lib.ptr(thr), _lib.ptr(nkp), n, kmax, a,
                               _lib.ptr(counts), _lib.stream_ptr())
     _lib.check(rc, "visrep_pck_count")
     return counts

@@ -6,6 +6,12 @@ Why: the sweep's C leg moves every launch's maps to the rank that owns their cat
 threading.Barrier and the payload is copied between REAL device buffers with the REAL split tables - everything but the transport
 is the production code path (index tables, send / receive splits, bank rows, asynchronous completion order).
 
+The ranks are COOPERATIVE: a rank thread holds one run lock while it computes and gives it up only inside a collective, so between two
+collectives exactly one rank runs - like one process per rank, each rank's launches reach the (shared) stream as one uninterrupted
+sequence.  (Free-running threads on one stream are not what the production launcher does, and they break an assumption every torch
+program makes: a temporary whose pointer was handed to a launch may be freed before the launch is enqueued, because the same thread's
+next allocation can only be written by a LATER kernel of the same stream - another thread's allocation can slip in between.)
+
 Only the calls sweep.py / C_score.pck_train make are implemented: get_rank, get_world_size, barrier, all_to_all_single (sync or
 async_op), all_gather_object, all_reduce (SUM), all_gather.
 """
@@ -29,6 +35,7 @@ class ThreadDist:
         self.world = world
         self._tls = threading.local()
         self._bar = threading.Barrier(world)
+        self._run = threading.Lock()                  # held by the one rank that is computing
         self._slots = [None] * world
         self.bytes_on_fabric = 0                      # rows that changed rank, in bytes (all ranks)
         self._lock = threading.Lock()
@@ -46,15 +53,23 @@ class ThreadDist:
     def get_world_size(self):
         return self.world
 
+    def _wait(self):
+        """rendezvous: give the run lock up while waiting, take it back before computing again"""
+        self._run.release()
+        try:
+            self._bar.wait()
+        finally:
+            self._run.acquire()
+
     def barrier(self):
-        self._bar.wait()
+        self._wait()
 
     def _exchange(self, obj):
         """every rank deposits obj; returns the list of all ranks' objects (valid until the next collective)"""
         r = self.get_rank()
-        self._bar.wait()
+        self._wait()
         self._slots[r] = obj
-        self._bar.wait()
+        self._wait()
         return list(self._slots)
 
     def all_gather_object(self, out_list, obj):
@@ -107,11 +122,14 @@ class ThreadDist:
 
         def body(r):
             self._tls.rank = r
+            self._run.acquire()
             try:
                 res[r] = fn(r)
             except BaseException as e:                                  # noqa: BLE001 - surfaced below
                 err.append(e)
                 self._bar.abort()
+            finally:
+                self._run.release()
         th = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
         for t in th:
             t.start()
