@@ -28,7 +28,7 @@ import torch
 from .. import cscore_ops
 from .model_utils.projection_network import DummyAggregationNetwork
 from .utils.logger import get_logger, load_config, log_geo_stats, log_weighted_pcks, update_geo_stats, update_stats
-from .utils.utils_correspondence import calculate_keypoint_transformation, kpts_to_patch_idx  # noqa: F401 (API parity)
+from .utils.utils_correspondence import calculate_keypoint_transformation, kpts_to_patch_idx, kpts_to_patch_idx_batch  # noqa: F401 (API parity)
 from .utils.utils_dataset import get_dataset_info, load_eval_data
 from .utils.utils_geoware import AP10K_GEO_AWARE, SPAIR_GEO_AWARE, filtered_groups, geo_aware_points, renumber_used_points
 
@@ -131,7 +131,7 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     rank, world = (d.get_rank(), d.get_world_size()) if d else (0, 1)
     lo, hi = (N * rank) // world, (N * (rank + 1)) // world                   # contiguous pair block of this rank
     k1, k2 = kps[0::2], kps[1::2]
-    idx = np.stack([kpts_to_patch_idx(args, k1[i], P) for i in range(N)]).astype(np.int32) if N else np.zeros((0, K), np.int32)
+    idx = kpts_to_patch_idx_batch(args, k1, P).astype(np.int32) if N else np.zeros((0, K), np.int32)     # = kpts_to_patch_idx per pair, one numpy op
     nkp = torch.full((N,), K, dtype=torch.int32)
     sl = slice(lo, hi)
     _check_patch_idx(idx[sl], P)
@@ -174,8 +174,15 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
     cnt = cnt.cpu().numpy()
     pred = pred.cpu()
     used = torch.arange(K) if used_points is None else used_points.cpu()
-    out_results = [{"src_fn": files[2 * i], "trg_fn": files[2 * i + 1],
-                    "src_kpts_pred": _renumber_used_points(pred[i], used).numpy(), "resize_resolution": args.ANNO_SIZE}
+    # renumber_used_points (utils_geoware.py) for every pair at once: zeros [N, 30, 2] with the used columns filled, then one row view per pair
+    if _renumber_used_points is renumber_used_points:
+        full = torch.zeros(N, 30, pred.shape[2])
+        full[:, used] = pred
+        full = full.numpy()
+        preds30 = [full[i] for i in range(N)]
+    else:                                                                       # a patched-in renumbering (tests): keep the per-pair call
+        preds30 = [_renumber_used_points(pred[i], used).numpy() for i in range(N)]
+    out_results = [{"src_fn": files[2 * i], "trg_fn": files[2 * i + 1], "src_kpts_pred": preds30[i], "resize_resolution": args.ANNO_SIZE}
                    for i in range(N)]
     # per-image PCK: float32 mean of 0/1 hits per pair (pck_train.py:158), then float32 mean over pairs (:205-206)
     with np.errstate(invalid="ignore", divide="ignore"):

@@ -14,6 +14,16 @@ def kpts_to_patch_idx(args, img1_kps, num_patches):
     return num_patches * img1_y_patch + img1_x_patch
 
 
+def kpts_to_patch_idx_batch(args, kps, num_patches):
+    """kpts_to_patch_idx for a stack of key-point sets [N, K, 3] -> int32 [N, K] in ONE numpy expression: the same elementwise float32
+    arithmetic as N calls (python-float factor x float32 array, truncation to int32), without 12,234 tiny tensor -> numpy round trips per
+    category list (0.4 s of host time per setting of the sweep, tools/diag/c_leg_profile.py)."""
+    a = kps.cpu().numpy()
+    y_patch = (num_patches / args.ANNO_SIZE * a[:, :, 1]).astype(np.int32)
+    x_patch = (num_patches / args.ANNO_SIZE * a[:, :, 0]).astype(np.int32)
+    return num_patches * y_patch + x_patch
+
+
 def calculate_keypoint_transformation(args, img1_desc, img2_desc, img1_patch_idx, num_patches):
     """img*_desc: [1, P^2, C] patch descriptors (normalised or not — the kernel applies normalize_feats itself, and
     re-normalising unit rows is the identity to fp32 rounding).  Returns Tensor[K, 2] (x, y) on the descriptors' device.

@@ -272,7 +272,9 @@ class VitEngineF32:
         3.98 (4 run)."""
         per = self.lib.visrep_vit_f32_workspace_bytes(C.byref(self._cfg), 1)
         cap = max(1, min(128, self.max_ws_bytes // max(per, 1)))
-        return best_chunk(self.spec.tokens, self.spec.d, cap)
+        import os
+        forced = int(os.environ.get("VISREP_F32_CHUNK", "0"))              # A/B knob (tools/)
+        return min(forced, cap) if forced > 0 else best_chunk(self.spec.tokens, self.spec.d, cap)
 
     def workspace(self, B: int) -> torch.Tensor:
         ws = self._ws.get(B)

@@ -58,11 +58,12 @@ class Setting:
 # an equalised 120 would be 4.5 / 4.23: 5 run), 7.9 / 15.8 of Q|K / fc1; 256 images of a 257-token tower = 4.02 rounds (the 4-tile remainder goes
 # to the tail launch; an equalised 225 would be 3.53).  The reference-precision engine cuts a launch into chunks by the same rule
 # (engine.best_chunk: 113 images of a 577-token tower, 127 of a 257-token one - exactly two rounds, no tail launch).
+_B224 = int(os.environ.get("VISREP_SWEEP_B224", "256"))        # A/B knob (tools/): launch size of the 257-token towers (255 = whole tile rounds, no tail)
 SETTINGS = (
     Setting("CLIP336", "clip336", (CLIP336,), 336, 113),
-    Setting("CLIP224", "clip224", (CLIP224,), 224, 256),
-    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, 256),
-    Setting("DINOv2", "dino", (DINOV2,), 224, 256),
+    Setting("CLIP224", "clip224", (CLIP224,), 224, _B224),
+    Setting("OpenCLIP", "openclip", (OPENCLIP,), 224, _B224),
+    Setting("DINOv2", "dino", (DINOV2,), 224, _B224),
     Setting("SDim", "imsd", (IMSD,), 768, 32),
     Setting("SD1.5", "sd1.5", (SD15,), 768, 32),
     Setting("SDXL", "sdxl", (SDXL,), 512, 32),
@@ -70,7 +71,7 @@ SETTINGS = (
     Setting("SD3", "sd3", (SD3,), 512, 32),
     Setting("SD2.1", "sd2.1", (SD21,), 768, 32),
     Setting("SigLIP", "siglip", (SIGLIP,), 224, 256),
-    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, 256),
+    Setting("CLIP224+DINOv2", "clip224+dino", (CLIP224, DINOV2), 224, _B224),
     Setting("CLIP336+DINOv2", "clip336+dino", (CLIP336, DINOV2), 336, 113),
 )
 REFS = ("clip336", "clip224")
