@@ -78,7 +78,8 @@ enum {
     VISREP_ROUTE_ATTN = 7,           /* attn_fwd<ND> (head width 64 / 128 / 192) */
     VISREP_ROUTE_ATTN_WIDE = 8,      /* attn_fwd_wide (head width 512) */
     VISREP_ROUTE_ATTN_CLS = 9,       /* attn_fwd_cls (image-aligned CLS towers) */
-    VISREP_ROUTE_COUNT = 10
+    VISREP_ROUTE_CONV_HALO = 10,     /* conv3x3_halo: halo-resident 3x3 convolution with the input's GroupNorm + SiLU fused */
+    VISREP_ROUTE_COUNT = 11
 };
 int visrep_debug_routes(long* out, int reset);
 /* Matrix-pipe ceiling of THIS device under THIS process' conditions: `iters` bursts of 32 dependent-free v_mfma_f32_16x16x32_bf16 per wave,
@@ -403,6 +404,28 @@ int visrep_conv3x3_bf16_gn(const void* x, int B, int H, int W, int C, const void
 /* GroupNorm (+ SiLU) of x [B*HW, C] from such partial sums (HW % 64 == 0): finalize + apply.  workspace: >= B * groups * 8 bytes. */
 int visrep_groupnorm_from_partials(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups, float eps,
                                    int silu, const void* partial, void* workspace, void* stream);
+
+/* ---- 3x3 convolution (stride 1, padding 1) with the INPUT's GroupNorm (+ SiLU) fused into its operand path, for the VAE encoder's
+ * 128-channel layers (diffusers resnet.py ResnetBlock2D.forward: norm1 -> SiLU -> conv1 -> norm2 -> SiLU -> conv2 (+ shortcut); vae.py
+ * Encoder at 768^2 / 384^2).  A workgroup owns a 16 x 16 output tile: its 18 x 18 x 128 input halo is fetched ONCE, normalised in registers
+ * (gn_table[b, c] = (scale, shift) = (rstd gamma, beta - mean rstd gamma), then SiLU when silu != 0 - groupnorm_apply's arithmetic bit for
+ * bit; NULL = use x as it is) and kept in LDS; the nine taps are shifted views of it, only W streams.  No normalised copy of the tensor
+ * ever exists in HBM (the separate apply pass reads and re-writes 2 x 2.4 GB per layer at 768^2 x 16 images).  Results equal
+ * visrep_conv3x3_bf16 on the normalised tensor bit for bit (same K order, same MFMA chains).
+ * x [B H W, 128] bf16 channels-last; Wt [Cout, ldw >= 1152] with K order (ky, kx, c); out / resid [B H W, ldc]; epilogue BIAS | RESID.
+ * gn_partial (may be NULL): GroupNorm partial sums of the OUTPUT for the norm that follows, layout of visrep_conv3x3_bf16_gn
+ * (visrep_conv_gn_partial_bytes(B, H W, groups_out) bytes; slot = 64 pixels of a 16 x 4 patch; consumed by visrep_groupnorm_stats_from_partials
+ * / visrep_groupnorm_from_partials).  Supported: C = 128, Cout in {128, 256}, H and W multiples of 16 (visrep_conv3x3_halo_supported). */
+int visrep_conv3x3_halo_supported(int B, int H, int W, int C, int Cout);
+int visrep_conv3x3_bf16_halo(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
+                             int epilogue, const void* resid, const void* gn_table, int silu, void* gn_partial, int groups_out, void* stream);
+/* The statistics half of GroupNorm on its own: stats[b, g] = (mean, rstd) fp32 pairs [B, groups], from a read-only pass over x
+ * (visrep_groupnorm_stats; workspace of visrep_groupnorm_workspace_bytes) or from a producing convolution's partial sums
+ * (visrep_groupnorm_stats_from_partials, HW % 64 == 0) - and the per-(image, channel) (scale, shift) table the fused convolution
+ * consumes: table [B, C] float2 (visrep_groupnorm_table_from_stats). */
+int visrep_groupnorm_stats(const void* x, void* stats, int B, int HW, int C, int groups, float eps, void* workspace, void* stream);
+int visrep_groupnorm_stats_from_partials(const void* partial, void* stats, int B, int HW, int C, int groups, float eps, void* stream);
+int visrep_groupnorm_table_from_stats(const void* stats, const float* gamma, const float* beta, void* table, int B, int C, int groups, void* stream);
 
 /* activations.py GEGLU: y[m, f] = x[m, f] * gelu_erf(x[m, F + f]); x [M, >= 2F] bf16, y [M, >= F] bf16. */
 int visrep_geglu(const void* x, int ldx, void* y, int ldy, long M, int F, void* stream);

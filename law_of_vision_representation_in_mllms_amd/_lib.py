@@ -69,6 +69,11 @@ SIGNATURES = {
     "visrep_conv3x3_bf16_gn": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "visrep_groupnorm_from_partials": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "visrep_conv3x3_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "visrep_conv3x3_halo_supported": (_i, [_i, _i, _i, _i, _i]),
+    "visrep_conv3x3_bf16_halo": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "visrep_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "visrep_groupnorm_stats_from_partials": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "visrep_groupnorm_table_from_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "visrep_geglu": (_i, [_vp, _i, _vp, _i, _l, _i, _vp]),
     "visrep_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "visrep_nchw_to_tokens": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -156,7 +161,7 @@ def load(build_if_missing: bool = True):
         return lib
 
 
-ROUTES = ("gemm_256", "gemm_128", "gemm_tail", "splitk", "conv_256", "conv_128", "conv_128_gn", "attn", "attn_wide", "attn_cls")
+ROUTES = ("gemm_256", "gemm_128", "gemm_tail", "splitk", "conv_256", "conv_128", "conv_128_gn", "attn", "attn_wide", "attn_cls", "conv_halo")
 
 
 def routes(reset: bool = False) -> dict:

@@ -380,6 +380,33 @@ extern "C" int visrep_groupnorm(const void* x, const float* gamma, const float* 
     return launch_groupnorm_apply(x, stats, gamma, beta, y, B, HW, C, cpg, silu, st);
 }
 
+// The statistics half alone (the fused convolution conv_halo.hip applies the normalisation itself): stats[b, g] = (mean, rstd)
+extern "C" int visrep_groupnorm_stats(const void* x, void* stats_out, int B, int HW, int C, int groups, float eps, void* workspace, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm_stats: empty problem");
+    if (C % groups || C % 8 || ((C / groups) & 1)) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm_stats: C % groups, C % 8, even channels per group");
+    if (!x || !stats_out || !workspace) return visrep_set_error(VISREP_ERR_ARG, "groupnorm_stats: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int cpg = C / groups, npair = C / 2;
+    int W = 256;
+    if (npair <= 128) { W = 1; while (W < npair) W <<= 1; }
+    const int R = 256 / W, rows = gn_rows_per_block(B, HW), nblk = (HW + rows - 1) / rows;
+    float2* partial = (float2*)workspace + (size_t)B * groups;          // same workspace layout as visrep_groupnorm (its stats slot stays unused)
+    hipLaunchKernelGGL(groupnorm_stats, dim3(nblk, B), dim3(256), (size_t)R * npair * sizeof(float2), st, (const bf16_t*)x, partial, HW, C, cpg, rows, W);
+    const int BG = B * groups;
+    hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 3) / 4), dim3(256), 0, st, (const float2*)partial, (float2*)stats_out, BG, groups, nblk,
+                       1.0f / ((float)HW * (float)cpg), eps);
+    return launched("groupnorm_stats: launch failed");
+}
+
+extern "C" int visrep_groupnorm_stats_from_partials(const void* partial, void* stats_out, int B, int HW, int C, int groups, float eps, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups || HW % 64) return visrep_set_error(VISREP_ERR_SHAPE, "groupnorm_stats_from_partials: bad shape");
+    if (!partial || !stats_out) return visrep_set_error(VISREP_ERR_ARG, "groupnorm_stats_from_partials: null pointer");
+    const int cpg = C / groups, BG = B * groups;
+    hipLaunchKernelGGL(groupnorm_finalize, dim3((BG + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float2*)partial, (float2*)stats_out, BG, groups, HW / 64,
+                       1.0f / ((float)HW * (float)cpg), eps);
+    return launched("groupnorm_stats_from_partials: launch failed");
+}
+
 // GroupNorm whose per-(image, 64-row slot, group) partial sums came out of the producing convolution's epilogue (visrep_conv3x3_bf16_gn):
 // finalize + apply only - the tensor is not read for its statistics.  workspace: >= B * groups float2.
 extern "C" int visrep_groupnorm_from_partials(const void* x, const float* gamma, const float* beta, void* y, int B, int HW, int C, int groups, float eps,

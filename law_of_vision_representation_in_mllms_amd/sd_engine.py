@@ -102,6 +102,52 @@ def conv3x3(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, stri
     return out, Ho, Wo
 
 
+def conv_halo_supported(B: int, H: int, W: int, C: int, Cout: int) -> bool:
+    return bool(_lib.load().visrep_conv3x3_halo_supported(int(B), int(H), int(W), int(C), int(Cout)))
+
+
+def groupnorm_stats(x: torch.Tensor, B: int, groups: int, eps: float, partial: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(mean, rstd) per (image, group) of x [B*HW, C] as fp32 [B, groups, 2]: from the producing convolution's partial sums when given
+    (no pass over the tensor), else from the read-only statistics pass."""
+    lib = _lib.require_gpu()
+    M, C = x.shape
+    HW = M // B
+    stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+    if partial is not None:
+        _lib.check(lib.visrep_groupnorm_stats_from_partials(_lib.ptr(partial), _lib.ptr(stats), B, HW, C, groups, float(eps), _lib.stream_ptr()),
+                   "visrep_groupnorm_stats_from_partials")
+        return stats
+    ws = torch.empty(lib.visrep_groupnorm_workspace_bytes(B, HW, groups), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.visrep_groupnorm_stats(_lib.ptr(x), _lib.ptr(stats), B, HW, C, groups, float(eps), _lib.ptr(ws), _lib.stream_ptr()), "visrep_groupnorm_stats")
+    return stats
+
+
+def groupnorm_table(stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """(scale, shift) = (rstd gamma, beta - mean rstd gamma) per (image, channel): fp32 [B, C, 2] - what conv3x3_halo applies in registers."""
+    lib = _lib.require_gpu()
+    B, groups, _ = stats.shape
+    C = gamma.shape[0]
+    tab = torch.empty(B, C, 2, dtype=torch.float32, device=stats.device)
+    _lib.check(lib.visrep_groupnorm_table_from_stats(_lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(tab), B, C, groups, _lib.stream_ptr()),
+               "visrep_groupnorm_table_from_stats")
+    return tab
+
+
+def conv3x3_halo(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, epi: int = _lib.EPI_BIAS, resid=None,
+                 gn_table: Optional[torch.Tensor] = None, silu: bool = True, gn_groups: int = 0):
+    """3x3 convolution (stride 1, padding 1) of x [B*H*W, 128] with the input's GroupNorm (+ SiLU) applied inside the kernel from `gn_table`
+    (groupnorm_table; None = x is used as it is) - visrep_conv3x3_bf16_halo.  Returns out [B*H*W, Cout], plus the GroupNorm partial sums of the
+    output when gn_groups > 0 (for groupnorm_stats(partial=) / groupnorm_from_partials)."""
+    lib = _lib.require_gpu()
+    C, N = x.shape[1], w.shape[0]
+    out = torch.empty(B * H * W, N, dtype=torch.bfloat16, device=x.device)
+    partial = torch.empty(lib.visrep_conv_gn_partial_bytes(B, H * W, gn_groups), dtype=torch.uint8, device=x.device) if gn_groups else None
+    rc = lib.visrep_conv3x3_bf16_halo(_lib.ptr(x), B, H, W, C, _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(out), out.stride(0), N, epi,
+                                      _lib.ptr(resid), _lib.ptr(gn_table), int(silu), _lib.ptr(partial), int(gn_groups), _lib.stream_ptr())
+    _lib.check(rc, "visrep_conv3x3_bf16_halo")
+    return (out, partial) if gn_groups else out
+
+
 def geglu(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.require_gpu()
     M, F2 = x.shape
@@ -185,6 +231,7 @@ class SdEngine:
         self.implicit_conv = True
         self.vae_flash = os.environ.get("VISREP_VAE_FLASH", "1") != "0"      # 0: the materialised-score route (A/B, tools/)
         self.fuse_gn_stats = os.environ.get("VISREP_GN_FUSE", "1") != "0"    # 0: every GroupNorm reads its input twice (A/B, tools/)
+        self.conv_halo = os.environ.get("VISREP_CONV_HALO", "1") != "0"      # 0: the 128-channel layers keep apply pass + implicit-GEMM convolution (A/B, tools/)
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
 
@@ -397,17 +444,40 @@ class SdEngine:
             return groupnorm_from_partials(x, gamma, beta, B, groups, eps, silu, ent[0])
         return groupnorm(x, gamma, beta, B, groups, eps, silu)
 
+    def _halo_conv(self, x, B, H, W, norm, name, groups, eps, epi=_lib.EPI_BIAS, resid=None):
+        """GroupNorm(+SiLU) + 3x3 convolution of a 128-channel tensor in ONE kernel (conv3x3_halo): the statistics come from the producing
+        convolution's partial sums when x carries them (else one read-only pass), the normalisation is applied in registers on the way into
+        LDS, and the output leaves with the partial sums of ITS GroupNorm attached.  None when the shape is not the kernel's."""
+        lin = self.P[name]
+        if not (self.conv_halo and self.implicit_conv and lin.w.shape[0] == lin.n and conv_halo_supported(B, H, W, x.shape[1], lin.n)):
+            return None
+        ent = getattr(x, "_visrep_gn", None)
+        stats = groupnorm_stats(x, B, groups, eps, partial=ent[0] if ent is not None and ent[1] == groups else None)
+        tab = groupnorm_table(stats, *norm)
+        cpg = lin.n // groups
+        emit = groups if (cpg in (4, 8, 16) and self.fuse_gn_stats) else 0
+        res = conv3x3_halo(x, B, H, W, lin.w, lin.b, epi, resid, tab, True, emit)
+        if emit:
+            out, partial = res
+            out._visrep_gn = (partial, groups)
+            return out
+        return res
+
     def _resnet(self, x, B, H, W, p, groups, eps):
         g1, b1 = self.P[f"{p}.norm1"]
-        h = self._gn(x, g1, b1, B, groups, eps, True)
-        h, _, _ = self._conv(h, B, H, W, f"{p}.conv1", gn=groups)
+        h = self._halo_conv(x, B, H, W, (g1, b1), f"{p}.conv1", groups, eps)          # VAE 128-channel layers: norm1 + SiLU + conv1 fused
+        if h is None:
+            h = self._gn(x, g1, b1, B, groups, eps, True)
+            h, _, _ = self._conv(h, B, H, W, f"{p}.conv1", gn=groups)
         g2, b2 = self.P[f"{p}.norm2"]
-        h = self._gn(h, g2, b2, B, groups, eps, True)
         sc = x
         if f"{p}.conv_shortcut" in self.P:
             s = self.P[f"{p}.conv_shortcut"]
             sc = gemm(x, s.w, s.b)
-        out, _, _ = self._conv(h, B, H, W, f"{p}.conv2", epi=_lib.EPI_RESID, resid=sc, gn=groups)
+        out = self._halo_conv(h, B, H, W, (g2, b2), f"{p}.conv2", groups, eps, epi=_lib.EPI_RESID, resid=sc)
+        if out is None:
+            h = self._gn(h, g2, b2, B, groups, eps, True)
+            out, _, _ = self._conv(h, B, H, W, f"{p}.conv2", epi=_lib.EPI_RESID, resid=sc, gn=groups)
         return out
 
     def _transformer(self, x, B, HW, p, groups):

@@ -188,6 +188,75 @@ def test_conv3x3_emits_groupnorm_partials(B, H, W, Ci, Co, stride, pad_mode):
     assert rel_err(got, tokens(ref)) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,Co,resid,exact", [(4, 128, 128, 128, False, True), (4, 128, 128, 128, True, True), (2, 128, 128, 256, True, True),
+                                                  (2, 32, 48, 128, True, False), (1, 16, 64, 256, False, False), (3, 16, 16, 128, False, False)])
+def test_conv3x3_halo_equals_groupnorm_apply_plus_implicit_gemm(B, H, W, Co, resid, exact):
+    """conv3x3_halo (GroupNorm + SiLU of the input fused into a halo-resident 3x3 convolution, csrc/conv_halo.hip) against the two launches it
+    replaces - groupnorm (statistics + apply pass) and the implicit-GEMM convolution.  Same normalisation arithmetic, same K order, same MFMA
+    chains: BIT-IDENTICAL outputs where the reference convolution is not split along K (`exact`: enough tiles to fill the chip); the small
+    shapes (image borders on every side of every tile, one-tile images) take the reference through split-K, whose fp32 summation order
+    differs - compared at bf16 rounding.  The output's GroupNorm partial sums feed groupnorm_from_partials like the 128x128 kernel's."""
+    g = torch.Generator().manual_seed(B * 1000 + H + W + Co)
+    C = 128
+    x = (torch.randn(B * H * W, C, generator=g) * (1 + torch.rand(1, C, generator=g)) + torch.randn(1, C, generator=g)).to(torch.bfloat16).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV), (0.2 * torch.randn(C, generator=g)).to(DEV)
+    w = (torch.randn(Co, 9 * C, generator=g) * 0.03).to(torch.bfloat16).to(DEV)
+    bias = (0.1 * torch.randn(Co, generator=g)).to(DEV)
+    res = (torch.randn(B * H * W, Co, generator=g)).to(torch.bfloat16).to(DEV) if resid else None
+    epi = _lib.EPI_RESID if resid else _lib.EPI_BIAS
+    assert SE.conv_halo_supported(B, H, W, C, Co) and not SE.conv_halo_supported(B, H + 8, W, C, Co) and not SE.conv_halo_supported(B, H, W, 256, Co)
+    h = SE.groupnorm(x, gamma, beta, B, 32, 1e-6, True)
+    want, _, _ = SE.conv3x3(h, B, H, W, w, bias, 1, 0, False, epi, res)
+    stats = SE.groupnorm_stats(x, B, 32, 1e-6)
+    tab = SE.groupnorm_table(stats, gamma, beta)
+    _lib.routes(reset=True)
+    got, part = SE.conv3x3_halo(x, B, H, W, w, bias, epi, res, tab, True, 32)
+    assert _lib.routes()["conv_halo"] == 1
+    if exact:
+        assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    else:
+        assert rel_err(got, want) < 2e-3 and (got.float() - want.float()).abs().max().item() <= 2.0 ** -6 * want.float().abs().max().item()
+    # no GroupNorm in front (gn_table = None): the plain convolution
+    plain_want, _, _ = SE.conv3x3(x, B, H, W, w, bias, 1, 0, False, epi, res)
+    plain = SE.conv3x3_halo(x, B, H, W, w, bias, epi, res, None, False, 0)
+    assert torch.equal(plain, plain_want) if exact else rel_err(plain, plain_want) < 2e-3
+    # the output's partial sums: the following GroupNorm without a statistics pass
+    g2, b2 = (1 + 0.3 * torch.randn(Co, generator=g)).to(DEV), (0.2 * torch.randn(Co, generator=g)).to(DEV)
+    a = SE.groupnorm_from_partials(got, g2, b2, B, 32, 1e-6, True, part)
+    b_ = SE.groupnorm(got, g2, b2, B, 32, 1e-6, True)
+    assert rel_err(a, b_) < 1e-3
+    st_a, st_b = SE.groupnorm_stats(got, B, 32, 1e-6, partial=part), SE.groupnorm_stats(got, B, 32, 1e-6)
+    # partial sums are over the fp32 (unrounded) outputs, the statistics pass reads the bf16 tensor: equal to bf16 rounding of the inputs
+    assert (st_a[..., 0] - st_b[..., 0]).abs().max().item() < 2e-3 and ((st_a[..., 1] - st_b[..., 1]).abs() / st_b[..., 1]).max().item() < 2e-3
+
+
+def test_vae_encoder_with_and_without_the_fused_halo_convolution(monkeypatch):
+    """SdEngine.vae_moments with the 128-channel layers on conv3x3_halo against the same engine with VISREP_CONV_HALO=0 (apply pass +
+    implicit-GEMM convolution): the same arithmetic up to the summation order of the GroupNorm statistics (partial sums per 16 x 4 patch
+    instead of per 64 raster pixels), on a 128-px image of the real SD1.5 VAE widths."""
+    sp = SW.SD_SPECS['runwayml/stable-diffusion-v1-5']
+    wv = SW.synthetic_vae(sp.vae, 22)
+    wu = SW.synthetic_unet(SW.tiny_sd_spec().unet, 21, n_up_blocks=1)
+    spec = SW.SdSpec("vae-halo", unet=SW.tiny_sd_spec().unet, vae=sp.vae, sched=sp.sched, text_len=sp.text_len)
+    img = torch.from_numpy(np.random.RandomState(8).uniform(-1, 1, (2, 3, 128, 128)).astype(np.float32)).to(DEV)
+    monkeypatch.setenv("VISREP_CONV_HALO", "1")
+    on = SE.SdEngine(spec, wu, wv, DEV, up_ft_index=0)
+    _lib.routes(reset=True)
+    m_on, h, w = on.vae_moments(img)
+    r = _lib.routes(reset=True)
+    assert r["conv_halo"] == 5, r                      # down block 0: 2 resnets x 2 convolutions at 128 channels, + conv1 of down block 1 (128 -> 256)
+    monkeypatch.setenv("VISREP_CONV_HALO", "0")
+    off = SE.SdEngine(spec, wu, wv, DEV, up_ft_index=0)
+    m_off, _, _ = off.vae_moments(img)
+    assert _lib.routes(reset=True)["conv_halo"] == 0
+    Z = sp.vae.latent_channels
+    e = rel_err(m_on[:, : 2 * Z], m_off[:, : 2 * Z])
+    m32, l32 = OD.vae_encode_moments(sp.vae, wv, img.cpu())
+    mean_on = untokens(m_on[:, :Z], 2, h, w).cpu()
+    print(f"VAE moments, halo on vs off: rel {e:.3e}; halo on vs fp32 oracle (mean): {rel_err(mean_on, m32):.3e}")
+    assert e < 2e-2 and rel_err(mean_on, m32) < 3e-2
+
+
 def test_conv3x3_gn_rejects_unsupported_shapes():
     x = torch.zeros(2 * 24 * 24, 64, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(320, 576, dtype=torch.bfloat16, device=DEV)
