@@ -22,6 +22,13 @@
 #include "gemm_epilogue.h"
 #include "visrep_internal.h"
 
+// 1: fetch and normalise the NEXT tile's halo under this tile's last K-tiles (registers -> LDS behind the K loop's closing barrier).  Built and
+// measured in round 5: the 44 registers of the staged halo on top of 64 accumulators + double-buffered fragments spill (45 registers, reloads
+// inside the K loop with the vmcnt(0) the compiler puts behind them) - 3.89 ms against 2.88 ms for the simple order at 768^2 x 16; kept as a knob.
+#ifndef HALO_PREFETCH
+#define HALO_PREFETCH 0
+#endif
+
 namespace {
 
 constexpr int HT = 16, HP = HT + 2, HPIX = HP * HP, HC = 128;
@@ -46,9 +53,9 @@ VR_DEV unsigned lds_off(const void* p) { return (unsigned)(uintptr_t)(const __at
 
 // fragment reads as ONE asm statement each (the compiler must not see LDS reads next to in-flight LDS-DMA: it would drain the W ring with
 // a vmcnt(0) per K-tile - gemm_bf16_v5.hip); A: four pixel rows of the tile (4608 B apart), W: NJ 16-row blocks (2048 B apart)
-VR_DEV void issue_a4(bf16x8 (&a)[4], unsigned addr) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4608\n\tds_read_b128 %2, %4 offset:9216\n\tds_read_b128 %3, %4 offset:13824"
-                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "v"(addr));
+template <int OFF> VR_DEV void issue_a4(bf16x8 (&a)[4], unsigned addr) {      // OFF = ky * HROW: the tap's row shift rides in the immediate offsets
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "v"(addr), "n"(OFF), "n"(OFF + 4608), "n"(OFF + 9216), "n"(OFF + 13824));
 }
 VR_DEV void issue_w4(bf16x8 (&w)[4], unsigned addr) {
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
@@ -65,6 +72,14 @@ template <int NJ> VR_DEV void wait_frags(bf16x8 (&a)[4], bf16x8 (&w)[NJ]) {
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]),
                      "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+}
+// counted form: all but the newest N LDS reads of this wave have landed; the named fragments may be consumed behind it
+template <int NJ, int N> VR_DEV void wait_frags_n(bf16x8 (&a)[4], bf16x8 (&w)[NJ]) {
+    if constexpr (NJ == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]),
+                     "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : "n"(N));
 }
 template <int N> VR_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 VR_DEV void wg_barrier() {
@@ -85,122 +100,200 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
     char* const wring = smem + HALO_BYTES;
 
     // ---- W staging: piece j covers chunk c = j * 512 + tid: row c >> 3, physical slot c & 7 <- logical slot (c & 7) ^ ((row >> 1) & 7)
-    const bf16_t* wsrc[P];
+    unsigned wofs[P];                                            // element offset of this lane's chunk inside W (32 bits: scalar base + vector offset addressing)
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int c = j * 512 + tid, row = c >> 3;
-        wsrc[j] = p.w + (size_t)row * p.ldw + ((((c & 7) ^ ((row >> 1) & 7))) << 3);
+        wofs[j] = (unsigned)row * (unsigned)p.ldw + (unsigned)((((c & 7) ^ ((row >> 1) & 7))) << 3);
     }
-    int g_issue = 0, kt_issue = 0;                               // stream index / K-tile of the next W tile to issue
-    auto issue_w = [&]() {
+    int g_issue = 0;                                             // stream index of the next W tile to issue
+    auto issue_w = [&](int kt_issue) {                           // kt_issue: compile-time at every call site (K offset = an immediate)
         char* dst = wring + (g_issue % NW) * WT + wave * 1024;
-        const int ko = kt_issue * 64;
 #pragma unroll
-        for (int j = 0; j < P; ++j) glds16(wsrc[j] + ko, dst + j * 8192);
+        for (int j = 0; j < P; ++j) glds16(p.w + (wofs[j] + (unsigned)(kt_issue * 64)), dst + j * 8192);
         ++g_issue;
-        kt_issue = kt_issue == NKT - 1 ? 0 : kt_issue + 1;
     };
 
     // ---- fragment addresses.  A: lane (fr, hg) reads pixel (row, hx = fr + kx), chunk cu + hg (cu = 8 h + 4 kk): slot (cu ^ (f & 12)) | (hg ^ (f & 3))
-    unsigned abase[3], ahi[3];
+    // twelve per-lane addresses cover every (kx, channel quarter); ky and the accumulator row i are immediate offsets of the reads
+    unsigned aaddr[3][4];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int hx = fr + kx, f = halo_swz(hx);
-        abase[kx] = lds_off(halo) + (unsigned)(wm * 4 * HROW + hx * 256 + ((hg ^ (f & 3)) << 4));
-        ahi[kx] = (unsigned)((f & 12) << 4);
+        const unsigned ab = lds_off(halo) + (unsigned)(wm * 4 * HROW + hx * 256 + ((hg ^ (f & 3)) << 4)), ah = (unsigned)((f & 12) << 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) aaddr[kx][q] = ab + ((unsigned)(q << 6) ^ ah);       // q = 2 h + kk: chunk base 4 q
     }
     // W: row wn * COUT / 2 + 16 j + fr, logical slot 4 kk + hg -> physical ((4 kk) ^ (s & 4)) | (hg ^ (s & 3)), s = (fr >> 1) & 7
     const int s3 = (fr >> 1) & 7;
     const unsigned wfrag = (unsigned)((wn * (COUT / 2) + fr) * 128 + ((hg ^ (s3 & 3)) << 4)), whi = (unsigned)((s3 & 4) << 4);
     const unsigned wring_off = lds_off(wring);
+    const unsigned wadr0 = wring_off + wfrag + (0u ^ whi), wadr1 = wring_off + wfrag + (64u ^ whi);      // k-step 0 / 1 of slot 0
 
     // ---- halo fill: task q = it * 512 + tid -> pixel q >> 4, chunk q & 15 = tid & 15 (fixed per thread: its (scale, shift) octet is loaded once per tile)
     const int chunk = tid & 15;
 
     // prologue of the W stream
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue_w();
+    for (int d = 0; d < D; ++d) issue_w(d);
     int g = 0;                                                   // stream index of the K-tile being consumed
 
     const int G = gridDim.x;
     const int lid = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);      // blocks of one XCD (b % 8) walk neighbouring tiles: shared halo rows in L2
-    for (int t = lid; t < p.ntiles; t += ((G + 7) >> 3) * 8) {
-        const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;
-        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * HT, x0 = tx * HT;
-        // ------------------------------------------------------------ halo
-        float sc[8], sh[8];
+    const int tstride = ((G + 7) >> 3) * 8;
+    constexpr int NIT = (HPIX * 16 + 511) / 512;                // 11 sixteen-byte tasks per thread and halo
+    // ---- the halo of a tile in three steps, so that the NEXT tile's halo can be fetched and normalised under this tile's MFMAs (PREFETCH, the
+    // Cout = 128 variant): load (global -> registers), transform (GroupNorm + SiLU in registers), store (registers -> LDS, after the barrier
+    // that ends the readers of the current halo).  sc / sh always belong to the halo that is transformed next.
+    constexpr bool PREFETCH = HALO_PREFETCH && NJ == 4;
+    float sc[8], sh[8];
+    u32x4 raw[NIT];
+    unsigned inmask = 0;                                         // bit it: task it lies inside the image (padding pixels stay zero)
+    auto load_tab = [&](int b) {
         if (p.gn_tab) {
             const float4* tb = reinterpret_cast<const float4*>(p.gn_tab + (size_t)b * HC + chunk * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float4 v = tb[e]; sc[2 * e] = v.x; sh[2 * e] = v.y; sc[2 * e + 1] = v.z; sh[2 * e + 1] = v.w; }
         }
-        __syncthreads();                                         // every wave is done reading the previous tile's halo
-        constexpr int NIT = (HPIX * 16 + 511) / 512;            // 11
-        u32x4 raw[NIT];
-        bool inside[NIT];
+    };
+    auto halo_load = [&](int t) {                                // branch-free: a task outside the image loads a clamped (valid) address and is zeroed
+        const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;    // by the transform - a divergent `if (inside) load` costs a vmcnt(0) per task
+        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * HT, x0 = tx * HT;
+        const bf16_t* img = p.x + (size_t)b * p.H * p.W * HC + chunk * 8;
+        inmask = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int q = it * 512 + tid, pix = q >> 4;
             const int hy = pix / HP, hx = pix - hy * HP;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            inside[it] = pix < HPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            raw[it] = u32x4{0u, 0u, 0u, 0u};
-            if (inside[it]) raw[it] = *reinterpret_cast<const u32x4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * HC + chunk * 8);
+            const bool in = pix < HPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            inmask |= (unsigned)in << it;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            raw[it] = *reinterpret_cast<const u32x4*>(img + (size_t)(cy * p.W + cx) * HC);
         }
+    };
+    auto halo_xform = [&](auto IT) __attribute__((always_inline)) {       // groupnorm_apply_rows' arithmetic, bit for bit; padding pixels become zeros
+        constexpr int it = decltype(IT)::value;
+        const bool in = (inmask >> it) & 1u;
+        u32x4 o4 = raw[it];
+        if (p.gn_tab) {                                          // uniform
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(raw[it][e]); v[2 * e + 1] = bf_hi(raw[it][e]); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = __builtin_fmaf(v[e], sc[e], sh[e]);
+                if (p.silu) o = o * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o * -1.4426950408889634f));
+                v[e] = o;
+            }
+            o4 = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        }
+        raw[it] = u32x4{in ? o4[0] : 0u, in ? o4[1] : 0u, in ? o4[2] : 0u, in ? o4[3] : 0u};
+    };
+    auto halo_store = [&]() {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int q = it * 512 + tid, pix = q >> 4;
             if (pix >= HPIX) continue;
-            const int hy = pix / HP, hx = pix - hy * HP;
-            u32x4 v4 = raw[it];
-            if (p.gn_tab && inside[it]) {                        // groupnorm_apply_rows' arithmetic, bit for bit; padding pixels stay zero
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(v4[e]); v[2 * e + 1] = bf_hi(v4[e]); }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float o = __builtin_fmaf(v[e], sc[e], sh[e]);
-                    if (p.silu) o = o * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o * -1.4426950408889634f));
-                    v[e] = o;
-                }
-                v4 = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-            }
-            *reinterpret_cast<u32x4*>(halo + pix * 256 + ((chunk ^ halo_swz(hx)) << 4)) = v4;
+            const int hx = pix - (pix / HP) * HP;
+            *reinterpret_cast<u32x4*>(halo + pix * 256 + ((chunk ^ halo_swz(hx)) << 4)) = raw[it];
         }
-        __syncthreads();
+    };
+    bool staged = false;                                         // raw[] holds this tile's halo, normalised, waiting for its LDS store
+    for (int t = lid; t < p.ntiles; t += tstride) {
+        const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;
+        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * HT, x0 = tx * HT;
+        // ------------------------------------------------------------ halo
+        if (!staged) {                                           // first tile of the block (or no prefetch): fetch and normalise here
+            halo_load(t);                                        // eleven 16-byte loads in flight, then the (scale, shift) octet behind them
+            load_tab(b);
+            static_for<NIT>(halo_xform);
+            __syncthreads();                                     // every wave is done reading the previous tile's halo
+            halo_store();
+        }
+        __syncthreads();                                         // the halo is in LDS (prefetched tiles: stored behind the previous K loop's closing barrier)
+        const int tn = t + tstride;
+        const bool has_next = PREFETCH && tn < p.ntiles;
 
-        // ------------------------------------------------------------ K loop: 9 taps x 2 channel halves, W through the ring
+        // ------------------------------------------------------------ K loop: 9 taps x 2 channel halves, W through the ring.  Fully unrolled (the tap
+        // geometry is compile-time), fragments double-buffered: the reads of k-step kk + 1 are in flight under the MFMAs of k-step kk, and the A
+        // fragments of the NEXT K-tile (the halo never changes during a tile: no barrier needed) under the MFMAs of this tile's second k-step.
+        // LDS returns in order, so the waits are counted (lgkmcnt(n) = all but the newest n reads have landed).
         f32x4 acc[4][NJ];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int tap = 0, kyo = 0, kx = 0;                            // kyo = ky * HROW
-        for (int kt = 0; kt < NKT; kt += 2) {
+        constexpr bool PIPE = NJ == 4;                           // double-buffered fragments (the Cout = 256 variant has no registers for a second set)
+        bf16x8 xa[PIPE ? 2 : 1][4], xw[PIPE ? 2 : 1][NJ];
+        // the W source offsets are re-"defined" once per tile: otherwise hipcc hoists the 18 x P 64-bit source pointers of the unrolled K loop out
+        // of the tile loop and spills them (72 registers); two 64-bit adds per K-tile are cheaper than their reloads
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                wait_vm<P * (D - 1)>();                          // this wave's pieces of W(g) have landed (newer tiles' pieces may be in flight)
-                wg_barrier();                                    // ... everybody's have, and everybody is done with the slot W(g + D) will take
-                issue_w();
-                const unsigned ws = wring_off + (unsigned)((g % NW) * WT);
-                const unsigned ab = abase[0] * (kx == 0) + abase[1] * (kx == 1) + abase[2] * (kx == 2) + (unsigned)kyo;
-                const unsigned ah = ahi[0] * (kx == 0) + ahi[1] * (kx == 1) + ahi[2] * (kx == 2);
+        for (int j = 0; j < P; ++j) asm volatile("" : "+v"(wofs[j]));
+        if constexpr (PIPE) issue_a4<0>(xa[0], aaddr[0][0]);
+        static_for<NKT>([&](auto KT) __attribute__((always_inline)) {
+            constexpr int kt = decltype(KT)::value, tp = kt >> 1, h = kt & 1, ky = tp / 3, kx = tp - 3 * ky;
+            // this wave's pieces of W(g) have landed; newer tiles' pieces - and, for three K-tiles, the next halo's loads issued behind W(15) - may fly
+            if constexpr (PREFETCH && kt >= 13 && kt <= 15) { if (has_next) wait_vm<P * (D - 1) + NIT>(); else wait_vm<P * (D - 1)>(); }
+            else wait_vm<P * (D - 1)>();
+            wg_barrier();                                        // ... everybody's have, and everybody is done with the slot W(g + D) will take
+            issue_w((kt + D) % NKT);
+            if constexpr (PREFETCH && kt == 12) {                // the next tile's halo: 11 loads per lane, consumed four K-tiles later
+                __builtin_amdgcn_sched_barrier(0);               // pinned: the counted waits below assume exactly this position in the VMEM queue
+                if (has_next) halo_load(tn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const unsigned so = (unsigned)((g % NW) * WT);
+            if constexpr (PIPE) {
+                issue_w4(xw[0], wadr0 + so);
+                issue_a4<ky * HROW>(xa[1], aaddr[kx][2 * h + 1]);
+                issue_w4(xw[1], wadr1 + so);
+                wait_frags_n<NJ, 4 + NJ>(xa[0], xw[0]);          // A(kt, 0) and W(kt, 0) are in; A(kt, 1) / W(kt, 1) still fly
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[0][j], xa[0][i], acc[i][j], 0, 0, 0);
+                if constexpr (kt + 1 < NKT) {
+                    __builtin_amdgcn_sched_barrier(0);           // the reload of xa[0] must stay behind the MFMAs that read it
+                    constexpr int kn = kt + 1, tpn = kn >> 1, hn = kn & 1, kyn = tpn / 3, kxn = tpn - 3 * kyn;
+                    issue_a4<kyn * HROW>(xa[0], aaddr[kxn][2 * hn]);
+                    wait_frags_n<NJ, 4>(xa[1], xw[1]);
+                } else {
+                    wait_frags_n<NJ, 0>(xa[1], xw[1]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[1][j], xa[1][i], acc[i][j], 0, 0, 0);
+            } else {                                             // 128 accumulators: one fragment set, read - wait - multiply per k-step
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 xa[4], xw[NJ];
-                    if constexpr (NJ == 4) issue_w4(xw, ws + wfrag + ((unsigned)(kk * 64) ^ whi));
-                    else issue_w8(xw, ws + wfrag + ((unsigned)(kk * 64) ^ whi));
-                    issue_a4(xa, ab + ((unsigned)((h * 8 + kk * 4) << 4) ^ ah));
-                    wait_frags<NJ>(xa, xw);
+                    issue_w8(xw[0], (kk ? wadr1 : wadr0) + so);
+                    issue_a4<ky * HROW>(xa[0], aaddr[kx][2 * h + kk]);
+                    wait_frags_n<NJ, 0>(xa[0], xw[0]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[j], xa[i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw[0][j], xa[0][i], acc[i][j], 0, 0, 0);
                 }
-                ++g;
             }
-            ++tap;
-            if (++kx == 3) { kx = 0; kyo += HROW; }
+            if constexpr (PREFETCH && kt >= 16) {               // normalise the prefetched halo in registers, under this K-tile's MFMAs
+                if (has_next) {
+                    if constexpr (kt == 16) {
+                        const int bn = tn / p.tiles_per_img;
+                        if (bn != b) load_tab(bn);               // the next tile belongs to the next image: its (scale, shift) octet
+                        static_for<6>(halo_xform);
+                    } else {
+                        static_for<NIT - 6>([&](auto I) __attribute__((always_inline)) { halo_xform(std::integral_constant<int, decltype(I)::value + 6>{}); });
+                    }
+                }
+            }
+            ++g;
+        });
+        if constexpr (PREFETCH) {
+            __syncthreads();                                     // every wave is done reading this tile's halo ...
+            if (has_next) halo_store();                          // ... the next one goes in; it becomes visible at the barrier that opens the next tile
+            staged = has_next;
         }
 
         // ------------------------------------------------------------ epilogue: bias (+ residual) -> bf16, 16-byte stores; GroupNorm partials of the output

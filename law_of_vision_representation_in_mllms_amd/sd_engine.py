@@ -232,6 +232,9 @@ class SdEngine:
         self.vae_flash = os.environ.get("VISREP_VAE_FLASH", "1") != "0"      # 0: the materialised-score route (A/B, tools/)
         self.fuse_gn_stats = os.environ.get("VISREP_GN_FUSE", "1") != "0"    # 0: every GroupNorm reads its input twice (A/B, tools/)
         self.conv_halo = os.environ.get("VISREP_CONV_HALO", "1") != "0"      # 0: the 128-channel layers keep apply pass + implicit-GEMM convolution (A/B, tools/)
+        # 128 -> 256 layers (one per VAE): the kernel's Cout = 256 variant is correct but measured SLOWER than the persistent 256x256 convolution
+        # + apply pass (1.80 against 1.48 ms at 384^2 x 16: 128 accumulators leave no registers for double-buffered fragments) - opt-in only
+        self.conv_halo_256 = os.environ.get("VISREP_CONV_HALO_256", "0") == "1"
         self._graphs = {}
         self._ac = spec.sched.alphas_cumprod()
 
@@ -449,7 +452,8 @@ class SdEngine:
         convolution's partial sums when x carries them (else one read-only pass), the normalisation is applied in registers on the way into
         LDS, and the output leaves with the partial sums of ITS GroupNorm attached.  None when the shape is not the kernel's."""
         lin = self.P[name]
-        if not (self.conv_halo and self.implicit_conv and lin.w.shape[0] == lin.n and conv_halo_supported(B, H, W, x.shape[1], lin.n)):
+        if not (self.conv_halo and self.implicit_conv and lin.w.shape[0] == lin.n and (lin.n == 128 or self.conv_halo_256)
+                and conv_halo_supported(B, H, W, x.shape[1], lin.n)):
             return None
         ent = getattr(x, "_visrep_gn", None)
         stats = groupnorm_stats(x, B, groups, eps, partial=ent[0] if ent is not None and ent[1] == groups else None)

@@ -244,7 +244,7 @@ def test_vae_encoder_with_and_without_the_fused_halo_convolution(monkeypatch):
     _lib.routes(reset=True)
     m_on, h, w = on.vae_moments(img)
     r = _lib.routes(reset=True)
-    assert r["conv_halo"] == 5, r                      # down block 0: 2 resnets x 2 convolutions at 128 channels, + conv1 of down block 1 (128 -> 256)
+    assert r["conv_halo"] == 4, r                      # down block 0: 2 resnets x 2 convolutions at 128 channels (128 -> 256 stays on the 256x256 kernel)
     monkeypatch.setenv("VISREP_CONV_HALO", "0")
     off = SE.SdEngine(spec, wu, wv, DEV, up_ft_index=0)
     m_off, _, _ = off.vae_moments(img)
