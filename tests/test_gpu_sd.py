@@ -776,7 +776,8 @@ def test_sd15_768px_sweep_launch_shape_parity_and_routes(monkeypatch):
     """SD1.5 at the shape the sweep LAUNCHES - 768-px images, 16 per launch - against the fp32 CPU oracle on one of the
     images (the other 15 are arbitrary), bounded by the oracle's own bf16 run; and the routes the dispatcher picks only at this shape are
     asserted, not assumed: the VAE's 256- / 512-channel 3x3 convolutions in the persistent 256x256 kernel (`conv_256`), its 128-channel
-    768^2 / 384^2 layers in the 128x128 kernel with GroupNorm partial sums from the epilogue (`conv_128_gn`), the 12^2 / 24^2 UNet
+    768^2 layers in the fused GroupNorm + convolution kernel (`conv_halo`), the stride-2 downsample in the 128x128 kernel with GroupNorm
+    partial sums from the epilogue (`conv_128_gn`), the 12^2 / 24^2 UNet
     convolutions through deterministic split-K, the VAE's mid-block attention in the wide-head flash kernel, head / tail splits with a row
     offset (`gemm_tail`).  The eager forward is measured (a HIP-graph replay does not pass the dispatcher); the replayed graph must give
     the same features bit for bit."""
@@ -804,7 +805,8 @@ def test_sd15_768px_sweep_launch_shape_parity_and_routes(monkeypatch):
     assert got.shape == (NB, 576, 1280) and torch.isfinite(got.float()).all()
     # what the sweep's launch shape is tuned for (profiles/round4_sd15_kernel_stats.md): asserted per route
     assert r["conv_256"] >= 16, r            # VAE 256- / 512-channel layers at 384^2 / 192^2 / 96^2: whole rounds of 256x256 tiles
-    assert r["conv_128_gn"] >= 4, r          # VAE 128-channel layers at 768^2 (+ the 384^2 downsample): statistics from the epilogue
+    assert r["conv_halo"] == 4, r            # VAE 128-channel layers at 768^2: GroupNorm + SiLU + convolution in one kernel (conv3x3_halo)
+    assert r["conv_128_gn"] >= 1, r          # the stride-2 128-channel downsample: 128x128 kernel, statistics from the epilogue
     assert r["attn_wide"] == 1, r            # the VAE's 512-wide single head: one flash launch for the batch
     assert r["splitk"] >= 4, r               # 12^2 / 24^2 UNet convolutions and projections: few tiles, deep K
     assert r["gemm_tail"] + r["conv_256"] + r["gemm_256"] > 0 and r["attn"] >= 8, r
