@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-flt = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"gemm_bf16|attn_fwd|ascore|cscore|layernorm|splitk|ln_stats")
+flt = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"gemm_bf16|attn_fwd|ascore|cscore|layernorm|splitk|ln_stats|conv3x3_halo|groupnorm")
 
 
 def short(name):
