@@ -423,7 +423,7 @@ def main():
         # every `frac` on this line divides by - `frac_of_practical_roof` reads the same numbers against what the pipe can actually sustain.
         practical = None
         try:
-            sink = torch.zeros(4, dtype=torch.float32, device=dev)
+            sink = torch.zeros(4, dtype=torch.int64, device=dev)   # [1] shader-clock cycles, [2] 100-MHz ticks of block 0's loop
             flop = C.c_double(0.0)
             best = 0.0
             for _ in range(2):                                   # ~15 ms each: long enough for the clock to settle under this load
@@ -435,7 +435,10 @@ def main():
                 e1.record()
                 torch.cuda.synchronize(dev)
                 best = max(best, flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+            cyc, ticks = sink[1].item(), sink[2].item()
             practical = {"tflops": round(best, 1), "frac_of_nominal": round(best / PEAK_BF16_TFLOPS, 4),
+                         "clock_ghz": (round(cyc / (ticks * 10.0), 3) if ticks > 0 else None),
+                         "clock_how": "s_memtime cycles / s_memrealtime (100 MHz) ticks of block 0's MFMA loop in the last launch: the shader clock the power management held under this stream (nominal peak is quoted at 2.4 GHz)",
                          "how": "visrep_debug_mfma_probe: 20000 x 32 v_mfma_f32_16x16x32_bf16 per wave, 8 waves per CU, random bf16 register operands with |x| in [0.25, 4), best of 3 launches after 2 warm-up launches, same process"}
         except Exception as e:
             practical = {"error": str(e)[:200]}

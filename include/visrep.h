@@ -87,7 +87,9 @@ int visrep_debug_routes(long* out, int reset);
  * traffic.  FLOP per launch = CUs * 8 * iters * 32 * 16384 (returned through *flop when non-NULL); the caller times the launch on
  * `stream`.  bench.py quotes the result beside the 2.5 PFLOP/s nominal peak: on random data the chip's power management holds a pure
  * MFMA stream near 1.9-2.0 PFLOP/s (DVFS), which is the practical roof every fraction on the line can also be read against.
- * sink: >= 4 bytes of device memory (never written in practice). */
+ * sink: >= 24 bytes of 8-byte-aligned device memory: bytes [0, 4) are never written in practice; u64 [1] = shader-clock cycles (s_memtime) and
+ * u64 [2] = 100-MHz ticks (s_memrealtime) of block 0's MFMA loop, i.e. the clock the stream ran at = [1] / ([2] * 10 ns) - the same pair of
+ * counters, read in the tile-timing build of the GEMM (tools/gemm_tile_timing.py), gives the clock the GEMM runs at (profiles/round5_gemm.md). */
 int visrep_debug_mfma_probe(int iters, int random, void* sink, double* flop, void* stream);
 
 /* ---- optional device scratch owned by the caller (e.g. one torch tensor kept alive for the process).  With it,
@@ -394,10 +396,13 @@ int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, const void* W
  * conv_norm_out that follows it in diffusers resnet.py:ResnetBlock2D / vae.py:Encoder - as partial sums from its epilogue:
  * gn_partial[((b * (Ho Wo / 64) + slot) * groups + g)] = (sum, sum of squares) of the fp32 outputs of image b, rows [64 slot, 64 slot + 64), group g
  * (visrep_conv_gn_partial_bytes(B, Ho Wo, groups) bytes, every entry written).  visrep_groupnorm_from_partials() then normalises without
- * reading the tensor for its statistics.  Supported when visrep_conv_gn_supported(B, Ho Wo, Cout, groups): Ho Wo % 128 == 0, Cout % 64 == 0,
- * Cout / groups in {4, 8, 16}, and a problem the 128x128 kernel runs (the 768^2 and 384^2 128-channel layers of the VAE encoder: the
- * largest tensors; the 256x256 kernel's epilogue has no registers left for the running sums). */
+ * reading the tensor for its statistics.  Supported when visrep_conv_gn_supported_epi(B, Ho Wo, Cout, groups, epilogue): Ho Wo % 128 == 0,
+ * Cout % 64 == 0, Cout / groups in {4, 8, 16}, and a kernel that emits the sums without costing the convolution its route: the 128x128
+ * kernel (both epilogues, from its epilogue's store loop) or - round 5 - the 256x256 ping-pong kernel for VISREP_EPI_BIAS (a packed-math pass
+ * over the accumulators in front of its epilogue); a RESID convolution that the 256x256 kernel runs is answered 0 and keeps the separate
+ * statistics pass.  visrep_conv_gn_supported() is the round-4 query without the epilogue (the answer that holds for both epilogues). */
 int visrep_conv_gn_supported(int B, int HWo, int Cout, int groups);
+int visrep_conv_gn_supported_epi(int B, int HWo, int Cout, int groups, int epilogue);
 size_t visrep_conv_gn_partial_bytes(int B, int HWo, int groups);
 int visrep_conv3x3_bf16_gn(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
                            int stride, int pad_mode, int epilogue, const void* resid, void* gn_partial, int groups, void* stream);

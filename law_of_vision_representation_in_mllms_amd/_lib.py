@@ -65,6 +65,7 @@ SIGNATURES = {
     "visrep_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "visrep_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_conv_gn_supported": (_i, [_i, _i, _i, _i]),
+    "visrep_conv_gn_supported_epi": (_i, [_i, _i, _i, _i, _i]),
     "visrep_conv_gn_partial_bytes": (_sz, [_i, _i, _i]),
     "visrep_conv3x3_bf16_gn": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "visrep_groupnorm_from_partials": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),

@@ -149,10 +149,10 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page5[4] = {0u, 0u, 0u, 
 // symmetric or (0,1,0,1) padding, no upsampling): the X rows are output pixels, a lane's four row cursors point at the pixel's top-left tap
 // and carry a 9-bit "tap is inside the image" mask; per K-tile the tap's offset (ky W + kx) C + c0 is one scalar and a lane whose tap is
 // padding fetches the zero page instead.  W, the ring, the ledger and the epilogues are the plain GEMM's.
-// (A variant whose epilogue also emits GroupNorm partial sums - GemmArgs::gn_partial, as the 128x128 kernel's does - was built in round 4 and
-// dropped: with 128 accumulators live the eight running sums tip the allocator into ~200 spilled registers, K loop included; convolutions that
-// take this kernel keep the separate statistics pass, profiles/round4_sd15_kernel_stats.md.)
-template <int EPI, bool OWN_, bool CONV_ = false>
+// GN_ (round 5, EPI_BIAS): the GroupNorm partial sums of the output (GemmArgs::gn_partial, as the 128x128 kernel's epilogue emits them) from a pass
+// over the accumulators in front of the plain epilogue (gemm_epilogue.h gemm_gn_partials_prepass, which also says why not inside it), in an
+// instantiation of its own.  Residual convolutions would need their residual tile twice and keep the separate statistics pass.
+template <int EPI, bool OWN_, bool CONV_ = false, bool GN_ = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -330,11 +330,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         int kt = 0, ti = 0;
 #ifdef V5_TILE_TIMING                                       // diagnostic build (-DV5_TILE_TIMING, tools/gemm_tile_timing.py): cycle stamps at the tile boundaries of block 0
         const bool timing = p.dbg_buf && blockIdx.x == 0 && wn == 0;      // wave 0 (group 0) and wave 4 (group 1)
-        unsigned long long t_loop = 0, t_epi = 0, t_mark = 0;
+        unsigned long long t_loop = 0, t_epi = 0, t_mark = 0, t_bar = 0, t_b = 0;
 #endif
         if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
 #ifdef V5_TILE_TIMING
         t_mark = __builtin_readcyclecounter();
+        const unsigned long long t_first = t_mark, r_first = __builtin_amdgcn_s_memrealtime();   // shader-clock cycles / 100-MHz ticks: the clock this launch ran at
 #endif
         for (int s = 0; s < S; ++s) {
             const unsigned sx = lds0 + (unsigned)((2 * s) % NSLOT) * XW_BYTES, sw = lds0 + (unsigned)((2 * s + 1) % NSLOT) * XW_BYTES;
@@ -383,16 +384,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 { const unsigned long long t = __builtin_readcyclecounter(); t_loop += t - t_mark; t_mark = t; }      // K loop of this tile (incl. its waits)
 #endif
                 if (V5_EPI_EARLY && G == 0) barrier();          // this iteration's closing barrier, taken before the epilogue (see V5_EPI_EARLY)
+#ifdef V5_TILE_TIMING
+                { const unsigned long long t = __builtin_readcyclecounter(); t_bar += t - t_mark; }                   // wait at the early barrier, if this group takes it here
+#endif
                 if constexpr (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, hi);
                 else if constexpr (EPI == EPI_F32X) gemm_epilogue_f32x<8, 4>(p, acc, mb, nb, fr, hi);
-                else gemm_epilogue_rowmajor<EPI, 8, 4, true>(p, acc, mb, nb, fr, hi);
+                else {
+                    if constexpr (GN_) gemm_gn_partials_prepass<8, 4>(p, acc, mb, nb, fr, hi);
+                    gemm_epilogue_rowmajor<EPI, 8, 4, true>(p, acc, mb, nb, fr, hi);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef V5_TILE_TIMING
+                t_b = __builtin_readcyclecounter();             // end of the epilogue body (loads, arithmetic, store ISSUE, accumulator reset)
+#endif
                 if (!(V5_EPI_EARLY && G == 0)) barrier();
 #ifdef V5_TILE_TIMING
-                { const unsigned long long t = __builtin_readcyclecounter(); t_epi += t - t_mark; t_mark = t; }       // barrier(s) + epilogue of this tile
+                { const unsigned long long t = __builtin_readcyclecounter(); t_epi += t - t_mark; t_bar += t - t_b; t_mark = t; }   // barrier(s) + epilogue of this tile
 #endif
             } else {
                 barrier();
@@ -400,7 +410,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         }
         if (G == 0) barrier();                                 // group 1 executed one extra barrier up front
 #ifdef V5_TILE_TIMING
-        if (timing && lane == 0) { p.dbg_buf[G * 8 + 0] = t_loop; p.dbg_buf[G * 8 + 1] = t_epi; p.dbg_buf[G * 8 + 2] = (unsigned long long)tw.count; }
+        if (timing && lane == 0) { p.dbg_buf[G * 8 + 0] = t_loop; p.dbg_buf[G * 8 + 1] = t_epi; p.dbg_buf[G * 8 + 2] = (unsigned long long)tw.count; p.dbg_buf[G * 8 + 3] = t_bar;
+                                   p.dbg_buf[G * 8 + 4] = __builtin_readcyclecounter() - t_first; p.dbg_buf[G * 8 + 5] = __builtin_amdgcn_s_memrealtime() - r_first; }
+        if (p.dbg_buf && G == 0 && wn == 0 && lane == 0) {     // every block: when its tile loop started / ended (100-MHz ticks, one clock for the whole device) and its cycles
+            unsigned long long* o = p.dbg_buf + 16 + (size_t)blockIdx.x * 4;
+            o[0] = r_first; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_readcyclecounter() - t_first; o[3] = (unsigned long long)tw.count;
+        }
 #endif
     };
     if (grp == 0) body(std::integral_constant<int, 0>{});
@@ -408,14 +423,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     wait_vm0();                                                // drain the (unused) run-ahead loads before exit
 }
 
-template <int EPI, bool OWN_, bool CONV_ = false>
+template <int EPI, bool OWN_, bool CONV_ = false, bool GN_ = false>
 int launch5o(const GemmArgs& a, hipStream_t s) {
     static VisrepLdsOptIn opt;                                   // per (kernel instantiation, device)
-    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_, CONV_>), LDS2);
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_, CONV_, GN_>), LDS2);
     const int ncu = visrep_cu_count();
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_, CONV_>), dim3(grid), dim3(512), LDS2, s, a);
+    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_, CONV_, GN_>), dim3(grid), dim3(512), LDS2, s, a);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
 
@@ -433,15 +448,17 @@ bool visrep_gemm_v5_supports(const GemmArgs& a) {
 
 // implicit 3x3 convolution in the 256x256 kernel: whole column tiles, 64-channel K-tiles inside one tap, no upsampled source
 bool visrep_gemm_v5_supports_conv(const GemmArgs& a) {
-    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && !a.gn_partial && (a.epi == EPI_BIAS || a.epi == EPI_RESID) &&
+    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && (a.epi == EPI_BIAS || (a.epi == EPI_RESID && !a.gn_partial)) &&
            (long)a.M / (a.cHo * a.cWo) * a.cH * a.cW * a.cC < (1L << 31) - (3L * a.cW + 3) * a.cC;     // 32-bit element offsets
 }
 
 int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.conv) {
         if (!visrep_gemm_v5_supports_conv(a)) return visrep_set_error(VISREP_ERR_ARG, "gemm v5: unsupported convolution");
+        if (a.gn_partial) return launch5o<EPI_BIAS, false, true, true>(a, s);
         return a.epi == EPI_BIAS ? launch5o<EPI_BIAS, false, true>(a, s) : launch5o<EPI_RESID, false, true>(a, s);
     }
+#ifndef V5_DEV_ONLY_CONV                                          // (development builds compile the convolution instantiations only)
     switch (a.epi) {
         case EPI_PATCH: return launch5<EPI_PATCH>(a, s);
         case EPI_BIAS: return launch5<EPI_BIAS>(a, s);
@@ -451,5 +468,6 @@ int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s) {
         case EPI_F32: return launch5<EPI_F32>(a, s);
         case EPI_F32X: return launch5<EPI_F32X>(a, s);
     }
+#endif
     return visrep_set_error(VISREP_ERR_ARG, "gemm: unknown epilogue");
 }

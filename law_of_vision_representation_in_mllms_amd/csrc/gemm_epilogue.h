@@ -94,6 +94,65 @@ VR_DEV float sum_over_fr(float v) {
     return v;
 }
 
+// (t1, t2) = this lane's sum / sum of squares over its rows of column quad c -> summed over the 16 row lanes and over the lanes a group spans,
+// written to the wave's slot of GemmArgs::gn_partial by the lane that owns the group's first column
+template <int NI_RBLK, int RBLK>
+VR_DEV void gn_partial_store(const GemmArgs& p, float2* dst, int G, float t1, float t2, int c, int nb, int fr, int hg) {
+    float s1 = sum_over_fr(t1), s2 = sum_over_fr(t2);
+    if (p.gn_cpg >= 8) {                          // uniform: a group spans the column quads of the lanes hg, hg ^ 1 (and hg ^ 2 for 16)
+        const auto a1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
+        const auto a2 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
+        s1 = __builtin_bit_cast(float, (unsigned)a1[0]) + __builtin_bit_cast(float, (unsigned)a1[1]);
+        s2 = __builtin_bit_cast(float, (unsigned)a2[0]) + __builtin_bit_cast(float, (unsigned)a2[1]);
+    }
+    if (p.gn_cpg >= 16) {
+        const auto a1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
+        const auto a2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
+        s1 = __builtin_bit_cast(float, (unsigned)a1[0]) + __builtin_bit_cast(float, (unsigned)a1[1]);
+        s2 = __builtin_bit_cast(float, (unsigned)a2[0]) + __builtin_bit_cast(float, (unsigned)a2[1]);
+    }
+    const int colq = nb + c * RBLK + hg * 4;       // first column of this lane's quad c
+    if (fr == 0 && (colq % p.gn_cpg) == 0) {
+        const int g = colq / p.gn_cpg;
+        // (asm stores: a compiler-visible VMEM operation pending at the K loop's header would cost the 256x256 kernel a vmcnt(0) per tile)
+        store_b64(dst + g, u32x2{__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2)});
+        if (NI_RBLK == 128) store_b64(dst + G + g, u32x2{0u, 0u});       // this wave covers two 64-row slots: all of it in the first
+    }
+}
+
+// The 256x256 ping-pong kernel's GroupNorm partial sums (EPI_BIAS convolutions): a pass over the accumulators BEFORE the plain epilogue.  Running
+// sums inside the epilogue (round 4, and again in round 5 with the output values written back over their accumulators) put 170-340 registers into
+// scratch, K loop included - that kernel sits at 252-256 registers and any live range added across its store stream cascades.  Here nothing is
+// live across the epilogue: per column quad two packed (v_pk_*) running pairs, the bias added on the fly, reduced and stored before the next quad.
+// The sums are those of the fp32 (unrounded) outputs, as the 128x128 kernel's; the order of summation differs (tests compare with a tolerance).
+template <int NI, int NJ, typename ACC>
+VR_DEV void gemm_gn_partials_prepass(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
+    constexpr int RBLK = AccGeom<ACC>::RBLK;
+    static_assert(AccGeom<ACC>::QN == 1 && NI * RBLK == 128, "16x16 accumulators, 128 rows per wave");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    if (mb >= p.M) return;                                        // uniform per wave; gn_hw % 128 == 0: all rows valid and inside one image
+    float4 bq[NJ];
+#pragma unroll
+    for (int c = 0; c < NJ; ++c) bq[c] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb + hg * 4 + c * RBLK) : float4{0.f, 0.f, 0.f, 0.f};
+    drain_visible_loads();
+    const int g0 = mb + p.a_row0;
+    const int b = g0 / p.gn_hw, slot = (g0 - b * p.gn_hw) >> 6, nblk = p.gn_hw >> 6, G = p.N / p.gn_cpg;
+    float2* dst = p.gn_partial + ((size_t)b * nblk + slot) * G;
+#pragma unroll
+    for (int c = 0; c < NJ; ++c) {
+        const f32x2 b01 = {bq[c].x, bq[c].y}, b23 = {bq[c].z, bq[c].w};
+        f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f32x2 v01 = f32x2{acc[i][c][0], acc[i][c][1]} + b01, v23 = f32x2{acc[i][c][2], acc[i][c][3]} + b23;
+            s01 += v01; s23 += v23;
+            q01 = __builtin_elementwise_fma(v01, v01, q01); q23 = __builtin_elementwise_fma(v23, v23, q23);
+        }
+        const f32x2 s = s01 + s23, q = q01 + q23;
+        gn_partial_store<NI * RBLK, RBLK>(p, dst, G, s[0] + s[1], q[0] + q[1], c, nb, fr, hg);
+    }
+}
+
 // HAS_GN (convolutions, EPI_BIAS / EPI_RESID): also emit the GroupNorm partial sums of this wave's rows (GemmArgs::gn_partial).
 template <int EPI, int NI, int NJ, int ACT, bool EDGE, bool HAS_LS, bool HAS_LN, bool HAS_ST, bool AL, bool HAS_GN, typename ACC>
 VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
@@ -278,25 +337,7 @@ VR_DEV void gemm_epilogue_rowmajor_impl(const GemmArgs& p, const ACC (&acc)[NI][
             float2* dst = p.gn_partial + ((size_t)b * nblk + slot) * G;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                float s1 = sum_over_fr(gs1[HAS_GN ? c : 0]), s2 = sum_over_fr(gs2[HAS_GN ? c : 0]);
-                if (p.gn_cpg >= 8) {                          // uniform: a group spans the column quads of the lanes hg, hg ^ 1 (and hg ^ 2 for 16)
-                    const auto a1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
-                    const auto a2 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
-                    s1 = __builtin_bit_cast(float, (unsigned)a1[0]) + __builtin_bit_cast(float, (unsigned)a1[1]);
-                    s2 = __builtin_bit_cast(float, (unsigned)a2[0]) + __builtin_bit_cast(float, (unsigned)a2[1]);
-                }
-                if (p.gn_cpg >= 16) {
-                    const auto a1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
-                    const auto a2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
-                    s1 = __builtin_bit_cast(float, (unsigned)a1[0]) + __builtin_bit_cast(float, (unsigned)a1[1]);
-                    s2 = __builtin_bit_cast(float, (unsigned)a2[0]) + __builtin_bit_cast(float, (unsigned)a2[1]);
-                }
-                const int colq = nb + c * RBLK + hg * 4;       // first column of this lane's quad c
-                if (fr == 0 && (colq % p.gn_cpg) == 0) {
-                    const int g = colq / p.gn_cpg;
-                    dst[g] = float2{s1, s2};
-                    if (NI * RBLK == 128) dst[G + g] = float2{0.f, 0.f};       // this wave covers two 64-row slots: all of it in the first
-                }
+                gn_partial_store<NI * RBLK, RBLK>(p, dst, G, gs1[HAS_GN ? c : 0], gs2[HAS_GN ? c : 0], c, nb, fr, hg);
             }
         }
     }

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void mfma_probe_kernel(float* sink, int ite
     f32x4 acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();   // shader-clock cycles / 100-MHz ticks
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
@@ -82,6 +83,12 @@ __global__ __launch_bounds__(512, 2) void mfma_probe_kernel(float* sink, int ite
 #pragma unroll
     for (int i = 0; i < 32; ++i) s += acc[i][1];
     if (s == 123.456f) sink[0] = s;                              // keeps the accumulators live; never true in practice
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // the clock this stream ran at: (c1 - c0) / ((r1 - r0) * 10 ns)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(sink);
+        o[1] = c1 - c0;
+        o[2] = r1 - r0;
+    }
 }
 }  // namespace
 
@@ -207,14 +214,21 @@ extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, co
     return visrep_gemm_dispatch(a, (hipStream_t)stream);
 }
 
-// Rows and groups must fit the epilogue's slots, and the convolution must be one the 128x128 kernel runs: the 256x256 kernel (whole rounds of
-// its tiles, Cout % 256 == 0) has no registers left for the running sums and keeps the separate statistics pass.
-extern "C" int visrep_conv_gn_supported(int B, int HWo, int Cout, int groups) {
+// Rows and groups must fit the epilogue's slots (64-row slots inside one image, a group inside a lane quad pair / quartet), and asking for the
+// sums must not cost the convolution its kernel: the 128x128 kernel emits them from its epilogue for both epilogues, the 256x256 kernel (whole
+// rounds of its tiles, Cout % 256 == 0) for EPI_BIAS only (round 5: a pass over the accumulators in front of the epilogue; a residual
+// convolution there keeps the separate statistics pass).  visrep_conv_gn_supported is the round-4 query (no epilogue argument: the
+// conservative answer that holds for both).
+extern "C" int visrep_conv_gn_supported_epi(int B, int HWo, int Cout, int groups, int epilogue) {
     if (B <= 0 || HWo <= 0 || Cout <= 0 || groups <= 0 || Cout % groups) return 0;
+    if (epilogue != VISREP_EPI_BIAS && epilogue != VISREP_EPI_RESID) return 0;
     const int cpg = Cout / groups;
     if (!(HWo % 128 == 0 && Cout % 64 == 0 && (cpg == 4 || cpg == 8 || cpg == 16))) return 0;
-    if (Cout % 256 == 0 && ((long)B * HWo + 255) / 256 * (Cout / 256) >= 2L * visrep_cu_count()) return 0;
+    if (epilogue != VISREP_EPI_BIAS && Cout % 256 == 0 && ((long)B * HWo + 255) / 256 * (Cout / 256) >= 2L * visrep_cu_count()) return 0;
     return 1;
+}
+extern "C" int visrep_conv_gn_supported(int B, int HWo, int Cout, int groups) {
+    return visrep_conv_gn_supported_epi(B, HWo, Cout, groups, VISREP_EPI_RESID);
 }
 
 extern "C" size_t visrep_conv_gn_partial_bytes(int B, int HWo, int groups) {
@@ -235,8 +249,8 @@ extern "C" int visrep_conv3x3_bf16_gn(const void* x, int B, int H, int W, int C,
     a.conv = 1; a.cH = H; a.cW = W; a.cC = C; a.cstride = stride; a.cpad = pad_mode == 0 ? 1 : 0; a.cup = 0;
     a.cHo = (H + pad_total - 3) / stride + 1;
     a.cWo = (W + pad_total - 3) / stride + 1;
-    if (!visrep_conv_gn_supported(B, a.cHo * a.cWo, Cout, groups))
-        return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3_gn: needs Ho Wo % 128 == 0, 4 | 8 | 16 channels per group and a shape the 128x128 kernel runs (see visrep_conv_gn_supported)");
+    if (!visrep_conv_gn_supported_epi(B, a.cHo * a.cWo, Cout, groups, epilogue))
+        return visrep_set_error(VISREP_ERR_SHAPE, "conv3x3_gn: needs Ho Wo % 128 == 0, 4 | 8 | 16 channels per group and a kernel that emits the sums for this epilogue (see visrep_conv_gn_supported_epi)");
     a.M = B * a.cHo * a.cWo; a.N = Cout; a.K = 9 * C; a.lda = 8; a.ldw = ldw; a.ldc = ldc; a.epi = epilogue;
     a.gn_partial = (float2*)gn_partial; a.gn_cpg = Cout / groups; a.gn_hw = a.cHo * a.cWo;
     return visrep_gemm_dispatch(a, (hipStream_t)stream);

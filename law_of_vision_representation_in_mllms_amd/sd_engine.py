@@ -59,8 +59,10 @@ def groupnorm_from_partials(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Te
     return y
 
 
-def conv_gn_supported(B: int, HWo: int, Cout: int, groups: int) -> bool:
-    return bool(_lib.load().visrep_conv_gn_supported(int(B), int(HWo), int(Cout), int(groups)))
+def conv_gn_supported(B: int, HWo: int, Cout: int, groups: int, epi: int = _lib.EPI_RESID) -> bool:
+    """Can conv3x3(..., gn_groups=) leave the output's GroupNorm partial sums without losing its kernel?  (The 256x256 kernel emits them for
+    EPI_BIAS only: the default asks for the answer that holds for both epilogues.)"""
+    return bool(_lib.load().visrep_conv_gn_supported_epi(int(B), int(HWo), int(Cout), int(groups), int(epi)))
 
 
 def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, ld: int, stride: int = 1, pad_mode: int = 0, upsample: bool = False):
@@ -231,6 +233,7 @@ class SdEngine:
         self.implicit_conv = True
         self.vae_flash = os.environ.get("VISREP_VAE_FLASH", "1") != "0"      # 0: the materialised-score route (A/B, tools/)
         self.fuse_gn_stats = os.environ.get("VISREP_GN_FUSE", "1") != "0"    # 0: every GroupNorm reads its input twice (A/B, tools/)
+        self.fuse_gn_256 = os.environ.get("VISREP_GN_FUSE_256", "1") != "0"  # 0: partial sums from the 128x128 kernel only, as in round 4 (A/B)
         self.conv_halo = os.environ.get("VISREP_CONV_HALO", "1") != "0"      # 0: the 128-channel layers keep apply pass + implicit-GEMM convolution (A/B, tools/)
         # 128 -> 256 layers (one per VAE): the kernel's Cout = 256 variant is correct but measured SLOWER than the persistent 256x256 convolution
         # + apply pass (1.80 against 1.48 ms at 384^2 x 16: 128 accumulators leave no registers for double-buffered fragments) - opt-in only
@@ -432,7 +435,7 @@ class SdEngine:
             if gn and self.fuse_gn_stats and not upsample and epi in (_lib.EPI_BIAS, _lib.EPI_RESID) and lin.w.shape[0] == lin.n:
                 pad_total = 2 if pad_mode == 0 else 1
                 Ho, Wo = (H + pad_total - 3) // stride + 1, (W + pad_total - 3) // stride + 1
-                if conv_gn_supported(B, Ho * Wo, lin.n, gn):
+                if conv_gn_supported(B, Ho * Wo, lin.n, gn, epi if self.fuse_gn_256 else _lib.EPI_RESID):
                     out, Ho, Wo, partial = conv3x3(x, B, H, W, lin.w, lin.b, stride, pad_mode, False, epi, resid, gn_groups=gn)
                     out._visrep_gn = (partial, gn)                       # rides on the tensor object: dies with it, never matches another tensor
                     return out, Ho, Wo

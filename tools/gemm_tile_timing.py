@@ -1,4 +1,4 @@
-"""Where a tile round of the persistent 256x256 GEMM goes (diagnostic build: build.build_variant_lib('tiletiming', ['-DV5_TILE_TIMING'], only=['gemm_bf16_v5.hip']), VISREP_LIB=.../libvisrep_hip_tiletiming.so;
+"""Where a tile round of the persistent 256x256 GEMM goes, and at which clock (diagnostic build: build.build_variant_lib('tiletiming', ['-DV5_TILE_TIMING'], only=['gemm_bf16_v5.hip']), VISREP_LIB=.../libvisrep_hip_tiletiming.so;
 the K loop itself is the production one):
 shader-clock stamps of block 0's wave 0 (group 0) and wave 4 (group 1) at the tile boundaries - the K loop of a tile (first fragment read to the
 counted wait behind its last MFMA segment) and the rest (closing barrier(s) + epilogue + accumulator reset), averaged over the block's tiles."""
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from law_of_vision_representation_in_mllms_amd import _lib, engine
 dev = "cuda:0"
 lib = _lib.load()
-buf = torch.zeros(16, dtype=torch.int64, device=dev)
+buf = torch.zeros(16 + 4 * 1024, dtype=torch.int64, device=dev)      # 16 sums of block 0 + (start tick, end tick, cycles, tiles) per block
 lib.visrep_debug_gemm_timing_buffer(_lib.ptr(buf))
 M = 147456
 for (N, K, epi, tag) in ((4096, 1024, "act", "fc1"), (2048, 1024, "bias", "Q|K"), (1024, 1024, "resid", "out"), (1024, 4096, "resid", "fc2"), (1024, 1024, "vt", "V^T")):
@@ -29,7 +29,21 @@ for (N, K, epi, tag) in ((4096, 1024, "act", "fc1"), (2048, 1024, "bias", "Q|K")
     ms = e0.elapsed_time(e1) / 10
     buf.zero_(); run(); torch.cuda.synchronize()
     t = buf.cpu().tolist()
+    blk = torch.tensor(t[16:]).reshape(-1, 4)
+    blk = blk[blk[:, 3] > 0].double()
+    if len(blk):
+        t0 = blk[:, 0].min()
+        st, en = (blk[:, 0] - t0) * 0.01, (blk[:, 1] - t0) * 0.01            # us since the first block's first tile
+        dur = en - st
+        xcd = torch.arange(len(blk)) % 8
+        print(f"{tag:4s} {len(blk)} blocks: tile loops start {st.min():.1f} .. {st.max():.1f} us, end {en.min():.1f} .. {en.max():.1f} us (launch {ms * 1e3:.1f} us); "
+              f"loop duration min / median / max {dur.min():.1f} / {dur.median():.1f} / {dur.max():.1f} us; "
+              f"per XCD (block % 8) mean end " + " ".join(f"{en[xcd == x].mean():.1f}" for x in range(8))
+              + "; clock per XCD " + " ".join(f"{(blk[xcd == x, 2] / ((blk[xcd == x, 1] - blk[xcd == x, 0]) * 10)).mean():.3f}" for x in range(8)), flush=True)
     for g in range(2):
-        loop, epi_c, n = t[g * 8], t[g * 8 + 1], max(t[g * 8 + 2], 1)
+        loop, epi_c, n, bar = t[g * 8], t[g * 8 + 1], max(t[g * 8 + 2], 1), t[g * 8 + 3]
         tot = loop + epi_c
-        print(f"{tag:4s} group {g}: {n} tiles  K loop {loop / n:8.0f} cyc ({loop / n / (K // 64):6.0f} per K-tile)  boundary {epi_c / n:8.0f} cyc = {100 * epi_c / max(tot, 1):4.1f} % of the block's time;  launch {ms:.4f} ms", flush=True)
+        print(f"{tag:4s} group {g}: {n} tiles  K loop {loop / n:8.0f} cyc ({loop / n / (K // 64):6.0f} per K-tile)  boundary {epi_c / n:8.0f} cyc = {100 * epi_c / max(tot, 1):4.1f} % of the block's time"
+              f" [epilogue body {(epi_c - bar) / n:6.0f} cyc, waiting at its barrier(s) {bar / n:6.0f} cyc];  launch {ms:.4f} ms;"
+              f"  shader clock {t[g * 8 + 4] / max(t[g * 8 + 5], 1) / 10.0:.3f} GHz (s_memtime / s_memrealtime over the block's tiles);"
+              f"  matrix pipe busy {100.0 * n * (K // 64) * 2048 / max(t[g * 8 + 4], 1):.1f} % of those cycles (2 waves x 64 MFMAs x 16 cycles per K-tile and SIMD)", flush=True)
