@@ -452,6 +452,7 @@ def main():
                 "achieved_back_to_back": top["tflops"], "frac_back_to_back": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
                 "n01_back_to_back": n01,
                 "practical_roof": practical,
+                "xcd_balance": dict(_lib.xcd_balance(), what="XCD-weighted tile split of the persistent 256x256 kernel: rel = measured time per round of tiles of each XCD relative to the mean (the XCDs run at their own clocks under the power limit); opt-in (VISREP_XCD_BALANCE=1), equal shares by default"),
                 "frac_of_practical_roof": (round(top["tflops_in_layer_mix"] / practical["tflops"], 4) if practical and practical.get("tflops") else None),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_provenance": traffic_src,
                 "algorithmic_bytes_per_launch": 2.0 * (M * d + m * d + M * m),

@@ -91,6 +91,21 @@ int visrep_debug_routes(long* out, int reset);
  * u64 [2] = 100-MHz ticks (s_memrealtime) of block 0's MFMA loop, i.e. the clock the stream ran at = [1] / ([2] * 10 ns) - the same pair of
  * counters, read in the tile-timing build of the GEMM (tools/gemm_tile_timing.py), gives the clock the GEMM runs at (profiles/round5_gemm.md). */
 int visrep_debug_mfma_probe(int iters, int random, void* sink, double* flop, void* stream);
+/* XCD-weighted tile split of the persistent 256x256 GEMM / convolution kernel (round 5).  The eight XCDs of an MI355X run at their own clocks
+ * under the power limit (+-4 % around the mean inside one launch, measured with s_memtime / s_memrealtime: profiles/round5_gemm.md), so equal
+ * shares of the tile list end when the slowest XCD does - and which XCD that is also depends on the kernel and its shape.  Per (kernel
+ * instantiation, M, N, K) one launch in 8 records when each XCD finished; its last block leaves the time per round of tiles of each XCD in
+ * pinned host memory; the following launches of that shape give every XCD whole rounds in proportion to its speed.  Results are bitwise
+ * independent of the split.  OFF by default: a round of tiles is 2.8 % of a block's work at the headline shapes, as large as the effect, and
+ * the same-box A/B measured +0.1 .. +0.3 % on the forward (profiles/round5_gemm.md section 3).  visrep_set_xcd_balance(1) (or
+ * VISREP_XCD_BALANCE=1 in the environment) switches it on, process-wide; returns the previous setting.  visrep_debug_xcd_balance: the smoothed relative time per round of each XCD (1 = mean; rel8 may
+ * be NULL) of the shape launched most recently on the current device, and the number of measurements folded in so far; returns the setting. */
+int visrep_set_xcd_balance(int on);
+int visrep_debug_xcd_balance(float* rel8, unsigned* updates);
+/* The split itself (pure host arithmetic, no device needed): rel8 = time per round of tiles of each XCD (any positive scale), grid = persistent
+ * blocks (a multiple of 8), ntiles >= grid -> bounds9[x] .. bounds9[x + 1] = the tile indices of XCD x, bounds9[8] = ntiles; whole rounds of
+ * grid / 8 tiles in proportion to speed, leftovers to the XCD that would finish first.  Returns 0, -1 for unusable arguments. */
+int visrep_debug_xcd_split(const float* rel8, int grid, int ntiles, int* bounds9);
 
 /* ---- optional device scratch owned by the caller (e.g. one torch tensor kept alive for the process).  With it,
  * visrep_gemm_bf16 splits the K loop of problems that have few output tiles but a deep reduction (the diffusion towers'

@@ -106,6 +106,9 @@ SIGNATURES = {
     "visrep_device_cu_count": (_i, []),
     "visrep_debug_routes": (_i, [C.POINTER(C.c_long), _i]),
     "visrep_debug_mfma_probe": (_i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
+    "visrep_set_xcd_balance": (_i, [_i]),
+    "visrep_debug_xcd_balance": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_uint)]),
+    "visrep_debug_xcd_split": (_i, [C.POINTER(C.c_float), _i, _i, C.POINTER(C.c_int)]),
     "visrep_mutual_nn_distance": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "visrep_ascore_workspace_bytes": (_sz, [_i, _i, _i]),
     "visrep_ascore_maxcos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -163,6 +166,15 @@ def load(build_if_missing: bool = True):
 
 
 ROUTES = ("gemm_256", "gemm_128", "gemm_tail", "splitk", "conv_256", "conv_128", "conv_128_gn", "attn", "attn_wide", "attn_cls", "conv_halo")
+
+
+def xcd_balance() -> dict:
+    """{"on": bool, "rel": [8 floats: smoothed time per round of tiles of each XCD relative to the mean], "updates": measurements folded in}
+    of the current device's XCD-weighted tile split (visrep_debug_xcd_balance)."""
+    rel = (C.c_float * 8)()
+    upd = C.c_uint(0)
+    on = load().visrep_debug_xcd_balance(rel, C.byref(upd))
+    return {"on": bool(on), "rel": [round(float(v), 4) for v in rel], "updates": int(upd.value)}
 
 
 def routes(reset: bool = False) -> dict:

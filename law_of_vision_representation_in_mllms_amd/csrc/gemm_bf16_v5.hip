@@ -37,6 +37,9 @@
 //         group 0 has confirmed W(s+1) and X-upper(s+1) before instance 4s+4; X-lower(s+1) is confirmed by group 1 before instance
 //         4s+5, which is all its only readers (group 1, from L0(s+1) on) need.
 #include <type_traits>
+#include <mutex>
+#include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -122,6 +125,30 @@ VR_DEV void barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// End of a SAMPLED launch (GemmArgs::xb, one launch in 16): when did each XCD finish?  Every block leaves its end time in its XCD's maximum;
+// the last block to arrive turns the eight maxima into "ticks per round of tiles" (a round = one tile on each of the XCD's blocks) and
+// stores them in pinned host memory for visrep_xcd_plan, then zeroes the slot.  Off the hot path: after the last tile's stores.
+VR_DEV void xcd_record(const GemmArgs& p, int ntiles, unsigned long long t0) {
+    VisrepXcdSlot* s = &p.xb->slot[(p.xb_seq >> 3) & 15];
+    const int G = gridDim.x, x = blockIdx.x & 7;
+    atomicMax(&s->t_end[x], __builtin_amdgcn_s_memrealtime());
+    if (blockIdx.x == 0) atomicExch(&s->t_start, t0);          // the blocks start within ~2 us of each other: block 0's start is the launch's
+    __threadfence();
+    if (atomicAdd(&s->done, 1u) != (unsigned)G - 1) return;
+    __threadfence();
+    const unsigned long long ts = atomicExch(&s->t_start, 0ull);
+    const int per8 = G >> 3, q = ntiles >> 3, r = ntiles & 7;
+    for (int y = 0; y < 8; ++y) {
+        const unsigned long long te = atomicExch(&s->t_end[y], 0ull);
+        const int n = p.xcd_bounds[8] == ntiles ? p.xcd_bounds[y + 1] - p.xcd_bounds[y] : q + (y < r ? 1 : 0);
+        const int rounds = (n + per8 - 1) / per8;
+        p.xb_host->tile_ticks[y] = (ts && te > ts && rounds > 0) ? (float)(te - ts) / (float)rounds : 0.f;
+    }
+    atomicExch(&s->done, 0u);
+    __threadfence_system();
+    p.xb_host->seq = p.xb_seq;
+}
+
 struct TileWalk {           // the block's list of output tiles: chunk of its XCD, strided by the blocks of that XCD
     int start, stride, count, ntn, ntm;
     // Tile order as in v2: the ~32 blocks of an XCD work on ~32 consecutive tile indices and share that XCD's 4-MB L2; for more than 8
@@ -167,14 +194,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         const int x = blockIdx.x % nx, j = blockIdx.x / nx;   // block b runs on XCD b % 8 (speed only)
         const int per = (G + nx - 1 - x) / nx;                // blocks on this XCD
         const int q = ntiles / nx, r = ntiles % nx;
-        const int cstart = x * q + (x < r ? x : r), csize = q + (x < r ? 1 : 0);
+        int cstart = x * q + (x < r ? x : r), csize = q + (x < r ? 1 : 0);
+        if (p.xcd_bounds[8] == ntiles && nx == 8) {            // XCD-weighted shares (visrep_xcd_plan): faster XCDs walk longer chunks
+            cstart = p.xcd_bounds[x];
+            csize = p.xcd_bounds[x + 1] - cstart;
+        }
         tw.start = cstart + j;
         tw.stride = per;
         tw.count = j < csize ? (csize - j + per - 1) / per : 0;
         tw.ntn = ntn;
         tw.ntm = ntm;
     }
-    if (tw.count == 0) return;                                 // uniform per block: no barrier has been executed yet
+    const unsigned long long xb_t0 = p.xb ? __builtin_amdgcn_s_memrealtime() : 0ull;      // sampled launches: when this block started (100-MHz ticks)
+    if (tw.count == 0) { if (p.xb && tid == 0) xcd_record(p, ntiles, xb_t0); return; }    // uniform per block: no barrier has been executed yet
 #ifdef V5_STAGGER_P                                             // A/B knob (tools/): block j of an XCD starts (j % P) x N sleeps of ~3.9 us late, so that the
     {                                                           // CUs' output bursts do not coincide (profiles/round4_gemm.md section 6)
         const int ph = (int)(blockIdx.x / 8) % V5_STAGGER_P;
@@ -331,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 #ifdef V5_TILE_TIMING                                       // diagnostic build (-DV5_TILE_TIMING, tools/gemm_tile_timing.py): cycle stamps at the tile boundaries of block 0
         const bool timing = p.dbg_buf && blockIdx.x == 0 && wn == 0;      // wave 0 (group 0) and wave 4 (group 1)
         unsigned long long t_loop = 0, t_epi = 0, t_mark = 0, t_bar = 0, t_b = 0;
+        unsigned long long t_kb[5] = {0, 0, 0, 0, 0}, n_kb[5] = {0, 0, 0, 0, 0}, tk_prev = 0; int kt_prev = 0;
 #endif
         if (G == 1) barrier();                                 // skew: group 1 runs one barrier interval behind
 #ifdef V5_TILE_TIMING
@@ -340,6 +373,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         for (int s = 0; s < S; ++s) {
             const unsigned sx = lds0 + (unsigned)((2 * s) % NSLOT) * XW_BYTES, sw = lds0 + (unsigned)((2 * s + 1) % NSLOT) * XW_BYTES;
             bf16x8 xf[8], wf[4];
+#ifdef V5_TILE_TIMING                                       // whole K-tile iterations (closing barrier included) by their position in the output tile: 0, 1, 2,
+            {                                                   // later ones, and the last one (which carries the epilogue and the closing barriers)
+                const unsigned long long now = __builtin_readcyclecounter();
+                if (s > 0) {
+                    const unsigned long long d = now - tk_prev;
+                    if (kt_prev == nk - 1) { t_kb[4] += d; ++n_kb[4]; } else if (kt_prev == 0) { t_kb[0] += d; ++n_kb[0]; } else if (kt_prev == 1) { t_kb[1] += d; ++n_kb[1]; }
+                    else if (kt_prev == 2) { t_kb[2] += d; ++n_kb[2]; } else { t_kb[3] += d; ++n_kb[3]; }
+                }
+                tk_prev = now; kt_prev = kt;
+            }
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 // ---------------- L(h): 12 fragment reads of k-half h + four LDS-DMA loads (L0: W of tile s+1, L1: X of tile s+2)
@@ -412,6 +456,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
 #ifdef V5_TILE_TIMING
         if (timing && lane == 0) { p.dbg_buf[G * 8 + 0] = t_loop; p.dbg_buf[G * 8 + 1] = t_epi; p.dbg_buf[G * 8 + 2] = (unsigned long long)tw.count; p.dbg_buf[G * 8 + 3] = t_bar;
                                    p.dbg_buf[G * 8 + 4] = __builtin_readcyclecounter() - t_first; p.dbg_buf[G * 8 + 5] = __builtin_amdgcn_s_memrealtime() - r_first; }
+        if (timing && lane == 0) {                             // K-tile time by position, without the barrier that closes the K-tile
+            for (int i = 0; i < 5; ++i) { p.dbg_buf[16 + 4096 + G * 16 + i] = t_kb[i]; p.dbg_buf[16 + 4096 + G * 16 + 8 + i] = n_kb[i]; }
+        }
         if (p.dbg_buf && G == 0 && wn == 0 && lane == 0) {     // every block: when its tile loop started / ended (100-MHz ticks, one clock for the whole device) and its cycles
             unsigned long long* o = p.dbg_buf + 16 + (size_t)blockIdx.x * 4;
             o[0] = r_first; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_readcyclecounter() - t_first; o[3] = (unsigned long long)tw.count;
@@ -421,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     if (grp == 0) body(std::integral_constant<int, 0>{});
     else body(std::integral_constant<int, 1>{});
     wait_vm0();                                                // drain the (unused) run-ahead loads before exit
+    if (p.xb && tid == 0) xcd_record(p, ntiles, xb_t0);
 }
 
 template <int EPI, bool OWN_, bool CONV_ = false, bool GN_ = false>
@@ -430,7 +478,9 @@ int launch5o(const GemmArgs& a, hipStream_t s) {
     const int ncu = visrep_cu_count();
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_, CONV_, GN_>), dim3(grid), dim3(512), LDS2, s, a);
+    GemmArgs b = a;
+    visrep_xcd_plan(b, s, grid, ntiles, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_, CONV_, GN_>));
+    hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_, CONV_, GN_>), dim3(grid), dim3(512), LDS2, s, b);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
 }
 
@@ -440,6 +490,127 @@ int launch5(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------ XCD-weighted tile split (host side)
+namespace {
+// One record per (kernel instantiation, M, N, K) and device: which XCD is slow depends on the kernel and its shape (operand placement in the
+// HBM channels, L2 behaviour), not only on the XCD's clock - a device-wide estimate measured no gain (profiles/round5_gemm.md).
+constexpr int XCD_RECORDS = 48;
+struct XcdRecord {
+    const void* fn = nullptr; int M = 0, N = 0, K = 0;
+    float rel[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // smoothed time per round of tiles of each XCD, relative to the mean
+    unsigned seen = 0, updates = 0, launches = 0;
+};
+struct XcdState {
+    VisrepXcdDev* dev = nullptr;                                 // XCD_RECORDS of them
+    VisrepXcdHost* host = nullptr;
+    XcdRecord rec[XCD_RECORDS];
+    int used = 0, last = -1;
+    bool failed = false;
+};
+XcdState g_xcd[VISREP_MAX_DEVICES];
+std::mutex g_xcd_mu;
+std::atomic<int> g_xcd_on{-1};                                  // -1: not decided yet (VISREP_XCD_BALANCE), 0 / 1
+bool xcd_enabled() {
+    int v = g_xcd_on.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("VISREP_XCD_BALANCE");      // opt-in: measured +0.1 .. +0.3 % on the forward (profiles/round5_gemm.md section 3)
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_xcd_on.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+}  // namespace
+
+extern "C" int visrep_set_xcd_balance(int on) {
+    const int old = xcd_enabled() ? 1 : 0;
+    g_xcd_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return old;
+}
+extern "C" int visrep_debug_xcd_balance(float* rel8, unsigned* updates) {     // the record of the most recent planned launch on this device
+    const int dev = visrep_device();
+    std::lock_guard<std::mutex> lk(g_xcd_mu);
+    const XcdState& st = g_xcd[dev];
+    const XcdRecord* r = st.last >= 0 ? &st.rec[st.last] : nullptr;
+    if (rel8) for (int y = 0; y < 8; ++y) rel8[y] = r ? r->rel[y] : 1.f;
+    if (updates) *updates = r ? r->updates : 0u;
+    return xcd_enabled() ? 1 : 0;
+}
+
+// The split itself (pure host arithmetic, exported for tests): whole rounds (one tile on each of an XCD's grid / 8 blocks) in proportion to speed
+// (rel8 = time per round of each XCD, any positive scale), the leftover rounds and the last partial round to whoever would finish first.
+// bounds9[x] .. bounds9[x + 1] = XCD x's tile indices, bounds9[8] = ntiles.  Returns 0, or -1 for arguments the kernel does not take.
+extern "C" int visrep_debug_xcd_split(const float* rel8, int grid, int ntiles, int* bounds9) {
+    if (!rel8 || !bounds9 || grid < 8 || (grid & 7) || ntiles < grid) return -1;
+    for (int y = 0; y < 8; ++y) if (!(rel8[y] > 0.f)) return -1;
+    const int per8 = grid >> 3, rounds = ntiles / per8, rem = ntiles - rounds * per8;
+    float inv = 0.f;
+    for (int y = 0; y < 8; ++y) inv += 1.f / rel8[y];
+    int R[8], tot = 0;
+    for (int y = 0; y < 8; ++y) { R[y] = (int)((float)rounds / (rel8[y] * inv)); tot += R[y]; }
+    for (; tot < rounds; ++tot) {
+        int best = 0;
+        for (int y = 1; y < 8; ++y) if ((R[y] + 1) * rel8[y] < (R[best] + 1) * rel8[best]) best = y;
+        ++R[best];
+    }
+    for (; tot > rounds; --tot) {                                // (floating-point rounding of the floors above; not expected)
+        int worst = 0;
+        for (int y = 1; y < 8; ++y) if (R[y] * rel8[y] > R[worst] * rel8[worst]) worst = y;
+        --R[worst];
+    }
+    int first = 0;
+    for (int y = 1; y < 8; ++y) if (R[y] * rel8[y] < R[first] * rel8[first]) first = y;
+    int acc = 0;
+    for (int y = 0; y < 8; ++y) { bounds9[y] = acc; acc += R[y] * per8 + (y == first ? rem : 0); }
+    bounds9[8] = acc;
+    return 0;
+}
+
+void visrep_xcd_plan(GemmArgs& a, hipStream_t s, int grid, int ntiles, const void* fn) {
+    a.xb = nullptr; a.xb_host = nullptr; a.xb_seq = 0; a.xcd_bounds[8] = 0;
+    if (!xcd_enabled() || grid < 64 || (grid & 7) || ntiles < 8 * grid) return;     // a full chip and at least eight rounds of tiles per block
+    const int dev = visrep_device();
+    std::lock_guard<std::mutex> lk(g_xcd_mu);
+    XcdState& st = g_xcd[dev];
+    if (st.failed) return;
+    if (!st.dev) {                                               // first eligible launch on this device: allocate (never during a stream capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+        VisrepXcdDev* d = nullptr; VisrepXcdHost* h = nullptr;
+        if (hipMalloc(&d, XCD_RECORDS * sizeof(VisrepXcdDev)) != hipSuccess || hipMemset(d, 0, XCD_RECORDS * sizeof(VisrepXcdDev)) != hipSuccess ||
+            hipHostMalloc(&h, XCD_RECORDS * sizeof(VisrepXcdHost), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError(); st.failed = true; return;
+        }
+        memset(h, 0, XCD_RECORDS * sizeof(VisrepXcdHost));
+        st.dev = d; st.host = h;
+    }
+    int k = -1;
+    for (int i = 0; i < st.used; ++i)
+        if (st.rec[i].fn == fn && st.rec[i].M == a.M && st.rec[i].N == a.N && st.rec[i].K == a.K) { k = i; break; }
+    if (k < 0) {
+        if (st.used == XCD_RECORDS) return;                      // table full: further shapes run with equal shares
+        k = st.used++;
+        st.rec[k].fn = fn; st.rec[k].M = a.M; st.rec[k].N = a.N; st.rec[k].K = a.K;
+    }
+    XcdRecord& r = st.rec[k];
+    st.last = k;
+    VisrepXcdHost* host = st.host + k;
+    // a new measurement?  (plain reads of pinned memory the device writes: a stale or half-updated set of floats only delays the update)
+    const unsigned seq = host->seq;
+    if (seq != r.seen) {
+        r.seen = seq;
+        float t[8], mean = 0.f, lo = 1e30f, hi = 0.f;
+        for (int y = 0; y < 8; ++y) { t[y] = host->tile_ticks[y]; mean += t[y] * 0.125f; lo = t[y] < lo ? t[y] : lo; hi = t[y] > hi ? t[y] : hi; }
+        if (lo > 0.f && hi < 1.25f * lo) {                       // a clean sample: every XCD reported, spread within what clocks explain
+            const float w = r.updates == 0 ? 1.f : 0.35f;        // the first sample replaces the prior, later ones are smoothed in
+            for (int y = 0; y < 8; ++y) r.rel[y] = (1.f - w) * r.rel[y] + w * t[y] / mean;
+            ++r.updates;
+        }
+    }
+    visrep_debug_xcd_split(r.rel, grid, ntiles, a.xcd_bounds);
+    const unsigned q = ++r.launches;
+    if ((q & 7) == 4) { a.xb = st.dev + k; a.xb_host = host; a.xb_seq = q; }     // launches 4, 12, 20, ... of this record are measurements
+}
 
 bool visrep_gemm_v5_supports(const GemmArgs& a) {
     if (a.epi == EPI_F32X && (a.ksplit <= 0 || a.ksplit % TK || a.K % a.ksplit || a.K / a.ksplit < 1 || a.K / a.ksplit > 8)) return false;

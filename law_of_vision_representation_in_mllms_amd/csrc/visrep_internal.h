@@ -62,9 +62,22 @@ struct GemmArgs {
     const float* resid32;
     bf16_t* planes;
     int ldp, out_planes;
+    // XCD-weighted tile split of the persistent 256x256 kernel (gemm_bf16_v5.hip, visrep_xcd_plan): the eight XCDs of an MI355X run at
+    // their own clocks under the power limit (measured: +-4 % around the mean inside one launch), so with equal shares of the tile list the
+    // launch ends when the slowest XCD does.  xcd_bounds[x] .. xcd_bounds[x + 1] = the tile indices of XCD x (xcd_bounds[8] = 0: equal
+    // shares); xb / xb_host / xb_seq: a sampled launch (xb != null) records when each XCD finished, its last block turns that into tile times
+    // and leaves them in pinned host memory, from where the next plans are made.  Results do not depend on the split.
+    struct VisrepXcdDev* xb;
+    struct VisrepXcdHost* xb_host;
+    unsigned xb_seq;
+    int xcd_bounds[9];
     unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };
+
+struct VisrepXcdSlot { unsigned long long t_end[8]; unsigned long long t_start; unsigned done, pad; };   // 100-MHz ticks (s_memrealtime)
+struct VisrepXcdDev { VisrepXcdSlot slot[16]; };                      // device memory; a slot serves one sampled launch at a time and is left zeroed by its last block
+struct VisrepXcdHost { float tile_ticks[8]; unsigned seq; unsigned pad; };   // pinned host memory: the last sampled launch's time per round of tiles, per XCD
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int visrep_a_row(const GemmArgs& p, int r) {          // logical -> physical row of A / ln_rt
@@ -80,6 +93,9 @@ int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v4_supports(const GemmArgs& a);
 int visrep_gemm_v4_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v5_supports(const GemmArgs& a);
+// Fills a.xcd_bounds (and, on every 8th launch of this (kernel, M, N, K), a.xb / a.xb_host / a.xb_seq) for a launch of `grid` persistent blocks
+// over `ntiles` output tiles on the current device.  VISREP_XCD_BALANCE=0 / visrep_set_xcd_balance(0): equal shares, nothing recorded.
+void visrep_xcd_plan(GemmArgs& a, hipStream_t s, int grid, int ntiles, const void* kernel);
 bool visrep_gemm_v5_supports_conv(const GemmArgs& a);
 int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v3_supports(const GemmArgs& a);

@@ -121,6 +121,33 @@ def test_gemm_v2_many_tiles_per_block_and_reuse(gemm_variant):
         assert max_err(out, want) < 1e-5
 
 
+def test_gemm_xcd_weighted_tile_split_is_bitwise_neutral():
+    """visrep_set_xcd_balance(1): per (kernel, shape) every 8th launch records when each XCD finished and the following launches give the XCDs
+    whole rounds of tiles in proportion to their speed.  Which block computes a tile must not show in the result: 40 launches (five
+    measurements folded in) equal the equal-shares result bitwise, the record reports its measurements, and the knob restores."""
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 256 * 288, 2048, 256                 # 2304 tiles = nine rounds on 256 CUs
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    lib = _lib.load()
+    want = engine.gemm(a, w, bias, _lib.EPI_ACT, act="quick_gelu")
+    torch.cuda.synchronize()
+    old = lib.visrep_set_xcd_balance(1)
+    try:
+        assert _lib.xcd_balance()["on"]
+        for i in range(40):
+            got = engine.gemm(a, w, bias, _lib.EPI_ACT, act="quick_gelu")
+            if i % 8 == 7:
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), i
+        st = _lib.xcd_balance()
+        assert st["updates"] >= 3 and all(0.8 < r < 1.25 for r in st["rel"]) and abs(sum(st["rel"]) / 8 - 1.0) < 0.02, st
+    finally:
+        lib.visrep_set_xcd_balance(old)
+    assert _lib.xcd_balance()["on"] == bool(old)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(577 * 3, 512, 256, "bias"), (300, 256, 1024, "act"), (1000, 1024, 256, "vt"), (70000, 256, 1024, "bias"),
                                         (256, 2048, 1024, "act")])
 def test_gemm_with_folded_layernorm(M, N, K, epi, gemm_variant):
