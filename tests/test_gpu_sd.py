@@ -867,6 +867,51 @@ def test_sd15_768px_sweep_launch_shape_parity_and_routes(monkeypatch):
     assert e_hip < max(1.5 * e_ref, 2e-2), (e_hip, e_ref)
 
 
+@pytest.mark.parametrize("tower_id,PX,tol", [('stabilityai/stable-diffusion-2-1', 768, 1.5), ('stabilityai/stable-diffusion-xl-base-1.0', 512, 2.0),
+                                            ('lambdalabs/sd-image-variations-diffusers', 768, 1.5)])
+def test_sd_family_at_the_sweeps_launch_shape(monkeypatch, tower_id, PX, tol):
+    """SD2.1 (Linear proj_in / proj_out, 64-wide heads, 1024-wide prompt), SDXL (2 / 10 transformer layers per attention,
+    2048-wide two-encoder prompt) and the image-variation tower (per-image CLIP context) at FULL width and at the resolution and launch size the
+    sweep runs them with (sweep.SETTINGS: 768 / 512 / 768 px, 16 images of a 32-image launch's two halves), one image of the launch against the fp32 CPU
+    oracle, bounded by the oracle's own bf16 run.  Until round 5 these were pinned at tiny width / 128 px only."""
+    from types import SimpleNamespace
+    from law_of_vision_representation_in_mllms_amd import _lib
+    from law_of_vision_representation_in_mllms_amd.llava.model.multimodal_encoder import builder as B
+    monkeypatch.setenv("VISREP_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("VISREP_FAST_SYNTHETIC", "cuda")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    NB = 16
+    args = SimpleNamespace(vision_tower=tower_id, up_ft_index=0, t=261, prompt="a photo of a cat", ensemble_size=1, img_size=PX)
+    feat = B.build_diffusion_vision_tower(args).vision_tower
+    sp = feat.spec
+    rs = np.random.RandomState(37)
+    imgs = torch.from_numpy(rs.uniform(-1, 1, (NB, 3, PX, PX)).astype(np.float32))
+    post = torch.from_numpy(rs.standard_normal((NB, 4, PX // 8, PX // 8)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((NB, 4, PX // 8, PX // 8)).astype(np.float32))
+    _lib.routes(reset=True)
+    got = feat.forward(imgs, args.prompt, t=261, up_ft_index=0, ensemble_size=1, post_noise=post, ddim_noise=ddim)     # [NB, c, h, w]
+    r = _lib.routes(reset=True)
+    assert got.shape[0] == NB and torch.isfinite(got.float()).all()
+    C, h, w = got.shape[1:]
+    k = 9                                                                                                               # the checked image: inside the launch
+    drop = tuple(f"up_blocks.{i}" for i in range(1, 4))
+    wu = {kk: v.float().cpu() for kk, v in feat._wu.items() if not kk.startswith(drop)}
+    wv = {kk: v.float().cpu() for kk, v in feat._wv.items()}
+    if hasattr(feat, "encode_image"):                                                                                   # image-variation tower: the image's own CLIP embedding is the context
+        ctx = feat.encode_image(imgs[k:k + 1]).float().cpu()                                                            # [1, 1, cross_dim]
+        want = OD.imsd_features(sp, wu, wv, imgs[k:k + 1], ctx, post[k:k + 1], ddim[k:k + 1], t=261, up_ft_index=0, ensemble_size=1)
+        ref_bf16 = OD.imsd_features(sp, wu, wv, imgs[k:k + 1], ctx, post[k:k + 1], ddim[k:k + 1], t=261, up_ft_index=0, ensemble_size=1, dtype=torch.bfloat16)
+    else:
+        ctx = feat.encode_prompt(args.prompt).float().cpu()
+        want = OD.sd_features(sp, wu, wv, imgs[k:k + 1], ctx, post[k:k + 1], ddim[k:k + 1], t=261)                      # [1, h w, C]
+        ref_bf16 = OD.sd_features(sp, wu, wv, imgs[k:k + 1], ctx, post[k:k + 1], ddim[k:k + 1], t=261, dtype=torch.bfloat16)
+    got_tok = got[k].permute(1, 2, 0).reshape(1, h * w, C)
+    e_hip, e_ref = rel_err(got_tok, want), rel_err(ref_bf16, want)
+    print(f"{tower_id} @{PX} px, image {k} of a {NB}-image launch: HIP {e_hip:.3e}  oracle bf16 {e_ref:.3e}  routes {r}")
+    assert e_hip < max(tol * e_ref, 3e-2), (e_hip, e_ref)
+    assert r["conv_256"] + r["conv_halo"] >= 8 and r["attn"] >= 4 and r["attn_wide"] >= 1, r       # the full-size routes (counted over the warm-up and the captured pass), not the small-image ones
+
+
 def test_vae_mid_block_attention_at_9216_tokens():
     """the 768-px VAE's mid-block attention (96 x 96 = 9,216 latent pixels, ONE head of width 512: fp32 score GEMM ->
     softmax_rows -> role-swapped V^T GEMM -> P V GEMM, per image through HBM) was only ever compared at 1,024 tokens.  Here at the real token
