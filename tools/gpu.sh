@@ -43,7 +43,7 @@ for step in "$@"; do
         done; done; unset VISREP_LIB ;;
     trace) rm -rf $O/$i.trace; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$i.trace -- python $arg > $O/$i.trace.log 2>&1; echo "[$i trace] rc=$?"
            python tools/summarize_pmc.py $O/$i.trace > $O/$i.trace.md 2>/dev/null; head -30 $O/$i.trace.md ;;
-    pmc) ctr=${arg%%:*}; cmd=${arg#*:}; rm -rf $O/$i.pmc; timeout 1200 rocprofv3 --pmc ${ctr//,/ } --output-format csv -d $O/$i.pmc -- python $cmd > $O/$i.pmc.log 2>&1; echo "[$i pmc $ctr] rc=$?"
+    pmc) ctr=${arg%%:*}; cmd=${arg#*:}; rm -rf $O/$i.pmc; timeout 400 rocprofv3 --pmc ${ctr//,/ } --output-format csv -d $O/$i.pmc -- python $cmd > $O/$i.pmc.log 2>&1; echo "[$i pmc $ctr] rc=$?"
          python tools/summarize_pmc.py $O/$i.pmc > $O/$i.pmc.md 2>/dev/null; head -20 $O/$i.pmc.md ;;
     py) timeout 1200 python $arg > $O/$i.log 2>&1; echo "[$i py $arg] rc=$?"; tail -25 $O/$i.log | cut -c1-400 ;;
     *) echo "unknown step $step" ;;
