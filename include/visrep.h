@@ -79,7 +79,8 @@ enum {
     VISREP_ROUTE_ATTN_WIDE = 8,      /* attn_fwd_wide (head width 512) */
     VISREP_ROUTE_ATTN_CLS = 9,       /* attn_fwd_cls (image-aligned CLS towers) */
     VISREP_ROUTE_CONV_HALO = 10,     /* conv3x3_halo: halo-resident 3x3 convolution with the input's GroupNorm + SiLU fused */
-    VISREP_ROUTE_COUNT = 11
+    VISREP_ROUTE_CONV_C8 = 11,       /* conv3x3_c8: the VAE's first convolution straight from 8-channel pixel tokens (no im2col) */
+    VISREP_ROUTE_COUNT = 12
 };
 int visrep_debug_routes(long* out, int reset);
 /* Matrix-pipe ceiling of THIS device under THIS process' conditions: `iters` bursts of 32 dependent-free v_mfma_f32_16x16x32_bf16 per wave,
@@ -439,6 +440,17 @@ int visrep_groupnorm_from_partials(const void* x, const float* gamma, const floa
 int visrep_conv3x3_halo_supported(int B, int H, int W, int C, int Cout);
 int visrep_conv3x3_bf16_halo(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
                              int epilogue, const void* resid, const void* gn_table, int silu, void* gn_partial, int groups_out, void* stream);
+
+/* ---- The VAE encoder's first convolution (diffusers vae.py Encoder.conv_in: Conv2d(3, 128, 3, padding = 1); dift_sd.py:172 vae.encode) without
+ * im2col: x [B*H*W, 8] bf16 tokens (visrep_nchw_to_tokens with Cpad = 8), Wt [128, ldw >= 96] in K order (ky, kx, c8) with zero padding columns (the
+ * packer's im2col layout), out [B*H*W, ldc].  The MFMA's pixel operand is read straight from the neighbour pixels' 16-byte tokens (one global load
+ * per lane and k-step, zeros outside the image), nothing is staged; the epilogue is the GEMM kernels' (bias, 16-byte stores) and optionally leaves
+ * the GroupNorm partial sums of the output (gn_partial as visrep_conv3x3_bf16_gn: visrep_conv_gn_partial_bytes(B, H W, groups) bytes; NULL = none).
+ * Supported: Cout = 128, W % 16 == 0, H W % 64 == 0 (% 128 with partial sums).  Equals visrep_im2col3x3 + visrep_gemm_bf16 up to the order of
+ * the fp32 sum inside an MFMA. */
+int visrep_conv3x3_c8_supported(int B, int H, int W, int Cout);
+int visrep_conv3x3_c8_bf16(const void* x, int B, int H, int W, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
+                           void* gn_partial, int groups, void* stream);
 /* The statistics half of GroupNorm on its own: stats[b, g] = (mean, rstd) fp32 pairs [B, groups], from a read-only pass over x
  * (visrep_groupnorm_stats; workspace of visrep_groupnorm_workspace_bytes) or from a producing convolution's partial sums
  * (visrep_groupnorm_stats_from_partials, HW % 64 == 0) - and the per-(image, channel) (scale, shift) table the fused convolution

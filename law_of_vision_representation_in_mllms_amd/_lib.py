@@ -66,6 +66,8 @@ SIGNATURES = {
     "visrep_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_conv_gn_supported": (_i, [_i, _i, _i, _i]),
     "visrep_conv_gn_supported_epi": (_i, [_i, _i, _i, _i, _i]),
+    "visrep_conv3x3_c8_supported": (_i, [_i, _i, _i, _i]),
+    "visrep_conv3x3_c8_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "visrep_conv_gn_partial_bytes": (_sz, [_i, _i, _i]),
     "visrep_conv3x3_bf16_gn": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "visrep_groupnorm_from_partials": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
@@ -165,7 +167,7 @@ def load(build_if_missing: bool = True):
         return lib
 
 
-ROUTES = ("gemm_256", "gemm_128", "gemm_tail", "splitk", "conv_256", "conv_128", "conv_128_gn", "attn", "attn_wide", "attn_cls", "conv_halo")
+ROUTES = ("gemm_256", "gemm_128", "gemm_tail", "splitk", "conv_256", "conv_128", "conv_128_gn", "attn", "attn_wide", "attn_cls", "conv_halo", "conv_c8")
 
 
 def xcd_balance() -> dict:

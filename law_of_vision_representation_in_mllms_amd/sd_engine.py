@@ -104,6 +104,24 @@ def conv3x3(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, stri
     return out, Ho, Wo
 
 
+def conv3x3_c8(x: torch.Tensor, B: int, H: int, W: int, w: torch.Tensor, bias, gn_groups: int = 0):
+    """3x3 convolution (stride 1, padding 1) of 8-channel pixel tokens x [B*H*W, 8] to 128 channels without im2col (visrep_conv3x3_c8_bf16: the
+    VAE encoder's conv_in); w [128, >= 96] in the im2col packer's K order.  Returns out [B*H*W, 128], plus the GroupNorm partial sums of the
+    output when gn_groups > 0."""
+    lib = _lib.require_gpu()
+    N = w.shape[0]
+    out = torch.empty(B * H * W, N, dtype=torch.bfloat16, device=x.device)
+    partial = torch.empty(lib.visrep_conv_gn_partial_bytes(B, H * W, gn_groups), dtype=torch.uint8, device=x.device) if gn_groups else None
+    rc = lib.visrep_conv3x3_c8_bf16(_lib.ptr(x), B, H, W, _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(out), out.stride(0), N,
+                                    _lib.ptr(partial), int(gn_groups), _lib.stream_ptr())
+    _lib.check(rc, "visrep_conv3x3_c8_bf16")
+    return (out, partial) if gn_groups else out
+
+
+def conv_c8_supported(B: int, H: int, W: int, Cout: int) -> bool:
+    return bool(_lib.load().visrep_conv3x3_c8_supported(int(B), int(H), int(W), int(Cout)))
+
+
 def conv_halo_supported(B: int, H: int, W: int, C: int, Cout: int) -> bool:
     return bool(_lib.load().visrep_conv3x3_halo_supported(int(B), int(H), int(W), int(C), int(Cout)))
 
@@ -234,6 +252,7 @@ class SdEngine:
         self.vae_flash = os.environ.get("VISREP_VAE_FLASH", "1") != "0"      # 0: the materialised-score route (A/B, tools/)
         self.fuse_gn_stats = os.environ.get("VISREP_GN_FUSE", "1") != "0"    # 0: every GroupNorm reads its input twice (A/B, tools/)
         self.fuse_gn_256 = os.environ.get("VISREP_GN_FUSE_256", "1") != "0"  # 0: partial sums from the 128x128 kernel only, as in round 4 (A/B)
+        self.conv_c8 = os.environ.get("VISREP_CONV_C8", "1") != "0"          # 0: the VAE's conv_in as im2col + GEMM, as until round 5 (A/B)
         self.conv_halo = os.environ.get("VISREP_CONV_HALO", "1") != "0"      # 0: the 128-channel layers keep apply pass + implicit-GEMM convolution (A/B, tools/)
         # 128 -> 256 layers (one per VAE): the kernel's Cout = 256 variant is correct but measured SLOWER than the persistent 256x256 convolution
         # + apply pass (1.80 against 1.48 ms at 384^2 x 16: 128 accumulators leave no registers for double-buffered fragments) - opt-in only
@@ -440,6 +459,14 @@ class SdEngine:
                     out._visrep_gn = (partial, gn)                       # rides on the tensor object: dies with it, never matches another tensor
                     return out, Ho, Wo
             return conv3x3(x, B, H, W, lin.w, lin.b, stride, pad_mode, upsample, epi, resid)
+        if (self.conv_c8 and x.shape[1] == 8 and stride == 1 and pad_mode == 0 and not upsample and epi == _lib.EPI_BIAS
+                and lin.w.shape[0] == lin.n and conv_c8_supported(B, H, W, lin.n)):        # the VAE's conv_in: straight from the pixel tokens
+            emit = gn if (gn and self.fuse_gn_stats and (H * W) % 128 == 0 and lin.n // gn in (4, 8, 16)) else 0
+            res = conv3x3_c8(x, B, H, W, lin.w, lin.b, emit)
+            if emit:
+                res[0]._visrep_gn = (res[1], gn)
+                return res[0], H, W
+            return res, H, W
         cols, Ho, Wo = im2col3x3(x, B, H, W, lin.w.shape[1], stride, pad_mode, upsample)       # 3 / 4-channel inputs (padded to 8)
         return gemm(cols, lin.w, lin.b, epi, resid=resid), Ho, Wo
 
@@ -529,7 +556,7 @@ class SdEngine:
         B, _, H, W = img.shape
         g = v.groups
         x = nchw_to_tokens(img.to(self.device).contiguous(), 8)
-        h, _, _ = self._conv(x, B, H, W, "vae.conv_in")
+        h, _, _ = self._conv(x, B, H, W, "vae.conv_in", gn=g)
         for i in range(len(v.block_out)):
             for j in range(v.layers_per_block):
                 h = self._resnet(h, B, H, W, f"encoder.down_blocks.{i}.resnets.{j}", g, 1e-6)

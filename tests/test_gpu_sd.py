@@ -189,6 +189,41 @@ def test_conv3x3_emits_groupnorm_partials(B, H, W, Ci, Co, stride, pad_mode):
     assert rel_err(got, tokens(ref)) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 48, 80), (1, 16, 16), (2, 256, 272)])
+def test_conv3x3_c8_equals_conv2d_and_the_im2col_route(B, H, W):
+    """visrep_conv3x3_c8_bf16 (the VAE encoder's conv_in: 3 channels as 8-channel tokens -> 128, no im2col): against F.conv2d in fp32, against the
+    im2col + GEMM route it replaces (same products; the order of the fp32 sum inside an MFMA differs), zero padding at all four borders, and the
+    GroupNorm partial sums of its output against float64 statistics of the stored tensor."""
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = bf(torch.randn(B, 3, H, W, generator=g))
+    w = bf(torch.randn(128, 3, 3, 3, generator=g) / math.sqrt(27))
+    b = torch.randn(128, generator=g) * 0.3
+    want = F.conv2d(x.float(), w.float(), b, padding=1)
+    Wp = torch.zeros(128, 9, 8)
+    Wp[:, :, :3] = w.float().permute(0, 2, 3, 1).reshape(128, 9, 3)                  # K order (ky, kx, c8): sd_engine.SdEngine._conv3
+    wp = torch.zeros(128, 128)
+    wp[:, :72] = Wp.reshape(128, 72)
+    wp = bf(wp).to(DEV)
+    xt = SE.nchw_to_tokens(x.to(DEV), 8)
+    assert SE.conv_c8_supported(B, H, W, 128) and not SE.conv_c8_supported(B, H, W + 8, 128) and not SE.conv_c8_supported(B, H, W, 256)
+    _lib.routes(reset=True)
+    got = SE.conv3x3_c8(xt, B, H, W, wp, b.to(DEV))
+    assert _lib.routes()["conv_c8"] == 1
+    cols, Ho, Wo = SE.im2col3x3(xt, B, H, W, 128)
+    old = SE.gemm(cols, wp, b.to(DEV))
+    assert (Ho, Wo) == (H, W) and got.shape == old.shape == (B * H * W, 128)
+    assert (got.float() - old.float()).abs().max().item() < 2e-2 and rel_err(got, tokens(want)) < 5e-3
+    if (H * W) % 128 == 0:
+        out, part = SE.conv3x3_c8(xt, B, H, W, wp, b.to(DEV), gn_groups=32)
+        assert torch.equal(out, got)
+        st = SE.groupnorm_stats(out, B, 32, 1e-6, partial=part).double().cpu()
+        o = out.double().cpu().reshape(B, H * W, 32, 4)
+        mean, var = o.mean(dim=(1, 3)), o.var(dim=(1, 3), unbiased=False)
+        assert (st[..., 0] - mean).abs().max().item() < 2e-3 and ((st[..., 1] - (var + 1e-6).rsqrt()) / (var + 1e-6).rsqrt()).abs().max().item() < 2e-3
+    with pytest.raises(RuntimeError, match="conv3x3_c8"):
+        SE.conv3x3_c8(xt, B, H, W, wp[:, :64].contiguous(), b.to(DEV))              # fewer than 96 weight columns
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(4, 192, 192, 64, 256),       # 576 tiles: two rounds in the 256x256 kernel + a 64-tile tail in the 128x128 one (row offset)
                                          (9, 128, 120, 128, 256),      # 540 tiles, rows wrap inside a lane's pieces; 8 channels per group
                                          (8, 128, 128, 64, 512)])      # two column tiles, 16 channels per group, whole rounds only
@@ -851,6 +886,7 @@ def test_sd15_768px_sweep_launch_shape_parity_and_routes(monkeypatch):
     # what the sweep's launch shape is tuned for (profiles/round4_sd15_kernel_stats.md): asserted per route
     assert r["conv_256"] >= 16, r            # VAE 256- / 512-channel layers at 384^2 / 192^2 / 96^2: whole rounds of 256x256 tiles
     assert r["conv_halo"] == 4, r            # VAE 128-channel layers at 768^2: GroupNorm + SiLU + convolution in one kernel (conv3x3_halo)
+    assert r["conv_c8"] == 1, r              # the VAE's conv_in straight from the pixel tokens (no im2col)
     assert r["conv_128_gn"] >= 1, r          # the stride-2 128-channel downsample: 128x128 kernel, statistics from the epilogue
     assert r["attn_wide"] == 1, r            # the VAE's 512-wide single head: one flash launch for the batch
     assert r["splitk"] >= 4, r               # 12^2 / 24^2 UNet convolutions and projections: few tiles, deep K
