@@ -438,6 +438,10 @@ int visrep_groupnorm_from_partials(const void* x, const float* gamma, const floa
  * (visrep_conv_gn_partial_bytes(B, H W, groups_out) bytes; slot = 64 pixels of a 16 x 4 patch; consumed by visrep_groupnorm_stats_from_partials
  * / visrep_groupnorm_from_partials).  Supported: C = 128, Cout in {128, 256}, H and W multiples of 16 (visrep_conv3x3_halo_supported). */
 int visrep_conv3x3_halo_supported(int B, int H, int W, int C, int Cout);
+/* Tile height of the Cout = 128 kernel: 16 (default; 16 x 16-pixel tiles, 8 waves, 147 KB of LDS: one workgroup per CU) or 8 (16 x 8 tiles, 4 waves,
+ * 77 KB: two workgroups per CU, one's halo phase under the other's K loop - measured 3 % slower, kept as a tested variant).  Results are bitwise the
+ * same.  Process-wide (also VISREP_HALO_TILE=8 in the environment); returns the previous value, < 0 for another argument. */
+int visrep_set_conv_halo_tile(int rows);
 int visrep_conv3x3_bf16_halo(const void* x, int B, int H, int W, int C, const void* Wt, int ldw, const float* bias, void* out, int ldc, int Cout,
                              int epilogue, const void* resid, const void* gn_table, int silu, void* gn_partial, int groups_out, void* stream);
 

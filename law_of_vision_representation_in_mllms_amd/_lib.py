@@ -66,6 +66,7 @@ SIGNATURES = {
     "visrep_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "visrep_conv_gn_supported": (_i, [_i, _i, _i, _i]),
     "visrep_conv_gn_supported_epi": (_i, [_i, _i, _i, _i, _i]),
+    "visrep_set_conv_halo_tile": (_i, [_i]),
     "visrep_conv3x3_c8_supported": (_i, [_i, _i, _i, _i]),
     "visrep_conv3x3_c8_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "visrep_conv_gn_partial_bytes": (_sz, [_i, _i, _i]),

@@ -18,6 +18,7 @@
 //   * epilogue: bias (+ residual), 16-byte stores, and optionally the GroupNorm partial sums of the OUTPUT (per 64-pixel wave slot and
 //     group) for the norm that follows - so a ResnetBlock2D is two launches + two tiny table kernels, no apply pass, no statistics pass.
 // Scope: Cin = 128, Cout in {128, 256}, stride 1, padding 1, H and W multiples of 16.  Everything else keeps the implicit-GEMM kernels.
+#include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "visrep_internal.h"
@@ -31,8 +32,9 @@
 
 namespace {
 
-constexpr int HT = 16, HP = HT + 2, HPIX = HP * HP, HC = 128;
-constexpr int HALO_BYTES = HPIX * HC * 2;                       // 82,944
+constexpr int HT = 16, HP = HT + 2, HC = 128;                   // tile width (and the full tile's height), halo width, input channels
+constexpr int halo_pixels(int ty) { return (ty + 2) * HP; }     // TY output rows: 16 (one workgroup of 8 waves per CU) or 8 (4 waves, two workgroups per CU)
+constexpr int halo_bytes(int ty) { return halo_pixels(ty) * HC * 2; }      // 82,944 / 46,080
 constexpr int HROW = HP * 256;                                  // bytes per halo pixel row (18 pixels x 256 B)
 constexpr int NKT = 18;                                         // K-tiles: 9 taps x 2 channel halves of 64
 
@@ -88,29 +90,33 @@ VR_DEV void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// NJ: 16-column blocks per wave (4: Cout 128, 8: Cout 256); NW: W ring slots
-template <int NJ, int NW, bool RESID>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
+// NJ: 16-column blocks per wave (4: Cout 128, 8: Cout 256); NW: W ring slots; TY: output rows per tile.  TY = 16: 8 waves as 4 (M) x 2 (N), 147 KB of
+// LDS, one workgroup per CU - its halo phase runs with the matrix pipe idle (the default).  TY = 8 (round 5, second half): 4 waves as 2 x 2, a 10-row halo
+// (46 KB) + a two-slot W ring (32 KB) = 77 KB: TWO workgroups per CU, one's halo phase under the other's K loop, for 11 % more halo bytes per output pixel -
+// built to hide the halo phase, measured 3 % slower (2.99 against 2.90 ms), kept as a tested variant (visrep_set_conv_halo_tile).
+template <int NJ, int NW, bool RESID, int TY = 16>
+__global__ __launch_bounds__((TY / 4) * 128, 2) void conv3x3_halo(const HaloArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int COUT = NJ * 32, WT = COUT * 128, P = COUT / 64, D = NW - 1;
+    constexpr int NT = (TY / 4) * 128, HPIX = halo_pixels(TY), HALO_BYTES = halo_bytes(TY);
+    constexpr int COUT = NJ * 32, WT = COUT * 128, P = COUT * 8 / NT, D = NW - 1;
     static_assert(D >= 1 && P * D <= 8, "ring depth");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, hg = lane >> 4;
     char* const halo = smem;
     char* const wring = smem + HALO_BYTES;
 
-    // ---- W staging: piece j covers chunk c = j * 512 + tid: row c >> 3, physical slot c & 7 <- logical slot (c & 7) ^ ((row >> 1) & 7)
+    // ---- W staging: piece j covers chunk c = j * NT + tid: row c >> 3, physical slot c & 7 <- logical slot (c & 7) ^ ((row >> 1) & 7)
     unsigned wofs[P];                                            // element offset of this lane's chunk inside W (32 bits: scalar base + vector offset addressing)
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        const int c = j * 512 + tid, row = c >> 3;
+        const int c = j * NT + tid, row = c >> 3;
         wofs[j] = (unsigned)row * (unsigned)p.ldw + (unsigned)((((c & 7) ^ ((row >> 1) & 7))) << 3);
     }
     int g_issue = 0;                                             // stream index of the next W tile to issue
     auto issue_w = [&](int kt_issue) {                           // kt_issue: compile-time at every call site (K offset = an immediate)
         char* dst = wring + (g_issue % NW) * WT + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < P; ++j) glds16(p.w + (wofs[j] + (unsigned)(kt_issue * 64)), dst + j * 8192);
+        for (int j = 0; j < P; ++j) glds16(p.w + (wofs[j] + (unsigned)(kt_issue * 64)), dst + j * (NT * 16));
         ++g_issue;
     };
 
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
     const unsigned wring_off = lds_off(wring);
     const unsigned wadr0 = wring_off + wfrag + (0u ^ whi), wadr1 = wring_off + wfrag + (64u ^ whi);      // k-step 0 / 1 of slot 0
 
-    // ---- halo fill: task q = it * 512 + tid -> pixel q >> 4, chunk q & 15 = tid & 15 (fixed per thread: its (scale, shift) octet is loaded once per tile)
+    // ---- halo fill: task q = it * NT + tid -> pixel q >> 4, chunk q & 15 = tid & 15 (fixed per thread: its (scale, shift) octet is loaded once per tile)
     const int chunk = tid & 15;
 
     // prologue of the W stream
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
     const int G = gridDim.x;
     const int lid = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);      // blocks of one XCD (b % 8) walk neighbouring tiles: shared halo rows in L2
     const int tstride = ((G + 7) >> 3) * 8;
-    constexpr int NIT = (HPIX * 16 + 511) / 512;                // 11 sixteen-byte tasks per thread and halo
+    constexpr int NIT = (HPIX * 16 + NT - 1) / NT;              // 11 (TY = 16) / 12 (TY = 8) sixteen-byte tasks per thread and halo
     // ---- the halo of a tile in three steps, so that the NEXT tile's halo can be fetched and normalised under this tile's MFMAs (PREFETCH, the
     // Cout = 128 variant): load (global -> registers), transform (GroupNorm + SiLU in registers), store (registers -> LDS, after the barrier
     // that ends the readers of the current halo).  sc / sh always belong to the halo that is transformed next.
@@ -158,12 +164,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
     };
     auto halo_load = [&](int t) {                                // branch-free: a task outside the image loads a clamped (valid) address and is zeroed
         const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;    // by the transform - a divergent `if (inside) load` costs a vmcnt(0) per task
-        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * HT, x0 = tx * HT;
+        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * TY, x0 = tx * HT;
         const bf16_t* img = p.x + (size_t)b * p.H * p.W * HC + chunk * 8;
         inmask = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int q = it * 512 + tid, pix = q >> 4;
+            const int q = it * NT + tid, pix = q >> 4;
             const int hy = pix / HP, hx = pix - hy * HP;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
             const bool in = pix < HPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
     auto halo_store = [&]() {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int q = it * 512 + tid, pix = q >> 4;
+            const int q = it * NT + tid, pix = q >> 4;
             if (pix >= HPIX) continue;
             const int hx = pix - (pix / HP) * HP;
             *reinterpret_cast<u32x4*>(halo + pix * 256 + ((chunk ^ halo_swz(hx)) << 4)) = raw[it];
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
     bool staged = false;                                         // raw[] holds this tile's halo, normalised, waiting for its LDS store
     for (int t = lid; t < p.ntiles; t += tstride) {
         const int b = t / p.tiles_per_img, r = t - b * p.tiles_per_img;
-        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * HT, x0 = tx * HT;
+        const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x, y0 = ty * TY, x0 = tx * HT;
         // ------------------------------------------------------------ halo
         if (!staged) {                                           // first tile of the block (or no prefetch): fetch and normalise here
             halo_load(t);                                        // eleven 16-byte loads in flight, then the (scale, shift) octet behind them
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo(const HaloArgs p) {
         });
         if (p.gn_partial) {                                      // slot = this wave's 64 pixels (tile, wm); groups of this wave's columns
             const int Gn = COUT / p.gn_cpg, nblk = (p.H * p.W) >> 6;
-            float2* dst = p.gn_partial + ((size_t)b * nblk + (size_t)r * 4 + wm) * Gn;
+            float2* dst = p.gn_partial + ((size_t)b * nblk + (size_t)r * (TY / 4) + wm) * Gn;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float s1 = sum_over_fr(gs1[j]), s2 = sum_over_fr(gs2[j]);
@@ -385,18 +391,39 @@ __global__ __launch_bounds__(256) void gn_table_kernel(const float2* __restrict_
     tab[i] = float2{gsc, __builtin_fmaf(-st.x, gsc, beta[c])};
 }
 
-template <int NJ, int NW, bool RESID>
-int launch_halo(const HaloArgs& a, hipStream_t s) {
-    constexpr int LDS = HALO_BYTES + NW * NJ * 32 * 128;
+template <int NJ, int NW, bool RESID, int TY = 16>
+int launch_halo(HaloArgs a, hipStream_t s) {
+    constexpr int LDS = halo_bytes(TY) + NW * NJ * 32 * 128;
     static VisrepLdsOptIn opt;
-    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(conv3x3_halo<NJ, NW, RESID>), LDS);
-    const int ncu = visrep_cu_count();
+    visrep_lds_opt_in(opt, reinterpret_cast<const void*>(conv3x3_halo<NJ, NW, RESID, TY>), LDS);
+    a.tiles_x = a.W / HT; a.tiles_per_img = (a.H / TY) * (a.W / HT); a.ntiles = a.B * a.tiles_per_img;
+    const int cap = visrep_cu_count() * (TY == 16 ? 1 : 2) / 8 * 8;     // resident workgroups: one (147 KB of LDS) or two (77 KB) per CU
     const int want = (a.ntiles + 7) / 8 * 8;                     // a multiple of 8: the XCD-contiguous tile walk is a bijection then (idle blocks just exit)
-    hipLaunchKernelGGL((conv3x3_halo<NJ, NW, RESID>), dim3(want < ncu ? want : ncu / 8 * 8), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((conv3x3_halo<NJ, NW, RESID, TY>), dim3(want < cap ? want : cap), dim3((TY / 4) * 128), LDS, s, a);
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "conv3x3_halo: launch failed");
 }
 
 }  // namespace
+
+namespace {
+std::atomic<int> g_halo_tile{0};                                 // 0: not decided yet (VISREP_HALO_TILE), else 8 | 16
+int halo_tile_rows() {
+    int v = g_halo_tile.load(std::memory_order_relaxed);
+    if (!v) {
+        const char* e = getenv("VISREP_HALO_TILE");
+        v = (e && atoi(e) == 8) ? 8 : 16;                       // 16 x 8 tiles measured 3 % slower (profiles/round5_sd15_kernel_stats.md section 1)
+        g_halo_tile.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+}  // namespace
+
+extern "C" int visrep_set_conv_halo_tile(int rows) {             // 16 (default: one workgroup per CU) | 8 (two); process-wide; returns the previous value
+    if (rows != 8 && rows != 16) return visrep_set_error(VISREP_ERR_ARG, "conv_halo tile rows must be 8 or 16");
+    const int old = halo_tile_rows();
+    g_halo_tile.store(rows, std::memory_order_relaxed);
+    return old;
+}
 
 extern "C" int visrep_conv3x3_halo_supported(int B, int H, int W, int C, int Cout) {
     return (B > 0 && C == HC && (Cout == 128 || Cout == 256) && H >= HT && W >= HT && H % HT == 0 && W % HT == 0 &&
@@ -431,10 +458,10 @@ extern "C" int visrep_conv3x3_bf16_halo(const void* x, int B, int H, int W, int 
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)Wt; a.bias = bias; a.resid = (const bf16_t*)resid; a.out = (bf16_t*)out;
     a.gn_tab = (const float2*)gn_table; a.gn_partial = (float2*)gn_partial;
     a.B = B; a.H = H; a.W = W; a.ldw = ldw; a.ldc = ldc; a.silu = silu; a.gn_cpg = cpg;
-    a.tiles_x = W / HT; a.tiles_per_img = (H / HT) * (W / HT); a.ntiles = B * a.tiles_per_img;
     hipStream_t s = (hipStream_t)stream;
     visrep_count_route(VISREP_ROUTE_CONV_HALO);
     const bool rs = epilogue == VISREP_EPI_RESID;
+    if (Cout == 128 && halo_tile_rows() == 8) return rs ? launch_halo<4, 2, true, 8>(a, s) : launch_halo<4, 2, false, 8>(a, s);
     if (Cout == 128) return rs ? launch_halo<4, 4, true>(a, s) : launch_halo<4, 4, false>(a, s);
     return rs ? launch_halo<8, 2, true>(a, s) : launch_halo<8, 2, false>(a, s);
 }

@@ -268,9 +268,19 @@ def test_conv3x3_emits_groupnorm_partials_from_the_256_kernel(B, H, W, Ci, Co):
         SE.conv3x3(xt, B, H, W, wp, b.to(DEV), 1, 0, False, _lib.EPI_RESID, resid=res, gn_groups=G)
 
 
+@pytest.fixture(params=[8, 16], ids=["tile16x8", "tile16x16"])
+def halo_tile(request):
+    """Both tile shapes of conv3x3_halo's Cout = 128 kernel: 16 x 16 pixels (default: 8 waves, one workgroup per CU) and 16 x 8 (4 waves, two)."""
+    lib = _lib.load()
+    old = lib.visrep_set_conv_halo_tile(request.param)
+    assert old in (8, 16)
+    yield request.param
+    lib.visrep_set_conv_halo_tile(old)
+
+
 @pytest.mark.parametrize("B,H,W,Co,resid,exact", [(4, 128, 128, 128, False, True), (4, 128, 128, 128, True, True), (2, 128, 128, 256, True, True),
                                                   (2, 32, 48, 128, True, False), (1, 16, 64, 256, False, False), (3, 16, 16, 128, False, False)])
-def test_conv3x3_halo_equals_groupnorm_apply_plus_implicit_gemm(B, H, W, Co, resid, exact):
+def test_conv3x3_halo_equals_groupnorm_apply_plus_implicit_gemm(B, H, W, Co, resid, exact, halo_tile):
     """conv3x3_halo (GroupNorm + SiLU of the input fused into a halo-resident 3x3 convolution, csrc/conv_halo.hip) against the two launches it
     replaces - groupnorm (statistics + apply pass) and the implicit-GEMM convolution.  Same normalisation arithmetic, same K order, same MFMA
     chains: BIT-IDENTICAL outputs where the reference convolution is not split along K (`exact`: enough tiles to fill the chip); the small
