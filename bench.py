@@ -27,6 +27,7 @@ Extra objects on the JSON line:
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -85,14 +86,21 @@ def timed_steps(step, steps, warmup, dist=None, device=None):
             dist.barrier()
         sync()
     result = None
-    for _ in range(warmup):
-        result = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        result = step()
-    fence()
-    dt = time.perf_counter() - t0
+    gc.collect()                              # the interpreter's cyclic collector stays out of the timed region (a full pass over the process'
+    gc_was_on = gc.isenabled()                # tensors and weight dictionaries takes ~35 ms of host time here); collected before the warm-up steps so
+    gc.disable()                              # that the timed steps follow them without an idle gap
+    try:
+        for _ in range(warmup):
+            result = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result = step()
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -285,14 +293,19 @@ def main():
         b1 = L0["b1"].to(dev)
 
         def time_kernel(fn, reps=20, warm=5):
-            for _ in range(warm):            # steady state: the first launches after an idle gap run at a lower clock
-                fn()
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
+            gc.disable()                     # a cyclic-collector pass between e0 and the first launch (35 ms of host time, seen in a kernel trace as a
+            try:                             # launch-free gap) once turned twenty 0.45-ms attention launches into "2.3 ms each".  Disabled, not collected
+                                             # here: a collection's 35 idle milliseconds drop the clock and cost the next launches ~10 %
+                for _ in range(warm):        # steady state: the first launches after an idle gap run at a lower clock
+                    fn()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+            finally:
+                gc.enable()
             torch.cuda.synchronize(dev)
             return e0.elapsed_time(e1) / reps * 1e-3
 
