@@ -103,6 +103,10 @@ def test_sweep_single_process_equals_the_oracle_chain(cpu_ops):
     out = run()
     assert out["settings"] == 4 and out["world"] == 1
     assert out["images"] == 4 * (7 + 14) and out["c_pairs_per_setting"] == 20
+    row = out["scaling_row"]                                                  # the row the driver's N = 1, 2, 4, 8 runs line up
+    assert row["n_gpus"] == 1 and row["images"] == out["images"] and len(row["setup_s_per_rank"]) == 1
+    assert set(row["c_leg_s_by_setting"]) == {st.name for st in SETTINGS} and abs(row["a_leg_s"] + row["c_leg_s"] - row["wall_s"]) < 1e-2
+    assert row["setup_s_max_over_ranks"] == max(row["setup_s_per_rank"]) and row["img_s"] > 0
     for st in SETTINGS:
         ent = out["per_setting"][st.name]
         assert abs(ent["A"] - direct_a(st.name)) < 1e-9, st.name
@@ -152,6 +156,8 @@ def test_two_rank_sweep_and_encoder_sharded_a_score_equal_single_process(cpu_ops
         assert p.exitcode == 0
     for rank, out, enc, gathered in got:
         assert out["world"] == 2 and out["images"] == single["images"]
+        row = out["scaling_row"]                                              # every rank reports every rank's setup time
+        assert row["n_gpus"] == 2 and len(row["setup_s_per_rank"]) == 2 and row["setup_s_max_over_ranks"] == max(row["setup_s_per_rank"])
         np.testing.assert_array_equal(gathered[:, 0], np.arange(10.))          # global row order restored, padding dropped
         for st in SETTINGS:
             assert abs(out["per_setting"][st.name]["A"] - single["per_setting"][st.name]["A"]) < 1e-12, st.name
