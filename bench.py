@@ -227,10 +227,12 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=8)                 # 8 of the same images
     ap.add_argument("--sweep", default="full", choices=["off", "reduced", "full"])
     ap.add_argument("--sweep-precision", default="reference", choices=["reference", "bf16", "fp32"])   # reference: A leg bf16, C leg per the reference's scripts
-    # split-bf16 product set of the sweep's fp32 ViT engines: the throughput sweep OPTS INTO three products over two-plane operands (validated at
-    # full size on synthetic weights, profiles/round4_precision.md); the drop-in extraction path's default is the fp32-equivalent six.  The
-    # choice is recorded in sweep.fp32_products and in every fp32 setting's dtype label.
-    ap.add_argument("--sweep-fp32-products", type=int, default=3, choices=[3, 4, 6])
+    # split-bf16 product set of the sweep's fp32 ViT engines.  Round 6: `wall_s` is the fp32-EQUIVALENT sweep (six products over three-plane
+    # operands - what stands in for the reference's true-fp32 C-leg towers, C_score/extract_feature.py:36-50); the throughput set (three products
+    # over two-plane operands: 16 significand bits, narrower than the reference's arithmetic) is timed beside it as `wall_s_fp32x3` and labelled.
+    # The choice is recorded in sweep.fp32_products and in every fp32 setting's dtype label.
+    ap.add_argument("--sweep-fp32-products", type=int, default=6, choices=[3, 4, 6])
+    ap.add_argument("--sweep-alt-fp32-products", type=int, default=3, choices=[0, 3, 4, 6])   # the fp32 C legs once more on this set ("wall_s_fp32x3"); 0 = off
     ap.add_argument("--no-scores", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 5])
     args = ap.parse_args()
@@ -293,9 +295,9 @@ def main():
         b1 = L0["b1"].to(dev)
 
         def time_kernel(fn, reps=20, warm=5):
-            gc.disable()                     # a cyclic-collector pass between e0 and the first launch (35 ms of host time, seen in a kernel trace as a
-            try:                             # launch-free gap) once turned twenty 0.45-ms attention launches into "2.3 ms each".  Disabled, not collected
-                                             # here: a collection's 35 idle milliseconds drop the clock and cost the next launches ~10 %
+            gc_was_on = gc.isenabled()       # a cyclic-collector pass between e0 and the first launch (35 ms of host time, seen in a kernel trace as a
+            gc.disable()                     # launch-free gap) once turned twenty 0.45-ms attention launches into "2.3 ms each".  Disabled, not collected
+            try:                             # here: a collection's 35 idle milliseconds drop the clock and cost the next launches ~10 %
                 for _ in range(warm):        # steady state: the first launches after an idle gap run at a lower clock
                     fn()
                 torch.cuda.synchronize(dev)
@@ -304,10 +306,11 @@ def main():
                 for _ in range(reps):
                     fn()
                 e1.record()
+                torch.cuda.synchronize(dev)
+                return e0.elapsed_time(e1) / reps * 1e-3
             finally:
-                gc.enable()
-            torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) / reps * 1e-3
+                if gc_was_on:
+                    gc.enable()
 
         o1 = torch.empty(M, m, dtype=torch.bfloat16, device=dev)
         hmlp = torch.empty(M, m, dtype=torch.bfloat16, device=dev)
@@ -455,6 +458,25 @@ def main():
                          "how": "visrep_debug_mfma_probe: 20000 x 32 v_mfma_f32_16x16x32_bf16 per wave, 8 waves per CU, random bf16 register operands with |x| in [0.25, 4), best of 3 launches after 2 warm-up launches, same process"}
         except Exception as e:
             practical = {"error": str(e)[:200]}
+        # ---- board telemetry under the dominant kernel and under the timed forward: socket power against the board's cap and
+        # the shader clock, sampled from amdgpu's sysfs files at ~200 Hz while the launches repeat for about a second each (telemetry.py).  A board
+        # sitting at its cap with a clock below the 2.4 GHz the nominal peak is quoted at is what bounds `frac` here (profiles/round6_power.md).
+        power = None
+        try:
+            from law_of_vision_representation_in_mllms_amd import telemetry
+            def brief(t):
+                if not t.get("available"):
+                    return {"available": False}
+                fw = t.get("firmware") or {}
+                return {"power_w": t["power_w"]["mean"], "power_w_p95": t["power_w"]["p95"], "power_cap_w": t.get("power_cap_w"),
+                        "sclk_mhz": t["sclk_mhz"]["mean"] if t.get("sclk_mhz") else None, "samples": t["samples"], "hz": t["hz"],
+                        "frac_samples_ge_95pct_of_cap": t.get("frac_of_cap_samples_ge_95pct"), "ppt_residency": fw.get("ppt_residency"),
+                        "throttle": ("power cap" if (t.get("frac_of_cap_samples_ge_95pct") or 0) >= 0.5 else "none seen")}
+            power = {"fc1_loop": brief(telemetry.measure(fc1, 1.0, index=local)), "forward": brief(telemetry.measure(step, 1.5, index=local)),
+                     "how": "hwmon power1_input / freq1_input of the card this process computes on, background thread, while the launch repeats; "
+                            "sclk at the nominal peak is 2400 MHz"}
+        except Exception as e:
+            power = {"error": f"{type(e).__name__}: {e}"[:200]}
         traffic, traffic_src = fc1_traffic(args.gemm_variant, B)
         roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1",
                 "achieved": top["tflops_in_layer_mix"], "peak": PEAK_BF16_TFLOPS,
@@ -465,6 +487,9 @@ def main():
                 "achieved_back_to_back": top["tflops"], "frac_back_to_back": round(top["tflops"] / PEAK_BF16_TFLOPS, 4),
                 "n01_back_to_back": n01,
                 "practical_roof": practical,
+                "power": power,
+                "power_w": ((power or {}).get("fc1_loop") or {}).get("power_w"), "sclk_mhz": ((power or {}).get("fc1_loop") or {}).get("sclk_mhz"),
+                "throttle": ((power or {}).get("fc1_loop") or {}).get("throttle"),
                 "xcd_balance": dict(_lib.xcd_balance(), what="XCD-weighted tile split of the persistent 256x256 kernel: rel = measured time per round of tiles of each XCD relative to the mean (the XCDs run at their own clocks under the power limit); opt-in (VISREP_XCD_BALANCE=1), equal shares by default"),
                 "frac_of_practical_roof": (round(top["tflops_in_layer_mix"] / practical["tflops"], 4) if practical and practical.get("tflops") else None),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_provenance": traffic_src,
@@ -554,7 +579,8 @@ def main():
             torch.cuda.empty_cache()
             from law_of_vision_representation_in_mllms_amd import sweep as SW
             spair = SW.synthetic_spair() if args.sweep == "full" else SW.synthetic_spair(180, 1224)
-            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev, precision=args.sweep_precision, also_bf16=True, fp32_products=args.sweep_fp32_products)
+            sweep = SW.run_sweep(SW.SETTINGS, 100, spair, dev, precision=args.sweep_precision, also_bf16=True, fp32_products=args.sweep_fp32_products,
+                                 alt_fp32_products=(args.sweep_alt_fp32_products or None) if args.sweep_alt_fp32_products != args.sweep_fp32_products else None)
             sweep["size"] = args.sweep
         except Exception as e:                                           # the headline line must survive a sweep failure
             sweep = {"error": f"{type(e).__name__}: {e}"[:300]}

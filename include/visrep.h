@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 500   /* round 5: device CU count, routing counters, MFMA probe, A-score reference arithmetic, host twins (new exports only).  410 = round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
+#define VISREP_VERSION 600   /* round 6: reserved CUs, GEMM tile-window knob (new exports only).  500 = round 5: device CU count, routing counters, MFMA probe, A-score reference arithmetic, host twins (new exports only).  410 = round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
@@ -120,6 +120,19 @@ int visrep_set_stream_scratch(void* stream, void* ptr, size_t bytes);
 /* Compute units of the CURRENT device as the dispatchers count them (cached per device; 256 on MI355X).  Callers that size launches for
  * whole tile rounds (engine.best_chunk, the sweep's launch plan) use it so that their arithmetic is the dispatcher's on any part. */
 int visrep_device_cu_count(void);
+/* CUs the persistent kernels leave free (round 6; multi-GPU insurance).  With world > 1 the sweep's C leg runs RCCL's all_to_all WHILE the next
+ * tower launch's persistent GEMMs (grid = CU count) would own every CU (sweep.c_score_of; the reference has no counterpart: its feature dump,
+ * llava/feature/extract.py:198-214, has no collective at all).  k (rounded down to a multiple of 8: the same number per XCD; ignored if fewer than
+ * 64 CUs would remain) is subtracted from what visrep_device_cu_count() and every dispatcher see; 0 = off (default).  Process-wide;
+ * VISREP_RESERVE_CUS=k in the environment is the same switch.  Set it before engines capture their HIP graphs.  Returns the previous value.
+ * Unmeasured: no multi-GPU box was available in rounds 1-6; it exists so that the first one can A/B it. */
+int visrep_set_reserved_cus(int k);
+/* Tile order of the persistent 256x256 GEMM kernel (round 6 A/B knob, per thread; results do not depend on it).  0 = default: XCD-contiguous
+ * chunks of the tile list, row-major, 4 x 8 windows for more than 8 column panels.  C = 1..255 (low byte): column-group-major - every XCD owns
+ * whole row panels and walks them once per group of C column panels, so that the group's weight panels stay in that XCD's 4-MB L2 across rounds
+ * (taken when the tile list splits into whole row panels per XCD and N / 256 is a multiple of C, else the default order).  Measured in
+ * profiles/round6_gemm.md (FETCH_SIZE and time per window shape); the default stays 0.  Returns the previous value. */
+int visrep_set_gemm_walk(int code);
 
 /* ---- dense layers: replaces torch.nn.functional.linear (+ bias / activation / residual) inside
  * HF CLIPEncoderLayer / Dinov2Layer / SiglipEncoderLayer (transformers, called from

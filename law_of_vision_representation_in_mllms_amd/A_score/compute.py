@@ -59,6 +59,9 @@ def _score_batch(other, ref, other_scale=None, ref_scale=None, arithmetic="exact
     """[n, Nt, D] x [n, Nr, D] -> [n] on the device: the HIP kernel (no CPU fallback; tests may monkeypatch this hook)."""
     from .. import ascore_ops
     if other.device.type == "cpu":                # only reachable through an EXPLICIT device="cpu" (compute(device=), --device cpu): the host twin
+        if arithmetic == "reference":             # the host twin computes in exact fp32: never print exact scores where the bf16 op chain was asked for
+            raise ValueError("arithmetic='reference' (torch's bf16 op chain, rounding by rounding) runs on the GPU kernel only: "
+                             "device='cpu' computes the exact-arithmetic score (use arithmetic='exact' there)")
         return ascore_ops.max_cos_mean_cpu(other, ref)
     if arithmetic == "reference" and other.dtype == torch.bfloat16 and ref.dtype == torch.bfloat16:
         return ascore_ops.max_cos_mean(other, ref, arithmetic="reference")        # torch's bf16 op chain, rounding by rounding
@@ -97,14 +100,15 @@ def per_image_scores_multi(other_tensors, ref_sets, idx, device="cuda", ref_cach
         groups.setdefault(key, []).append(i)
     for ids in groups.values():
         o = _stack(other_tensors, ids, device)
-        o_scale = _row_scales(o)
+        ref_arith = mode == "reference" and o.dtype == torch.bfloat16 and o.device.type != "cpu"      # the in-dtype kernel normalises in its own op chain
+        o_scale = None if ref_arith else _row_scales(o)
         for k, rs in enumerate(ref_sets):
             ck = (k, id(rs), tuple(ids))
             if ref_cache is not None and ck in ref_cache:
                 r, r_scale = ref_cache[ck]
             else:
                 r = _stack(rs, ids, device)
-                r_scale = _row_scales(r) if r.dtype == o.dtype else None        # mixed dtypes take the fp32 path inside the op
+                r_scale = _row_scales(r) if (r.dtype == o.dtype and not ref_arith) else None        # mixed dtypes take the fp32 path inside the op
                 if ref_cache is not None:
                     ref_cache[ck] = (r, r_scale)
             same = r.dtype == o.dtype

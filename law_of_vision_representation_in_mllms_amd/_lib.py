@@ -11,7 +11,7 @@ import threading
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VISREP_LIB") or os.path.join(_PKG, "libvisrep_hip.so")   # VISREP_LIB: diagnostic builds only
 
-ABI_VERSION = 500                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
+ABI_VERSION = 600                 # include/visrep.h VISREP_VERSION this binding was written against (checked at load)
 BF16, F32 = 0, 1
 EPI_BIAS, EPI_ACT, EPI_RESID, EPI_VT, EPI_PATCH, EPI_F32 = range(6)
 ACT = {"none": 0, "quick_gelu": 1, "gelu": 2, "gelu_erf": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3}
@@ -107,6 +107,8 @@ SIGNATURES = {
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_row_rnorm_f32": (_i, [_vp, _l, _i, _f, _vp, _vp]),
     "visrep_device_cu_count": (_i, []),
+    "visrep_set_reserved_cus": (_i, [_i]),
+    "visrep_set_gemm_walk": (_i, [_i]),
     "visrep_debug_routes": (_i, [C.POINTER(C.c_long), _i]),
     "visrep_debug_mfma_probe": (_i, [_i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "visrep_set_xcd_balance": (_i, [_i]),

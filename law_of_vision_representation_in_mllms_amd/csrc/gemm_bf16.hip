@@ -14,6 +14,7 @@
 //                four consecutive n  -> one 8-byte bf16x4 store per fragment into row-major C.
 //   SWAP = false (V^T epilogue): a = X fragment, b = W fragment -> lane holds C[m = 4g+r][n = l&15]:
 //                four consecutive m -> one 8-byte store into the token-contiguous V^T layout.
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -238,6 +239,12 @@ bool splitk_reduce_emits_stats(const GemmArgs& a) { return a.stat_rt && a.epi ==
 }  // namespace
 
 thread_local int t_visrep_gemm_variant = 5;
+thread_local int t_visrep_gemm_walk = 0;
+extern "C" int visrep_set_gemm_walk(int code) {                  // per-thread A/B knob: tile order of the persistent 256x256 kernel; returns the previous value
+    const int old = t_visrep_gemm_walk;
+    t_visrep_gemm_walk = code < 0 ? 0 : code;
+    return old;
+}
 int g_visrep_gemm_dbg = 0;
 unsigned long long* g_visrep_gemm_dbg_buf = nullptr;
 
@@ -246,6 +253,26 @@ int visrep_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     return dev < VISREP_MAX_DEVICES ? dev : VISREP_MAX_DEVICES - 1;
+}
+// CUs the persistent kernels leave free (round 6): with world > 1 the C leg's all_to_all runs on RCCL's own kernels WHILE the next tower launch's
+// persistent GEMMs would otherwise own every CU (sweep.c_score_of); reserving k CUs (a multiple of 8: one or more per XCD) gives the collective
+// somewhere to run.  Process-wide, off by default (0): no multi-GPU box has been available to A/B it.  VISREP_RESERVE_CUS=k in the environment
+// or visrep_set_reserved_cus(k); grids captured into a HIP graph keep the size they were captured with.
+static std::atomic<int> g_reserved_cus{-1};
+static int reserved_cus() {
+    int v = g_reserved_cus.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("VISREP_RESERVE_CUS");
+        v = e ? atoi(e) : 0;
+        v = v < 0 ? 0 : v / 8 * 8;
+        g_reserved_cus.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" int visrep_set_reserved_cus(int k) {
+    const int old = reserved_cus();
+    g_reserved_cus.store(k < 0 ? 0 : k / 8 * 8, std::memory_order_relaxed);
+    return old;
 }
 int visrep_cu_count() {
     static std::atomic<int> n[VISREP_MAX_DEVICES];
@@ -256,7 +283,8 @@ int visrep_cu_count() {
         v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         n[dev].store(v, std::memory_order_relaxed);
     }
-    return v;
+    const int r = reserved_cus();
+    return (r > 0 && v - r >= 64) ? v - r : v;                   // never below 64 CUs: a mistyped reservation must not serialise the chip
 }
 
 // split-K scratch registry: (device, stream) -> caller-owned buffer.  A handful of entries per device, searched under a mutex (a launch-path

@@ -68,6 +68,14 @@
 #ifndef V5_DMA_IN_M
 #define V5_DMA_IN_M 0
 #endif
+// A/B knobs (round 6, variant libraries): non-temporal cache policy (aux = 2) on the X / W LDS-DMA loads, so that the operand that is streamed
+// once per round does not evict the one a column-group-major walk keeps in the XCD's L2 (profiles/round6_gemm.md)
+#ifndef V5_NT_X
+#define V5_NT_X 0
+#endif
+#ifndef V5_NT_W
+#define V5_NT_W 0
+#endif
 #ifndef V5_OWN
 #if V5_DMA_IN_M == 2
 #define V5_OWN 0
@@ -97,6 +105,10 @@ constexpr int XW_BYTES = 256 * TK * 2;          // 32 KB per operand tile
 constexpr int NSLOT = 5;
 constexpr int LDS2 = NSLOT * XW_BYTES;            // 160 KB: all of the CU's LDS
 
+template <int AUX>
+VR_DEV void glds16a(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
 VR_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 VR_DEV void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 // Fragment reads are hand-written: hipcc's waitcnt pass cannot tell an LDS read from the bytes an in-flight LDS-DMA will
@@ -151,11 +163,22 @@ VR_DEV void xcd_record(const GemmArgs& p, int ntiles, unsigned long long t0) {
 
 struct TileWalk {           // the block's list of output tiles: chunk of its XCD, strided by the blocks of that XCD
     int start, stride, count, ntn, ntm;
+    int cgc, cstart, rows_x;    // column-group-major walk (round 6 experiment, GemmArgs::walk): cgc columns per group, the XCD's first tile, its row panels
     // Tile order as in v2: the ~32 blocks of an XCD work on ~32 consecutive tile indices and share that XCD's 4-MB L2; for more than 8
     // column panels (fc1: 16) the indices walk 4 x 8 blocks of tiles, so a window touches 4 + 8 operand panels instead of 2 + 16.
     VR_DEV void decode(int i, int& m0, int& n0) const {
         const int ii = i < count ? i : count - 1;        // past-the-end loads re-read the last tile (never consumed)
         const int t = start + ii * stride;
+        if (cgc) {
+            // The XCD owns rows_x whole row panels and walks them once per GROUP of cgc column panels: a round of its ~32 blocks is (32 / cgc) row
+            // panels x cgc column panels, the next round the same columns and the next rows - the group's W panels (cgc x 512 KB at K = 1024) are what
+            // stays in the XCD's 4-MB L2 across rounds, every X panel is fetched ntn / cgc times per launch instead of once per 4 x 8 window pair.
+            const int u = t - cstart;
+            const int cg = u / (rows_x * cgc), v = u - cg * rows_x * cgc;
+            m0 = (cstart / ntn + v / cgc) * TM;
+            n0 = (cg * cgc + v % cgc) * TN;
+            return;
+        }
         if (ntn > 8 && (ntn & 7) == 0) {
             const int R = 4, c = 8;
             const int sr = t / (R * ntn), u = t - sr * R * ntn;
@@ -204,6 +227,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         tw.count = j < csize ? (csize - j + per - 1) / per : 0;
         tw.ntn = ntn;
         tw.ntm = ntm;
+        const int wc = p.walk & 0xff;                          // column-group-major walk: whole row panels per XCD and whole groups, else the default order
+        tw.cgc = (wc > 0 && ntn % wc == 0 && cstart % ntn == 0 && csize % ntn == 0 && csize > 0) ? wc : 0;
+        tw.cstart = cstart;
+        tw.rows_x = csize / ntn;
     }
     const unsigned long long xb_t0 = p.xb ? __builtin_amdgcn_s_memrealtime() : 0ull;      // sampled launches: when this block started (100-MHz ticks)
     if (tw.count == 0) { if (p.xb && tid == 0) xcd_record(p, ntiles, xb_t0); return; }    // uniform per block: no barrier has been executed yet
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
         char* dst = smem + ((2 * cx.idx) % NSLOT) * XW_BYTES + wave * 4096;
         const int kc = col_of(cx, p.tab_a);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(x_src(cx, j, kc), dst + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16a<V5_NT_X ? 2 : 0>(x_src(cx, j, kc), dst + j * 1024);
         advance(cx);
         if (cx.k == p.K) { cx.k = 0; cx.kin = 0; cx.seg = 0; ++cx.ti; set_x(cx); }
     };
@@ -299,11 +326,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
             char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wn * 8192;
             const size_t step = (size_t)16 * p.ldw;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) glds16(cw.p[j & 1] + (j >> 1) * step + kc, dst + j * 1024);
+            for (int j = 0; j < 8; ++j) glds16a<V5_NT_W ? 2 : 0>(cw.p[j & 1] + (j >> 1) * step + kc, dst + j * 1024);
         } else {
             char* dst = smem + ((2 * cw.idx + 1) % NSLOT) * XW_BYTES + wave * 4096;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(cw.p[j] + kc, dst + j * 1024);
+            for (int j = 0; j < 4; ++j) glds16a<V5_NT_W ? 2 : 0>(cw.p[j] + kc, dst + j * 1024);
         }
         advance(cw);
         if (cw.k == p.K) { cw.k = 0; cw.kin = 0; cw.seg = 0; ++cw.ti; set_w(cw); }
@@ -479,6 +506,7 @@ int launch5o(const GemmArgs& a, hipStream_t s) {
     const int ntiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int grid = ntiles < ncu ? ntiles : ncu;
     GemmArgs b = a;
+    b.walk = t_visrep_gemm_walk;
     visrep_xcd_plan(b, s, grid, ntiles, reinterpret_cast<const void*>(gemm_bf16_256q<EPI, OWN_, CONV_, GN_>));
     hipLaunchKernelGGL((gemm_bf16_256q<EPI, OWN_, CONV_, GN_>), dim3(grid), dim3(512), LDS2, s, b);
     return hipGetLastError() == hipSuccess ? 0 : VISREP_ERR_LAUNCH;
@@ -569,13 +597,18 @@ extern "C" int visrep_debug_xcd_split(const float* rel8, int grid, int ntiles, i
 void visrep_xcd_plan(GemmArgs& a, hipStream_t s, int grid, int ntiles, const void* fn) {
     a.xb = nullptr; a.xb_host = nullptr; a.xb_seq = 0; a.xcd_bounds[8] = 0;
     if (!xcd_enabled() || grid < 64 || (grid & 7) || ntiles < 8 * grid) return;     // a full chip and at least eight rounds of tiles per block
+    // A launch that is being CAPTURED into a HIP graph runs with equal shares and is never a measurement: a plan baked into a graph would be
+    // replayed forever with the bounds and the sample sequence number of capture time (the host would never see a new measurement and the
+    // split would stop adapting - ADVICE r5).  The ViT and diffusion engines replay graphs: the opt-in split serves eager launches only.
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    }
     const int dev = visrep_device();
     std::lock_guard<std::mutex> lk(g_xcd_mu);
     XcdState& st = g_xcd[dev];
     if (st.failed) return;
-    if (!st.dev) {                                               // first eligible launch on this device: allocate (never during a stream capture)
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    if (!st.dev) {                                               // first eligible launch on this device: allocate
         VisrepXcdDev* d = nullptr; VisrepXcdHost* h = nullptr;
         if (hipMalloc(&d, XCD_RECORDS * sizeof(VisrepXcdDev)) != hipSuccess || hipMemset(d, 0, XCD_RECORDS * sizeof(VisrepXcdDev)) != hipSuccess ||
             hipHostMalloc(&h, XCD_RECORDS * sizeof(VisrepXcdHost), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {

@@ -34,6 +34,7 @@ hipError_t visrep_lds_opt_in_slow(VisrepLdsOptIn& st, const void* kernel, int by
         return e;
     }
     st.bytes[dev].store(bytes, std::memory_order_release);       // recorded only after the attribute holds: never larger than what is set
+    g_lds_note[0] = 0;                                           // a stale note of an earlier failed opt-in must not ride on an unrelated later error
     return hipSuccess;
 }
 

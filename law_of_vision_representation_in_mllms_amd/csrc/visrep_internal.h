@@ -71,6 +71,7 @@ struct GemmArgs {
     struct VisrepXcdHost* xb_host;
     unsigned xb_seq;
     int xcd_bounds[9];
+    int walk;                       // v5 tile walk (set by the launcher from t_visrep_gemm_walk): 0 = default; low byte C > 0 = column-group-major walk, C columns per group
     unsigned long long* dbg_buf;    // timing-only: per-segment cycle sums (VISREP_GEMM_ABLATE builds)
     int dbg;                        // timing-only ablation mask for the v2 kernel (1 = no MFMA, 2 = no LDS-DMA, 4 = no ds_read); 0 in production
 };
@@ -128,6 +129,7 @@ constexpr int VISREP_MAX_DEVICES = 16;
 // ---- per-DEVICE one-shot state: a process may drive several GPUs, and both the multiprocessor count and the function attribute
 // hipFuncAttributeMaxDynamicSharedMemorySize belong to a device, not to the process
 int visrep_device();      // current device index, clamped to [0, VISREP_MAX_DEVICES)
+extern thread_local int t_visrep_gemm_walk;    // A/B knob (visrep_set_gemm_walk): tile order of the persistent 256x256 kernel
 int visrep_cu_count();    // multiprocessors of the current device (cached per device)
 struct VisrepLdsOptIn { std::atomic<int> bytes[VISREP_MAX_DEVICES]; };   // largest dynamic-LDS size opted in so far, per device (static storage: zeros)
 // Raises the kernel's dynamic-LDS limit on the current device to at least `bytes`.  Returns hipSuccess or the error of hipFuncSetAttribute

@@ -460,7 +460,8 @@ class SdEngine:
                     return out, Ho, Wo
             return conv3x3(x, B, H, W, lin.w, lin.b, stride, pad_mode, upsample, epi, resid)
         if (self.conv_c8 and x.shape[1] == 8 and stride == 1 and pad_mode == 0 and not upsample and epi == _lib.EPI_BIAS
-                and lin.w.shape[0] == lin.n and conv_c8_supported(B, H, W, lin.n)):        # the VAE's conv_in: straight from the pixel tokens
+                and lin.w.shape[0] == lin.n and lin.w.shape[1] >= 96 and lin.w.stride(0) % 8 == 0          # the kernel reads 96 K columns (72 + zero padding) of 16-byte-aligned rows
+                and conv_c8_supported(B, H, W, lin.n)):                                                        # the VAE's conv_in: straight from the pixel tokens
             emit = gn if (gn and self.fuse_gn_stats and (H * W) % 128 == 0 and lin.n // gn in (4, 8, 16)) else 0
             res = conv3x3_c8(x, B, H, W, lin.w, lin.b, emit)
             if emit:

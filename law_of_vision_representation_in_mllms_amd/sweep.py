@@ -182,7 +182,7 @@ class SettingModel:
     """Tower(s) + mlp2x_gelu projector of one setting, built through the drop-in registry (llava_arch.build_function_mapping)."""
 
     def __init__(self, setting: Setting, device, hidden: int = 4096, synthetic: bool = True, precision: str = "bf16", fast_weights: bool = True,
-                 fp32_products: Optional[int] = None):
+                 fp32_products: Optional[int] = None, alt_fp32_products: Optional[int] = None):
         """fp32_products: split-bf16 product set of the reference-precision (fp32) ViT engines this setting builds - None = the engine's
         fp32-equivalent default (6); 3 = the throughput set (two-plane operands), an explicit opt-in that the `dtypes` labels carry
         ("fp32[split-bf16 x3]") into the sweep's output.
@@ -203,11 +203,11 @@ class SettingModel:
         if synthetic and fast_weights:
             env["VISREP_FAST_SYNTHETIC"] = "cuda" if self.device.type == "cuda" else "1"
 
-        def tower(tid, prec):
+        def tower(tid, prec, products=fp32_products):
             cfg = SimpleNamespace(mm_vision_tower=tid, vision_tower=tid, mm_vision_select_layer=-2, mm_vision_select_feature='patch',
                                   up_ft_index=0, t=1, prompt='', ensemble_size=1, img_size=setting.size,        # train.py:83-87 defaults
                                   vit_img_size=setting.size, synthetic_weights=synthetic, device=self.device, tower_precision=prec,
-                                  tower_products=fp32_products)
+                                  tower_products=products)
             return LA.build_function_mapping[tid](cfg)
         a_prec = "fp32" if precision == "fp32" else "bf16"
         with _environ(env):
@@ -217,6 +217,11 @@ class SettingModel:
                 c_prec = reference_c_precision(tid) if precision == "reference" else a_prec
                 same = (ta.dtype == torch.float32) == (c_prec == "fp32") or hasattr(ta, "up_ft_index")
                 self.c_towers.append(ta if same else tower(tid, c_prec))
+            # alt_fp32_products: the fp32 C-leg towers once more with another split-bf16 product set (bench.py times the throughput set, 3,
+            # beside the fp32-equivalent 6 the reference-precision leg runs); same weights (same seed), engines of their own
+            self.alt_c_towers = None
+            if alt_fp32_products is not None and any(t.dtype == torch.float32 for t in self.c_towers):
+                self.alt_c_towers = [tower(tid, "fp32", alt_fp32_products) if tc.dtype == torch.float32 else tc for tid, tc in zip(setting.towers, self.c_towers)]
         def label(t):
             if t.dtype != torch.float32:
                 return "bf16"
@@ -225,6 +230,8 @@ class SettingModel:
             return f"fp32[split-bf16 x{pr}]" if pr else "fp32"                                    # pr None: exact-fp32 MFMA route
         name = lambda ts: "+".join(sorted({label(t) for t in ts}))
         self.dtypes = {"a": name(self.towers), "c": name(self.c_towers)}
+        if self.alt_c_towers is not None:
+            self.dtypes["c_alt"] = name(self.alt_c_towers)
         self.width = sum(t.hidden_size for t in self.towers)
         torch.manual_seed(7)                                             # same projector on every rank
         self.projector = build_vision_projector(SimpleNamespace(mm_projector_type='mlp2x_gelu', mm_hidden_size=self.width, hidden_size=hidden))
@@ -243,6 +250,8 @@ class SettingModel:
             self.project(self.tokens(px))
             if any(c is not a for c, a in zip(self.c_towers, self.towers)):
                 self.c_tokens(px)
+            if self.alt_c_towers is not None:
+                self.c_tokens_alt(px)
 
     @staticmethod
     def _run(towers, px):
@@ -258,6 +267,11 @@ class SettingModel:
     def c_tokens(self, px: torch.Tensor) -> torch.Tensor:
         """C leg: the same towers in the dtype C_score/extract_feature.py runs them in (pck_train_two: per-encoder maps, concatenated)."""
         return self._run(self.c_towers, px)
+
+    @torch.no_grad()
+    def c_tokens_alt(self, px: torch.Tensor) -> torch.Tensor:
+        """C leg on the alternative product set's engines (alt_fp32_products)."""
+        return self._run(self.alt_c_towers, px)
 
     @torch.no_grad()
     def project(self, tok: torch.Tensor) -> torch.Tensor:
@@ -417,7 +431,8 @@ def c_exchange_plan(n_items: int, item_owner: Sequence[int], world: int, off: in
     return send
 
 
-def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int, tokens: Optional[Callable] = None):
+def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, rank: int, world: int, tokens: Optional[Callable] = None,
+               timing: Optional[dict] = None):
     """pck_train.eval (pck_train.py:315-340) over the synthetic SPair set, every feature resident in HBM.  tokens: the tower pass
     ([B, 3, s, s] -> [B, N, C]); default = the model's C-leg engines (`c_tokens`, else `tokens`).
     1. ONE image-sharded tower pass over all categories' distinct images (global item g = (category, image) on rank g mod world) in
@@ -425,11 +440,14 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
        all-to-all over xGMI: every row crosses the fabric once; the round-3 all-gather sent it to all `world` ranks), asynchronous: the
        exchange of launch j runs under launch j + 1; 3. the owner evaluates its categories with _compute_pck(local=True);
     4. one all_gather_object of (pck, img_correct) per category; statistics are accumulated in category order on every rank, so the
-       result does not depend on the world size."""
+       result does not depend on the world size.
+    timing: a dict that receives {"tower_s", "eval_s"} - the leg's wall-clock split at the point where this rank's banks are complete (one extra
+    device sync there): what the scaling prediction (`predict_scaling`) needs, since the two parts shard differently."""
     from .C_score import pck_train as PT
     from .C_score.utils.logger import log_weighted_pcks, update_stats
     aggre = PT.DummyAggregationNetwork()
     tokens = tokens or getattr(model, "c_tokens", None) or model.tokens
+    t_begin = time.perf_counter()
     d = _dist() if world > 1 else None
     items = [(ci, i) for ci, cat in enumerate(spair) for i in range(cat.n_images)]
     n_items = len(items)
@@ -484,6 +502,10 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
         inflight()
     if store is None:
         raise ValueError("empty SPair set")
+    if timing is not None:
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+        timing["tower_s"] = time.perf_counter() - t_begin
     P = int(round(store.shape[1] ** 0.5))
     if P * P != store.shape[1]:
         raise ValueError(f"{model.setting.name}: {store.shape[1]} tokens is not a square map")
@@ -508,19 +530,66 @@ def c_score_of(model, spair: Sequence[SpairCategory], pixels: Callable, device, 
         update_stats(args, pcks, pcks_05, pcks_01, weights, kpt_weights, *results[ci])
     import logging
     quiet = logging.getLogger("visrep.sweep")
+    if timing is not None:
+        timing["eval_s"] = time.perf_counter() - t_begin - timing["tower_s"]
     return log_weighted_pcks(args, quiet, pcks, pcks_05, pcks_01, weights)
+
+
+# ------------------------------------------------------------------------------------------------ predicted scaling (no multi-GPU box so far)
+VIT_LAUNCH_FIXED_IMAGES = 24       # a ViT tower launch costs about (images + 24) image-times (tile-round quantisation + launch tail)
+PER_SETTING_SYNC_S = 0.025         # fences, the all_gather_object, Python between the legs
+
+
+def predict_scaling(per: dict, settings: Sequence[Setting], n_a_images: int, spair, worlds=(2, 4, 8)) -> dict:
+    """What the measured single-GPU legs predict for N ranks - a MODEL, printed next to the measured row so that the first multi-GPU run has
+    something to be compared with; it is not a measurement.  Per setting: the C leg's tower part (`c_tower_s`) scales with the cost of one rank's
+    launch plan (`c_launch_plan`; ViT launch = images + 24, diffusion launch = images), its evaluation part (`c_eval_s`) with the largest
+    owner's share of the pairs (`category_owners`), the A leg with a rank's share of the A images in launches of `batch`, plus 25 ms of fences per
+    setting.  NOT modelled: RCCL's all_to_all kernels competing for CUs with the persistent GEMMs that own every CU (the exchange of launch j
+    runs under launch j + 1), host launch overhead of the graph replays, clock differences between GPUs, rank skew at the fences."""
+    def launch_cost(plan, vit):
+        return sum(x + (VIT_LAUNCH_FIXED_IMAGES if vit else 0) for x in plan)
+    by_name = {s.name: s for s in settings}
+    total_pairs = sum(len(c.thresholds) for c in spair)
+    out = {}
+    base = sum(v.get("a_s", 0.0) + v.get("c_s", 0.0) for v in per.values())
+    for n in worlds:
+        owners = category_owners(spair, n)
+        load = [0] * n
+        for ci, c in enumerate(spair):
+            load[owners[ci]] += len(c.thresholds)
+        eval_share = max(load) / max(total_pairs, 1)
+        wall = 0.0
+        for name, v in per.items():
+            st = by_name.get(name)
+            if st is None or "c_s" not in v:
+                continue
+            vit = st.batch > 32
+            c1, cn = launch_cost(c_launch_plan(spair, st.batch, 1), vit), launch_cost(c_launch_plan(spair, st.batch, n), vit)
+            a1 = launch_cost(plan_launches(n_a_images, st.batch, equal=False), vit)
+            an = launch_cost(plan_launches(-(-n_a_images // n), st.batch, equal=False), vit)
+            wall += v.get("c_tower_s", v["c_s"]) * cn / c1 + v.get("c_eval_s", 0.0) * eval_share + v.get("a_s", 0.0) * an / a1 + PER_SETTING_SYNC_S
+        out[f"n{n}"] = {"wall_s": round(wall, 2), "speedup": round(base / wall, 2) if wall else None}
+    out["from_wall_s"] = round(base, 3)
+    out["model"] = ("per setting: c_tower_s x launch-plan cost ratio (ViT launch = images + 24, diffusion launch = images) + c_eval_s x largest owner's pair share "
+                    "+ a_s x A-launch cost ratio + 0.025 s of fences; a prediction, not a measurement")
+    out["not_modelled"] = ("RCCL all_to_all kernels need CUs while the next tower launch's persistent GEMMs own all of them (VISREP_RESERVE_CUS reserves some "
+                           "when world > 1), host launch overhead of graph replays, per-GPU clock spread, rank skew at the two fences per leg")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ the sweep
 def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spair: Optional[Sequence[SpairCategory]] = None,
               device="cuda", build: Optional[Callable[[Setting], object]] = None, pixels: Optional[Callable] = None, a_hooks=None,
               hidden: int = 4096, precision: str = "reference", do_a: bool = True, do_c: bool = True, verbose: bool = False,
-              also_bf16: bool = False, fp32_products: Optional[int] = None) -> dict:
+              also_bf16: bool = False, fp32_products: Optional[int] = None, alt_fp32_products: Optional[int] = None) -> dict:
     """Runs the sweep on this process' share (one process per GPU; world size from torch.distributed).  Returns
     {"wall_s", "setup_s", "per_setting": {name: {"a_s", "c_s", "A", "pck": [..3], "images", "dtype": {"a", "c"}}}, "images", ...}.
     precision: see SettingModel ('reference' = A leg bf16, C leg in the dtype the reference's C path uses per tower).
     fp32_products: product set of the fp32 ViT engines (SettingModel): None = fp32-equivalent (6); bench.py's throughput sweep opts into 3
     and the per-setting "dtype" / the top-level "fp32_products" say so.
+    alt_fp32_products ('reference' only): the settings whose C leg is fp32 run it once more on engines with this product set ("c_s_fp32x<n>",
+    "pck_fp32x<n>"; "wall_s_fp32x<n>" = the sweep's wall-clock with those legs swapped in).  bench.py: reference leg = 6 (fp32-equivalent), alt = 3.
     also_bf16 ('reference' only): the settings whose C leg is fp32 run their C leg a second time on the bf16 engines, timed the same way
     ("c_s_bf16", "pck_bf16"), and "wall_s_all_bf16" is the wall-clock of the sweep with those legs swapped in - the all-bf16 sweep's
     number without running the eleven other legs twice (they are the same launches in both modes).
@@ -534,14 +603,17 @@ def run_sweep(settings: Sequence[Setting] = SETTINGS, n_a_images: int = 100, spa
     old_level = clog.level
     clog.setLevel(logging.WARNING)                                       # 18 per-category lines x 13 settings are not a bench output
     try:
-        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16, fp32_products)
+        return _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16, fp32_products,
+                          alt_fp32_products)
     finally:
         clog.setLevel(old_level)
 
 
 def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden, precision, do_a, do_c, verbose, rank, world, also_bf16=False,
-               fp32_products=None):
-    build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision, fp32_products=fp32_products))
+               fp32_products=None, alt_fp32_products=None):
+    if precision != "reference":
+        alt_fp32_products = None
+    build = build or (lambda s: SettingModel(s, dev, hidden=hidden, precision=precision, fp32_products=fp32_products, alt_fp32_products=alt_fp32_products))
     # fp32 pixels wherever an fp32 engine may consume them (every tower is fed its own dtype: SettingModel._run); the bf16 cast of the same
     # draw is what the all-bf16 mode generates directly, so the three modes see the same images
     pixels = pixels or ResidentPixels(dev, torch.bfloat16 if precision == "bf16" else torch.float32)
@@ -549,7 +621,8 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
         spair = synthetic_spair()
     per, refs, pending = {}, {}, []
     _, scales_fn = a_hooks or (_a_hooks() if do_a else (None, None))
-    wall = setup = wall_swap = 0.0
+    wall = setup = wall_swap = wall_alt = 0.0
+    alt_key = f"fp32x{int(alt_fp32_products)}" if alt_fp32_products else None
     n_c_images = sum(c.n_images for c in spair) if do_c else 0
     my_a = list(range(rank, n_a_images, world))
     for st in settings:
@@ -580,12 +653,23 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
         if do_c:
             _fence(dev)
             t0 = time.perf_counter()
-            pck = c_score_of(model, spair, pixels, dev, rank, world)
+            split = {}
+            pck = c_score_of(model, spair, pixels, dev, rank, world, timing=split)
             _fence(dev)
-            ent["c_s"] = round(time.perf_counter() - t0, 4)
+            c_s = time.perf_counter() - t0
+            ent["c_s"] = round(c_s, 4)
+            ent["c_tower_s"], ent["c_eval_s"] = round(split.get("tower_s", 0.0), 4), round(split.get("eval_s", 0.0), 4)
             ent["pck"] = [float(x) for x in pck]
-            wall += time.perf_counter() - t0
+            wall += c_s
             dts = getattr(model, "dtypes", None)
+            if alt_key and getattr(model, "alt_c_towers", None) is not None:
+                _fence(dev)
+                t1 = time.perf_counter()
+                pck_x = c_score_of(model, spair, pixels, dev, rank, world, tokens=model.c_tokens_alt)
+                _fence(dev)
+                ent[f"c_s_{alt_key}"] = round(time.perf_counter() - t1, 4)
+                ent[f"pck_{alt_key}"] = [float(x) for x in pck_x]
+                wall_alt += (time.perf_counter() - t1) - c_s
             if also_bf16 and precision == "reference" and dts and dts["c"] != dts["a"]:
                 _fence(dev)
                 t1 = time.perf_counter()
@@ -593,7 +677,7 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
                 _fence(dev)
                 ent["c_s_bf16"] = round(time.perf_counter() - t1, 4)
                 ent["pck_bf16"] = [float(x) for x in pck_b]
-                wall_swap += (time.perf_counter() - t1) - (t1 - t0)
+                wall_swap += (time.perf_counter() - t1) - c_s
         if getattr(model, "dtypes", None):
             ent["dtype"] = dict(model.dtypes)
         ent["images"] = (n_a_images if do_a else 0) + n_c_images
@@ -607,6 +691,8 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
         raise ValueError("the A score needs the clip336 and clip224 settings in the sweep (A_score/compute.py:31-35)")
     images = sum(v["images"] for v in per.values())
     extra = {"wall_s_all_bf16": round(wall + wall_swap, 3)} if also_bf16 and precision == "reference" and do_c else {}
+    if alt_key and do_c:
+        extra[f"wall_s_{alt_key}"] = round(wall + wall_alt, 3)
     # every rank's setup time (engine construction + HIP-graph capture + resident pixels): outside the timed legs, inside anyone's wall-clock
     setup_ranks = [round(setup, 3)]
     d = _dist()
@@ -622,6 +708,8 @@ def _run_sweep(settings, n_a_images, spair, dev, build, pixels, a_hooks, hidden,
                    "a_leg_s": round(a_total, 3), "c_leg_s": round(c_total, 3),
                    "c_leg_s_by_setting": {k: v.get("c_s") for k, v in per.items() if "c_s" in v},
                    "setup_s_max_over_ranks": max(setup_ranks), "setup_s_per_rank": setup_ranks, "images": images}
+    if world == 1 and do_a and do_c:
+        scaling_row["predicted"] = predict_scaling(per, settings, n_a_images, spair)
     return {"wall_s": round(wall, 3), **extra, "setup_s": round(setup, 3), "world": world, "settings": len(per), "images": images,
             "img_s": round(images / wall, 2) if wall else None, "img_s_per_gpu": round(images / wall / world, 2) if wall else None,
             "a_images_per_setting": n_a_images if do_a else 0, "c_images_per_setting": n_c_images,

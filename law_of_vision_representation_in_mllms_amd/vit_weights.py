@@ -271,3 +271,77 @@ def weights_at_resolution(spec: ViTSpec, w: dict, image_size: int):
     w2["pos_native"] = src                                   # every later resize starts from the same table
     w2["pos"] = interpolate_pos(src, spec.has_cls, spec2.grid)
     return spec2, w2
+
+
+def hostile_weights(spec: ViTSpec, seed: int = 1, n_layers: Optional[int] = None, profile: str = "outlier", n_outlier: int = 4,
+                    outlier=(50.0, 200.0), ls_range=(1e-5, 1.0), const_token: int = 7, const_value: float = 25.0, sharp: float = 5.0) -> dict:
+    """Synthetic weights in the regime real checkpoints live in and N(0, 0.02) draws do not: the stand-in for the
+    CLIP / DINOv2 checkpoints that are not available offline.  Starts from `synthetic_weights` and plants, deterministically per seed:
+
+    profile "outlier" (and "all"):
+      * massive-activation channels: `n_outlier` residual channels whose writers - the rows of one early layer's fc2 (`w2`) and of one middle
+        layer's attention output (`wo`) - are scaled by log-uniform factors in `outlier` (50-200x) and whose writer biases are set to
+        +-(50-200) in units of the stream's O(1) scale: those channels carry values 50-200x the others from that layer on, for every token
+        (a token-dependent and a token-independent part, as the massive activations of ViT-L checkpoints have);
+      * LayerNorm gains that fight them: in every later layer half of those channels get gamma = 0.02 and half gamma = 3 (ln1 and ln2 the
+        other way round), so the folded GEMM (gamma o W) sees both a squashed and an amplified outlier column.
+    profile "const" (and "all"):
+      * one near-constant token: `const_value` (25) added to every channel of position-embedding row `const_token` (a patch token).  Towers
+        without a pre-LayerNorm (DINOv2, SigLIP) carry that row at |mean| ~ 25-50 std through every layer - the case E[x^2] - mean^2 row
+        statistics are worst at; CLIP's pre_layrnorm removes the shift (there the pre-LN's own statistics pass is what it exercises).
+        (With the outlier channels present the row's std is theirs, |mean| / std drops to ~2-5: hence a profile of its own.)
+    every profile:
+      * LayerScale (DINOv2 family) spread log-uniformly over `ls_range` (1e-5 .. 1) with random signs (outlier channels keep 0.5 so that
+        the planted activations survive);
+      * sharp attention heads: the Q and K rows of two heads scaled by `sharp` (5) in every third layer - logits x25: near-one-hot softmax
+        rows with large pre-softmax scores (the pre-scaled-Q / running-reference paths of the attention kernels).
+    Returns the packed dict plus w["hostile"] = {"profile", "channels", "factors", "const_token", ...} for the tests' own assertions."""
+    if profile not in ("outlier", "const", "all"):
+        raise ValueError(f"profile must be 'outlier', 'const' or 'all', got {profile!r}")
+    w = synthetic_weights(spec, seed=seed, n_layers=n_layers)
+    rs = np.random.RandomState(seed + 7919)
+    d, n = spec.d, len(w["layers"])
+    ch = np.sort(rs.choice(d, n_outlier, replace=False))
+    fac = np.exp(rs.uniform(np.log(outlier[0]), np.log(outlier[1]), n_outlier)).astype(np.float32)
+    sgn_o = np.where(rs.rand(n_outlier) < 0.5, -1.0, 1.0).astype(np.float32)
+    early, mid = min(1, n - 1), min(max(n // 3, 1), n - 1)
+    half = max(n_outlier // 2, 1)
+    cht, fact = torch.from_numpy(ch), torch.from_numpy(fac)
+    plant = profile in ("outlier", "all")
+    lsdiv = 0.5 if spec.layerscale else 1.0
+    if plant:
+        for L, wk, bk, sl in ((w["layers"][early], "w2", "b2", slice(0, half)), (w["layers"][mid], "wo", "bo", slice(half, None))):
+            L[wk] = L[wk].clone()
+            L[wk][cht[sl]] *= fact[sl][:, None]
+            L[bk] = L[bk].clone()
+            L[bk][cht[sl]] = torch.from_numpy(sgn_o[sl] * fac[sl] / lsdiv)
+    for i, L in enumerate(w["layers"]):
+        if plant and i > early:
+            for k, (a, b) in (("ln1_g", (0.02, 3.0)), ("ln2_g", (3.0, 0.02))):
+                L[k] = L[k].clone()
+                L[k][cht[0::2]] = a
+                L[k][cht[1::2]] = b
+        if spec.layerscale:
+            for k in ("ls1", "ls2"):
+                mag = np.exp(rs.uniform(np.log(ls_range[0]), np.log(ls_range[1]), d)).astype(np.float32)
+                sgn = np.where(rs.rand(d) < 0.5, -1.0, 1.0).astype(np.float32)
+                v = torch.from_numpy(mag * sgn)
+                if plant:
+                    v[cht] = 0.5
+                L[k] = v
+        if sharp and i % 3 == 2:
+            L["wqkv"] = L["wqkv"].clone()
+            L["bqkv"] = L["bqkv"].clone()
+            dh = d // spec.heads
+            for hd in (0, spec.heads - 1):
+                for base in (0, d):                                  # Q rows, K rows of the head
+                    L["wqkv"][base + hd * dh: base + (hd + 1) * dh] *= sharp
+                    L["bqkv"][base + hd * dh: base + (hd + 1) * dh] *= sharp
+    tok = None
+    if profile in ("const", "all"):
+        tok = min(int(const_token) + (1 if spec.has_cls else 0), spec.tokens - 1)
+        w["pos"] = w["pos"].clone()
+        w["pos"][tok] += const_value
+    w["hostile"] = {"profile": profile, "channels": ch.tolist() if plant else [], "factors": fac.tolist() if plant else [], "const_token": tok,
+                    "early": early, "mid": mid}
+    return w

@@ -2,6 +2,7 @@
 # The one parameterised gpurun script (round 5; the 59 one-off scripts of rounds 1-4 are archived under tools/history/ next to the profiles
 # they produced).  Usage on the GPU box:   bash tools/gpu.sh <out-tag> <step> [<step> ...]      - every step writes under gpurun_out/<out-tag>/
 #   tests[:<pytest -k expression>]      python -m pytest tests -m gpu -x (whole suite, or the selection)
+#   testsall:<pytest -k expression>     the selection without -x and with -s (printed diagnostics kept)
 #   smoke                               __graft_entry__.smoke()
 #   bench[:<bench.py flags>]            bench.py (default: --sweep off --no-cpu-baseline --steps 10 --warmup 3); prints value / fractions
 #   benchfull                           the driver's line: python bench.py (full sweep, scores, CPU baseline)
@@ -34,6 +35,8 @@ for step in "$@"; do
   case $kind in
     tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q -x --tb=short -k "$arg" > $O/$i.pytest.log 2>&1; else timeout 1800 python -m pytest tests -m gpu -q -x --tb=short > $O/$i.pytest.log 2>&1; fi
            echo "[$i tests] rc=$?"; tail -4 $O/$i.pytest.log | cut -c1-300 ;;
+    testsall) timeout 1800 python -m pytest tests -m gpu -q --tb=line -s -k "$arg" > $O/$i.pytest.log 2>&1      # no -x, prints kept: a first look at a new test file
+           echo "[$i testsall] rc=$?"; grep -E "^hostile|passed|failed" $O/$i.pytest.log | cut -c1-420 | tail -80 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/$i.smoke.log 2>&1; echo "[$i smoke] rc=$?"; tail -1 $O/$i.smoke.log ;;
     bench) timeout 900 python bench.py ${arg:---sweep off --no-cpu-baseline --steps 10 --warmup 3} > $O/$i.bench.json 2> $O/$i.bench.err; echo "[$i bench] rc=$?"; short $O/$i.bench.json ;;
     benchfull) timeout 2400 python bench.py > $O/$i.bench.json 2> $O/$i.bench.err; echo "[$i benchfull] rc=$?"; short $O/$i.bench.json ;;
