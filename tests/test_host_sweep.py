@@ -317,3 +317,86 @@ def test_resident_pixels_are_the_same_images():
         assert all(len(g) == -(-n // world) for g in got)
         flat = sorted({i for g in got for i in g})
         assert flat == sorted(ci * 100000 + i for ci, c in enumerate(spair) for i in range(c.n_images))
+
+
+# ------------------------------------------------------------------------------------------------ world 8 as eight real processes
+TWIN_SETTINGS = (S.Setting("CLIP336", "clip336", ("clip_a",), 42, 5), S.Setting("CLIP224", "clip224", ("clip_b",), 28, 7),
+                 S.Setting("DINOv2", "dino", ("dino_c",), 28, 4), S.Setting("CLIP224+DINOv2", "clip224+dino", ("clip_b", "dino_c"), 28, 3))
+
+
+class TwinModel:
+    """Tiny towers on the product's HOST twins (engine.VitEngineCPU = visrep_vit_forward_cpu; no oracle, no torch model): what a rank of the
+    sweep runs when its device is "cpu".  Projector = one fixed linear map (the sweep driver is what is under test)."""
+
+    def __init__(self, st):
+        from law_of_vision_representation_in_mllms_amd import engine, vit_weights as VW
+        self.setting = st
+        self.engines = []
+        for tid in st.towers:
+            fam = "clip" if tid.startswith("clip") else "dinov2"
+            spec = VW.tiny_spec(fam, image_size=st.size, patch=7, d=32, heads=2, mlp=64, layers=2)
+            w = VW.synthetic_weights(spec, seed=sum(map(ord, tid)))
+            self.engines.append((spec, engine.VitEngineCPU(spec, w, threads=1)))
+        g = torch.Generator().manual_seed(5 + len(st.towers))
+        self.proj = torch.randn(32 * len(st.towers), D_OUT, generator=g) * 0.2
+        self.split = 32 if len(st.towers) == 2 else 0
+
+    def tokens(self, px):
+        return torch.cat([e.forward(px.float(), n_layers=1)[:, (1 if s.has_cls else 0):] for s, e in self.engines], -1)
+
+    def project(self, tok):
+        return tok @ self.proj
+
+
+def _twin_ops():
+    """the score kernels' host twins behind the device entry points' signatures (explicit, as a device="cpu" caller wires them)"""
+    from law_of_vision_representation_in_mllms_amd import ascore_ops
+    cscore_ops.transfer = lambda bank, *a, **k: cscore_ops.transfer_cpu(bank.float().contiguous(), *a, **{x: v for x, v in k.items() if x not in ("packed", "sort_pairs")})
+    cscore_ops.pck_counts = cscore_ops.pck_counts_cpu
+    return (lambda o, r, os_=None, rs_=None: ascore_ops.max_cos_mean_cpu(o, r, threads=1)), (lambda x: None)
+
+
+def _twin_run():
+    hooks = _twin_ops()
+    return S.run_sweep(TWIN_SETTINGS, n_a_images=19, spair=S.synthetic_spair(n_images=21, n_pairs=30, kmax=6, seed=4, categories=("aeroplane", "cat", "dog", "bus", "tvmonitor")),
+                       device="cpu", build=TwinModel, pixels=fake_pixels, a_hooks=hooks)
+
+
+def _twin_worker(rank, world, port, q):
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _twin_run()
+    q.put((rank, {k: (v["A"], v["pck"]) for k, v in out["per_setting"].items()}, out["world"], out["images"], out["scaling_row"]["n_gpus"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_8_processes(monkeypatch):
+    """The WHOLE sweep (A leg with its all-reduce, C leg with the owner-addressed all_to_all exchange and the all_gather_object of the category
+    results) as EIGHT gloo processes on the host twins - 19 A images and 21 C images over 8 ranks: ragged shares, ranks whose share of a
+    launch is empty, owners without a category - equals the single-process run: A to 1e-6 relative (fp32 sums re-associated by the all-reduce),
+    PCK exactly."""
+    monkeypatch.setattr(cscore_ops, "transfer", cscore_ops.transfer)          # _twin_ops rebinds them: restore after the test
+    monkeypatch.setattr(cscore_ops, "pck_counts", cscore_ops.pck_counts)
+    single = _twin_run()
+    assert single["world"] == 1 and "predicted" in single["scaling_row"]
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_twin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g[0] for g in got) == list(range(world))
+    for rank, per, w, images, n in got:
+        assert w == world and n == world and images == single["images"]
+        for st in TWIN_SETTINGS:
+            a1, pck1 = single["per_setting"][st.name]["A"], single["per_setting"][st.name]["pck"]
+            assert abs(per[st.name][0] - a1) <= 1e-6 * abs(a1), (rank, st.name, per[st.name][0], a1)
+            np.testing.assert_array_equal(per[st.name][1], pck1, err_msg=f"rank {rank} {st.name}")
