@@ -23,7 +23,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libvisrep_hip.so")
 # the product library: GEMM v1 (128x128: tails, split-K, N % 256 != 0, implicit convolution), v2 (K % 64 != 0), v5 (default), attn_fwd
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v5.hip", "attention.hip", "rowops.hip", "convnet.hip", "conv_halo.hip", "conv_in.hip", "ascore.hip", "ascore_ref.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_v2.hip", "gemm_bf16_v5.hip", "gemm_bf16_duo.hip", "attention.hip", "rowops.hip", "convnet.hip", "conv_halo.hip", "conv_in.hip", "ascore.hip", "ascore_ref.hip",
            "cscore.hip", "f32ops.hip", "jpeg_decode.hip", "host_twins.hip", "visrep_abi.hip"]
 # measured dead ends (GEMM v3 / v4, attn_fwd_ab): since round 5 they live as a patch (tools/experiments/dead_end_kernels_r2_r3.patch adds the three
 # files back); with it applied, build_experiments_lib() compiles them into the tools-only libvisrep_hip_exp.so (-DVISREP_EXPERIMENTS) - never

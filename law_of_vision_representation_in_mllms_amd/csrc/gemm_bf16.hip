@@ -325,7 +325,17 @@ int visrep_scratch_register(bool any_stream, hipStream_t s, void* ptr, size_t by
 }
 
 namespace {
+// variant 6: the duo kernel (gemm_bf16_duo.hip: two independent 4-wave workgroups per CU, 256 x 128 tiles) wherever it supports the problem;
+// variant 7: for N <= 1024 only (out-proj, fc2, V^T: the shapes whose epilogue is the largest share of a tile).  Everything else as variant 5.
+bool duo_wanted(const GemmArgs& a, int variant) {
+    return variant >= 6 && visrep_gemm_duo_supports(a) && !a.gn_partial && a.a_period <= 0 && (variant != 7 || a.N <= 1024);
+}
 int dispatch_one(const GemmArgs& a, hipStream_t s, int variant) {
+    if (duo_wanted(a, variant)) {
+        visrep_count_route(VISREP_ROUTE_GEMM_256);
+        return visrep_gemm_duo_dispatch(a, s, variant != 8);       // 8 = the unpipelined first build (kept for the table in profiles/round6_gemm.md)
+    }
+    if (variant >= 6) variant = 5;
     if (a.conv) {                                              // implicit 3x3 convolution: the 256x256 kernel when whole rounds of its tiles exist
 #ifndef VISREP_NO_CONV5                                           // A/B builds (tools/): every convolution on the 128x128 kernel, as until round 4
         if (variant == 5 && visrep_gemm_v5_supports_conv(a) && (long)((a.M + 255) / 256) * (a.N / 256) >= 2L * visrep_cu_count()) {
@@ -423,7 +433,7 @@ int try_split_k(const GemmArgs& a, hipStream_t s) {
 namespace {
 // the statistics-emitting epilogue exists in the 256x256 v2 kernel only
 bool v2_emits_stats(const GemmArgs& a, int variant) {
-    return a.stat_rt && a.stat_partial && a.epi == EPI_RESID && !a.conv && (variant == 2 || variant == 5) && visrep_gemm_v2_supports(a) && a.N % 128 == 0;   // v5 falls back to v2 when K % 64 != 0: both emit
+    return a.stat_rt && a.stat_partial && a.epi == EPI_RESID && !a.conv && (variant == 2 || variant >= 5) && visrep_gemm_v2_supports(a) && a.N % 128 == 0;   // v5 falls back to v2 when K % 64 != 0: both emit
 }
 // rows [0, a.M) of a finished residual GEMM -> a.stat_rt: from the epilogue's partial sums, else by reading the rows back
 int finish_stats(const GemmArgs& a, bool from_partials, hipStream_t s) {
@@ -453,7 +463,7 @@ bool conv5_ok(const GemmArgs& a, int variant) {
 #ifdef VISREP_NO_CONV5
     return false;
 #else
-    return variant == 5 && visrep_gemm_v5_supports_conv(a);
+    return variant >= 5 && visrep_gemm_v5_supports_conv(a);
 #endif
 }
 }  // namespace
@@ -478,7 +488,8 @@ int visrep_gemm_dispatch(const GemmArgs& a, hipStream_t s) {
     // remainder that would cost a whole extra round on 252 idle CUs.  When the remainder is small, the rows of the last
     // round are split off and run as 128x128 tiles (v1), which spread over many CUs and finish in a fraction of a round.
     if (variant >= 2 && a.N % 256 == 0 && a.epi != EPI_PATCH && (!a.conv || conv5_ok(a, variant))) {
-        const int ncu = cu_count(), ntn = a.N / 256, ntm = (a.M + 255) / 256;
+        const bool duo = duo_wanted(a, variant);                         // 256 x 128 tiles, two workgroups per CU: rounds of 2 x CUs tiles
+        const int ncu = duo ? 2 * cu_count() : cu_count(), ntn = a.N / (duo ? 128 : 256), ntm = (a.M + 255) / 256;
         const long tiles = (long)ntm * ntn, rounds = tiles / ncu, rem = tiles % ncu;
         if (rounds >= 1 && rem > 0 && rem * 4 <= ncu && (rounds * ncu) % ntn == 0) {
             const int m1 = (int)(rounds * ncu / ntn) * 256;             // rows covered by the full rounds

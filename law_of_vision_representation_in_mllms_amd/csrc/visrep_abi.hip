@@ -103,11 +103,11 @@ extern "C" int visrep_debug_mfma_probe(int iters, int random, void* sink, double
 
 extern "C" int visrep_set_gemm_variant(int variant) {            // per-thread (see visrep_internal.h); returns the previous value
 #ifdef VISREP_EXPERIMENTS
-    const bool ok = variant >= 1 && variant <= 5;
+    const bool ok = variant >= 1 && variant <= 8;
 #else
-    const bool ok = variant == 1 || variant == 2 || variant == 5;
+    const bool ok = variant == 1 || variant == 2 || variant == 5 || variant == 6 || variant == 7 || variant == 8;
 #endif
-    if (!ok) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1, 2 or 5 (3 / 4: VISREP_EXPERIMENTS builds only)");
+    if (!ok) return visrep_set_error(VISREP_ERR_ARG, "gemm variant must be 1, 2, 5, 6, 7 or 8 (3 / 4: VISREP_EXPERIMENTS builds only)");
     const int old = t_visrep_gemm_variant;
     t_visrep_gemm_variant = variant;
     return old;

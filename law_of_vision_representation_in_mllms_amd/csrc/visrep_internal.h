@@ -94,6 +94,8 @@ int visrep_gemm_v2_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v4_supports(const GemmArgs& a);
 int visrep_gemm_v4_dispatch(const GemmArgs& a, hipStream_t s);
 bool visrep_gemm_v5_supports(const GemmArgs& a);
+bool visrep_gemm_duo_supports(const GemmArgs& a);                 // gemm_bf16_duo.hip (variants 6 / 7: A/B only)
+int visrep_gemm_duo_dispatch(const GemmArgs& a, hipStream_t s, bool pipelined);
 // Fills a.xcd_bounds (and, on every 8th launch of this (kernel, M, N, K), a.xb / a.xb_host / a.xb_seq) for a launch of `grid` persistent blocks
 // over `ntiles` output tiles on the current device.  VISREP_XCD_BALANCE=0 / visrep_set_xcd_balance(0): equal shares, nothing recorded.
 void visrep_xcd_plan(GemmArgs& a, hipStream_t s, int grid, int ntiles, const void* kernel);
@@ -105,7 +107,7 @@ extern int g_visrep_gemm_dbg;
 extern unsigned long long* g_visrep_gemm_dbg_buf;
 // Kernel-variant selection is PER-THREAD state (visrep_set_*_variant changes the calling thread's choice only): two threads - or two
 // engines on two GPUs driven from two threads - never see each other's diagnostic setting, and the defaults need no setter at all.
-extern thread_local int t_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 5 = 256x256 persistent ping-pong kernels (when N % 256 == 0); 3 / 4: VISREP_EXPERIMENTS builds; default 5
+extern thread_local int t_visrep_gemm_variant;   // 1 = 128x128 kernel, 2 / 5 = 256x256 persistent ping-pong kernels (when N % 256 == 0); 3 / 4: VISREP_EXPERIMENTS builds; 6 / 7 = the duo kernel (two 4-wave workgroups per CU) everywhere it applies / for N <= 1024 only, 8 = its unpipelined first build; default 5
 int visrep_attention_ab_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out, int ldo,
                                int B, int Tq, int Tk, int H, int kv_shared, int causal, float scale, hipStream_t st);
 extern thread_local int t_visrep_attn_variant;

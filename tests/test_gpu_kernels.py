@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(params=[1, 2, 5], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v5_256k64"])
+@pytest.fixture(params=[1, 2, 5, 6], ids=["gemm_v1_128", "gemm_v2_256", "gemm_v5_256k64", "gemm_v6_duo"])
 def gemm_variant(request):
     """Run a test under every GEMM kernel family of the product library (v2 / v5 fall back to v1 when N % 256 != 0; the measured dead
-    ends v3 / v4 live in the tools-only VISREP_EXPERIMENTS build)."""
+    ends v3 / v4 live in the tools-only VISREP_EXPERIMENTS build; 6 = the round-6 duo kernel, two 4-wave workgroups per CU on 256 x 128 tiles,
+    wherever N % 128 == 0 - an A/B variant, profiles/round6_gemm.md)."""
     lib = _lib.load()
     old = lib.visrep_set_gemm_variant(request.param)
     yield request.param
