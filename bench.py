@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--sweep-fp32-products", type=int, default=6, choices=[3, 4, 6])
     ap.add_argument("--sweep-alt-fp32-products", type=int, default=3, choices=[0, 3, 4, 6])   # the fp32 C legs once more on this set ("wall_s_fp32x3"); 0 = off
     ap.add_argument("--no-scores", action="store_true")
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 5])
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("VISREP_GEMM_VARIANT", "5")), choices=[1, 2, 5, 6, 7])   # 6 / 7: the round-6 duo kernel (A/B only, profiles/round6_gemm.md)
     args = ap.parse_args()
 
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # host-side weight packing: torch's default (128 here) thrashes, see cpu_baseline
@@ -482,7 +482,7 @@ def main():
         except Exception as e:
             power = {"error": f"{type(e).__name__}: {e}"[:200]}
         traffic, traffic_src = fc1_traffic(args.gemm_variant, B)
-        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 5: "gemm_bf16_256q"}[args.gemm_variant] + "<EPI_ACT> fc1",
+        roof = {"bound": "mfma", "kernel": {1: "gemm_bf16_128", 2: "gemm_bf16_256", 5: "gemm_bf16_256q"}.get(args.gemm_variant, "gemm_bf16_duo") + "<EPI_ACT> fc1",
                 "achieved": top["tflops_in_layer_mix"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(top["tflops_in_layer_mix"] / PEAK_BF16_TFLOPS, 4),
                 "timing": "HIP event pair around each fc1 dispatch (head launch + its 128x128 tail pair) inside the layer's launch mix, 12 layers' worth; "

@@ -46,7 +46,10 @@ size_t visrep_last_error(char* buf, size_t n);
  * implicit 3x3 convolution); 2 = 256x256 persistent ping-pong kernel, 64-byte LDS rows (runs when K % 64 != 0); 5 (default) = the same
  * structure with 128-byte LDS rows, a five-slot LDS-DMA ring and half the barriers (profiles/round2_gemm_v5.md).  2 and 5 need
  * N % 256 == 0.  Results are identical up to fp32 summation order.  (Variants 3 and 4 - measured dead ends, profiles/round2_gemm_v4.md -
- * exist only in the tools-only VISREP_EXPERIMENTS build.) */
+ * exist only in the tools-only VISREP_EXPERIMENTS build.)  6 / 7 / 8 (round 6, A/B only: measured 20-30 % slower, profiles/round6_gemm.md) =
+ * the "duo" kernel, two independent 4-wave workgroups per CU on 256 x 128 tiles (N % 128 == 0, K % 64 == 0, K >= 128; BIAS / ACT / RESID / VT
+ * epilogues, everything else runs as variant 5): 6 = wherever it applies, 7 = for N <= 1024 only, 8 = its unpipelined first build.  Bitwise
+ * equal to variant 5. */
 int visrep_set_gemm_variant(int variant);
 /* Attention forward at head width 64: 1 (default) = attn_fwd, the four-wave kernel that also serves head widths 128 / 192.  2 = attn_fwd_ab
  * (two 32-row query blocks per wave; measured equal-to-slower, profiles/round3_attention.md) exists only in the VISREP_EXPERIMENTS build;

@@ -190,3 +190,37 @@ def test_a_score_from_images_on_hostile_towers(products):
     print("hostile A", (products, got, want, abs(got - want) / abs(want), gbf, abs(gbf - want) / abs(want)))
     assert abs(got - want) <= 1e-4 * abs(want), (products, got, want)
     assert abs(gbf - want) <= 2e-2 * abs(want), (gbf, want)
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm of the diffusion towers on hostile statistics
+@pytest.mark.parametrize("ratio", [10.0, 30.0, 100.0])
+@pytest.mark.parametrize("B,HW,C", [(2, 9216, 128), (1, 36864, 128), (2, 2304, 512), (2, 576, 1280)])
+def test_groupnorm_with_large_group_means(B, HW, C, ratio):
+    """The diffusion towers' GroupNorm (csrc/convnet.hip: per-block partial sums of x and x^2 in fp32, variance = E[x^2] - mean^2) where that
+    formula is weakest: every group's |mean| is `ratio` x its standard deviation (VAE activations have such channels; N(0, 1)-like test data
+    does not).  Yardstick: torch's fp32 group_norm on the SAME bf16 inputs.  The error of E[x^2] - mean^2 grows like ratio^2 x (fp32 rounding of
+    the sums): measured 7e-6 / 1e-4 / 7e-4 relative error of rstd at ratio 10 / 30 / 100 - below the bf16 rounding of the output (1.7e-3 of the
+    normalised tensor, the same at every ratio) in all of them; the per-group statistics themselves (mean, rstd) are checked against float64."""
+    from law_of_vision_representation_in_mllms_amd import sd_engine as SE
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(int(ratio) + HW + C)
+    G = 32
+    cpg = C // G
+    sign = torch.where(torch.rand(G, generator=g) < 0.5, -1.0, 1.0)
+    mean_c = (sign * ratio).repeat_interleave(cpg) * (1 + 0.02 * torch.randn(C, generator=g))        # channels of a group share the large mean
+    x = (torch.randn(B, HW, C, generator=g) + mean_c).to(torch.bfloat16)
+    gam, bet = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    want = F.silu(F.group_norm(x.float().permute(0, 2, 1), G, gam, bet, 1e-6)).permute(0, 2, 1)
+    xd = x.view(B * HW, C).to(DEV)
+    got = SE.groupnorm(xd, gam.to(DEV), bet.to(DEV), B, G, 1e-6, True).view(B, HW, C)
+    err = ((got.float().cpu() - want).norm() / want.norm()).item()
+    st = SE.groupnorm_stats(xd, B, G, 1e-6).cpu().double()                                          # [B, G, 2] = (mean, rstd)
+    x64 = x.double().view(B, HW, G, cpg)
+    m64 = x64.mean(dim=(1, 3))
+    r64 = 1.0 / torch.sqrt(x64.var(dim=(1, 3), unbiased=False) + 1e-6)
+    e_mean = ((st[..., 0] - m64).abs() / m64.abs()).max().item()
+    e_rstd = ((st[..., 1] - r64).abs() / r64).max().item()
+    print("hostile GN", (B, HW, C, ratio, err, e_mean, e_rstd))
+    assert e_mean < 1e-5, (B, HW, C, ratio, e_mean)
+    assert e_rstd < (3e-4 if ratio <= 30 else 2e-3), (B, HW, C, ratio, e_rstd)     # measured: 7e-6 / 6e-5..1.3e-4 / 1.7e-4..6.7e-4 at ratio 10 / 30 / 100
+    assert err < 3e-3, (B, HW, C, ratio, err)                                        # measured 1.5e-3..1.7e-3 everywhere: the bf16 rounding of the OUTPUT
