@@ -307,6 +307,12 @@ int visrep_groupnorm_f32(const float* x, const float* gamma, const float* beta, 
 int visrep_gram_pairs_f32(const float* bank, const int* idx1, const int* idx2, int n_pairs, int PP, int C, float* gram, void* stream);
 int visrep_row_rnorm_f32(const float* x, long rows, int C, float eps, float* r, void* stream);
 int visrep_mutual_nn_distance(const float* gram, const float* r1, const float* r2, int n_pairs, int PP, float eps, float* out, void* stream);
+/* ADAPT_FLIP WITHOUT MUTUAL_NN (C_score/pck_train.py:122-124 -> utils/utils_correspondence.py:22-52 get_distance, the mask-based flip
+ * distance; round 6): the search of lines 41-50 - for every source cell (row of src [ns, C]: the cells inside the source mask) the squared
+ * Euclidean distance to the nearest of the nt target cells (rows of tgt [nt, C]), difference first as the reference computes it (its operands
+ * hold -100000 where a mask or an exact zero was), -> min_d2 [ns] fp32.  The resize / mask / substitution steps of lines 23-37 are the host
+ * side's (cscore_ops.masked_nn_distance); the mean of sqrt(min_d2) is the reference's return value.  C % 4 == 0. */
+int visrep_masked_nn_min_f32(const float* src, const float* tgt, int ns, int nt, int C, float* min_d2, void* stream);
 
 /* ---- JPEG decode for the device input pipeline.  Replaces PIL's Image.open(path).convert('RGB') of the reference's
  * image loaders (C_score/extract_feature.py:65-66, llava/mm_utils.py:78-95, llava/feature/extract.py:198-214) bit for bit; what PIL runs

@@ -28,7 +28,8 @@ import torch
 from .. import cscore_ops
 from .model_utils.projection_network import DummyAggregationNetwork
 from .utils.logger import get_logger, load_config, log_geo_stats, log_weighted_pcks, update_geo_stats, update_stats
-from .utils.utils_correspondence import calculate_keypoint_transformation, kpts_to_patch_idx, kpts_to_patch_idx_batch  # noqa: F401 (API parity)
+from .utils.utils_correspondence import (calculate_keypoint_transformation, convert_to_binary_mask, get_distance, get_distance_mutual_nn,  # noqa: F401 (API parity)
+                                         kpts_to_patch_idx, kpts_to_patch_idx_batch)
 from .utils.utils_dataset import get_dataset_info, load_eval_data
 from .utils.utils_geoware import AP10K_GEO_AWARE, SPAIR_GEO_AWARE, filtered_groups, geo_aware_points, renumber_used_points
 
@@ -49,10 +50,20 @@ def _feature_path(img_path, flip, ensemble, model):
     return f"{feature_base}_{model}{suffix_flip}.pt".replace('features', ensemble_folder)
 
 
+def _mask_path(img_path, flip):
+    # pck_train.py:33-36: `<feature_base>_mask[_flip].png` (next to the features, never in the ensemble folder)
+    return f"{img_path.replace('JPEGImages', 'features').replace('.jpg', '')}_mask{'_flip' if flip else ''}.png"
+
+
+def _load_mask(img_path, flip):
+    path = _mask_path(img_path, flip)
+    return convert_to_binary_mask(path) if os.path.exists(path) else None          # pck_train.py:40-43
+
+
 def prepare_feature_paths_and_load(aggre_net, img_path, flip, ensemble, num_patches, device, model):
     desc = torch.load(_feature_path(img_path, flip, ensemble, model), map_location="cpu").to(device)
     desc = aggre_net(desc).reshape(1, 1, -1, num_patches ** 2).permute(0, 1, 3, 2)
-    return desc, None
+    return desc, _load_mask(img_path, flip)
 
 
 def get_patch_descriptors(args, aggre_net, num_patches, files, pair_idx, flip=False, flip2=False, img1=None, img2=None,
@@ -98,10 +109,6 @@ def compute_pck(args, save_path, aggre_net, files, kps, category=None, used_poin
 def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, thresholds, bank, models, local=False):
     """local: this rank evaluates ALL pairs of the category by itself (sweep.py: categories are owned by ranks) - no pair sharding, no collective."""
     adapt_flip = bool(getattr(args, "ADAPT_FLIP", False))
-    if adapt_flip and not getattr(args, "MUTUAL_NN", False):
-        # pck_train.py:122-124: without MUTUAL_NN the flip decision uses get_distance, which is hard-wired to 60x60 SD+DINO maps and
-        # SAM masks (utils_correspondence.py:22-52) - it cannot run on any other feature grid in the reference either
-        raise NotImplementedError("ADAPT_FLIP needs MUTUAL_NN here: the mask-based get_distance only accepts 60x60 maps (SURVEY §8f N4)")
     if adapt_flip and len(models) != 1:
         raise NotImplementedError("ADAPT_FLIP is defined by pck_train.py only (pck_train_two.py has no flip branch that reads two encoders)")
     if getattr(args, "TOTAL_SAVE_RESULT", 0):
@@ -213,7 +220,8 @@ def _compute_pck(args, save_path, aggre_net, files, kps, category, used_points, 
 def _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t, layout, slot, sl, src, trg, xy, P, dev, models):
     """ADAPT_FLIP of compute_pck (pck_train.py:82-94,111-126) for this rank's pair block: a second keypoint transfer from the MIRRORED
     source image's features (`<img>_<MODEL>_flip.pt`) with the mirrored, left/right-permuted key points, the mutual-nearest-neighbour
-    distance of both source variants to the target (get_distance_mutual_nn), and per pair the reference's choice between the two."""
+    distance of both source variants to the target (get_distance_mutual_nn) - or, without MUTUAL_NN, the mask-based get_distance - and per
+    pair the reference's choice between the two."""
     from .utils.utils_geoware import AP10K_FLIP, SPAIR_FLIP, flip_keypoints, flip_permutation, optimized_kps_1_to_2, permute_indices
     if layout != "pc":
         raise NotImplementedError("ADAPT_FLIP needs channel counts that are multiples of 4 (position-major bank)")
@@ -245,8 +253,26 @@ def _adapt_flip(args, aggre_net, files, kps, category, used_points, bank, bank_t
     nkp = torch.full((hi - lo,), K, dtype=torch.int32)
     xy_f = cscore_ops.transfer(both, src_f, trg, torch.from_numpy(idx_f), nkp, P, window=args.SOFT_EVAL_WINDOW,
                                soft_eval=bool(args.SOFT_EVAL), anno_size=args.ANNO_SIZE, layout="pc")
-    d_orig = cscore_ops.mutual_nn_distance(both, src, trg, P).cpu()
-    d_flip = cscore_ops.mutual_nn_distance(both, src_f, trg, P).cpu()
+    if getattr(args, "MUTUAL_NN", False):
+        d_orig = cscore_ops.mutual_nn_distance(both, src, trg, P).cpu()
+        d_flip = cscore_ops.mutual_nn_distance(both, src_f, trg, P).cpu()
+    else:
+        # pck_train.py:122-124: the mask-based get_distance (utils_correspondence.py:22-52) on the normalised descriptors of the pair and the
+        # `_mask.png` / `_mask_flip.png` files next to the features (round 6; the reference hard-codes 60 x 60 maps, this takes any square grid).
+        # Masks of a caller-provided bank: bank[5] = (masks, flipped source masks), lists indexed like the bank's / the flip bank's images.
+        if bank is not None and len(bank) > 5:
+            masks, fmasks = bank[5]
+            mask_of = lambda i, which: (masks[int(slot[2 * i + which])] if masks is not None else None)
+            fmask_of = lambda n: (fmasks[int(src_f[n]) - n_img] if fmasks is not None else None)
+        else:
+            mask_of = lambda i, which: _load_mask(files[2 * i + which], False)
+            fmask_of = lambda n: _load_mask(files[2 * (lo + n)], True)
+        norm = lambda m: m / (torch.linalg.norm(m, dim=-1, keepdim=True) + 1e-10)              # normalize_feats (pck_train.py:24-29)
+        d_orig, d_flip = torch.empty(hi - lo), torch.empty(hi - lo)
+        for n, i in enumerate(range(lo, hi)):
+            t_desc, m2 = norm(both[int(trg[n])]), mask_of(i, 1)
+            d_orig[n] = cscore_ops.masked_nn_distance(norm(both[int(src[n])]), t_desc, mask_of(i, 0), m2).item()
+            d_flip[n] = cscore_ops.masked_nn_distance(norm(both[int(src_f[n])]), t_desc, fmask_of(n), m2).item()
     out = xy.clone()
     xy_c, xyf_c = xy.cpu(), xy_f.cpu()
     for n, i in enumerate(range(lo, hi)):

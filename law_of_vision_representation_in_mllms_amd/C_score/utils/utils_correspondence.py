@@ -42,6 +42,24 @@ def calculate_keypoint_transformation(args, img1_desc, img2_desc, img1_patch_idx
     return torch.cat(outs, 0)
 
 
+def convert_to_binary_mask(img_path, threshold=127, angle=None):
+    """utils_correspondence.py:6-20: a mask image -> float32 {0, 1} tensor [H, W] (grey level > threshold)."""
+    import numpy as np
+    from PIL import Image
+    img = Image.open(img_path).convert('L')
+    if angle is not None:
+        img = img.rotate(angle)
+    return (torch.from_numpy(np.array(img)) > threshold).float()
+
+
+def get_distance(feature1, feature2, mask1, mask2, RESOLUTION=64):
+    """utils_correspondence.py:22-52: the mask-based flip distance (ADAPT_FLIP without MUTUAL_NN, pck_train.py:122-124).  feature* [1, P^2, C]
+    normalised descriptors, mask* [H, W] binary masks -> 0-dim tensor.  The reference reshapes to 60 x 60 whatever it is given (so it only
+    runs on 60 x 60 maps); this one takes any square grid and equals it at 60 (tests/golden/maskdist.npz).  cscore_ops.masked_nn_distance."""
+    from ... import cscore_ops
+    return cscore_ops.masked_nn_distance(feature1.cuda(), feature2.cuda(), mask1, mask2, RESOLUTION)
+
+
 def get_distance_mutual_nn(feature1, feature2):
     """utils_correspondence.py:54-73: feature* [1, P^2, C] descriptors -> mean cdist over the mutual nearest neighbours (a 0-dim tensor).
     Runs visrep_gram_pairs_f32 + visrep_mutual_nn_distance; the descriptors are L2-normalised there (idempotent for the reference's

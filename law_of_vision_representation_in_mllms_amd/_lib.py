@@ -106,6 +106,7 @@ SIGNATURES = {
     "visrep_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp]),
     "visrep_gram_pairs_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_row_rnorm_f32": (_i, [_vp, _l, _i, _f, _vp, _vp]),
+    "visrep_masked_nn_min_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "visrep_device_cu_count": (_i, []),
     "visrep_set_reserved_cus": (_i, [_i]),
     "visrep_set_gemm_walk": (_i, [_i]),

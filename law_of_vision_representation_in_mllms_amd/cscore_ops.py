@@ -208,6 +208,43 @@ def mutual_nn_distance(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tenso
     return out
 
 
+@torch.no_grad()
+def masked_nn_distance(desc1: torch.Tensor, desc2: torch.Tensor, mask1: torch.Tensor, mask2: torch.Tensor, resolution: int = 64) -> torch.Tensor:
+    """The mask-based flip distance of ADAPT_FLIP without MUTUAL_NN (utils_correspondence.py:22-52 get_distance, called at pck_train.py:122-124)
+    on the device.  desc* [1 | -, P^2, C] L2-normalised descriptors of one image each (the reference hard-codes P = 60; any square grid here),
+    mask* [H, W] binary masks (convert_to_binary_mask).  Lines 23-37 - bilinear resize of the maps and nearest resize of the masks to
+    resolution^2, masking, `== 0 -> -100000` - are torch glue on the device; the search of lines 41-50 (4096 x 4096 x C differences) is
+    visrep_masked_nn_min_f32.  Returns a 0-dim fp32 tensor (nan for an empty source mask, like the reference's empty mean)."""
+    import torch.nn.functional as F
+    if mask1 is None or mask2 is None:
+        raise AttributeError("'NoneType' object has no attribute 'unsqueeze' (get_distance needs the `_mask.png` of both images: "
+                             "prepare_feature_paths_and_load found none, as in the reference, utils_correspondence.py:27)")
+    d1, d2 = desc1.reshape(-1, desc1.shape[-1]), desc2.reshape(-1, desc2.shape[-1])
+    P = int(round(d1.shape[0] ** 0.5))
+    if P * P != d1.shape[0] or d2.shape != d1.shape:
+        raise ValueError("descriptors must be two [P*P, C] maps of one square grid")
+    lib = _lib.require_gpu()
+    dev = d1.device
+    R, C_ = int(resolution), d1.shape[1]
+    m1 = F.interpolate(mask1.to(dev).float()[None, None], size=(R, R), mode="nearest")[0, 0]
+    m2 = F.interpolate(mask2.to(dev).float()[None, None], size=(R, R), mode="nearest")[0, 0]
+    f1 = F.interpolate(d1.float().t().reshape(1, C_, P, P), size=(R, R), mode="bilinear")[0] * m1[None]
+    f2 = F.interpolate(d2.float().t().reshape(1, C_, P, P), size=(R, R), mode="bilinear")[0] * m2[None]
+    f1 = torch.where(f1 == 0, torch.full_like(f1, -100000.0), f1).reshape(C_, R * R).t()
+    f2 = torch.where(f2 == 0, torch.full_like(f2, -100000.0), f2).reshape(C_, R * R).t()
+    pad = (-C_) % 4                                                   # zero channels on both sides add nothing to a difference
+    src = f1[m1.reshape(-1) == 1]
+    if pad:
+        src, f2 = F.pad(src, (0, pad)), F.pad(f2, (0, pad))
+    src, tgt = src.contiguous(), f2.contiguous()
+    if src.shape[0] == 0:
+        return torch.tensor(float("nan"), device=dev)
+    d2min = torch.empty(src.shape[0], dtype=torch.float32, device=dev)
+    _lib.check(lib.visrep_masked_nn_min_f32(_lib.ptr(src), _lib.ptr(tgt), src.shape[0], tgt.shape[0], src.shape[1], _lib.ptr(d2min), _lib.stream_ptr()),
+               "visrep_masked_nn_min_f32")
+    return d2min.sqrt().mean()
+
+
 # ------------------------------------------------------------------------------------------------ host twins (explicit device "cpu" only)
 @torch.no_grad()
 def transfer_cpu(bank: torch.Tensor, img1, img2, patch_idx, nkp, P: int, window: int = 5, soft_eval: bool = True, beta: float = 0.02,

@@ -462,6 +462,63 @@ extern "C" int visrep_mutual_nn_distance(const float* gram, const float* r1, con
     return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "mutual_nn_distance: launch failed");
 }
 
+// ---- nearest-neighbour search of the MASK-based flip distance (utils_correspondence.py:41-50 get_distance: for every source cell inside its mask
+// the Euclidean distance to the nearest target cell).  Operands arrive as the reference builds them - resized, masked, zeros replaced by
+// -100000 - so distances are computed difference FIRST (line 47: norm(tgt - src)): a Gram-matrix form would cancel 1e10-sized squares.  A
+// workgroup owns a 64 x 64 tile of (source cell, target cell) pairs, 4 x 4 per thread, channels staged through LDS sixteen at a time; the
+// running minimum of a source row is kept as the bit pattern of a non-negative float (order-preserving), one atomicMin per row and tile.
+__global__ __launch_bounds__(256) void masked_nn_min(const float* __restrict__ S, const float* __restrict__ T, unsigned* __restrict__ out, int ns, int nt, int C) {
+    __shared__ float sS[16][64], sT[16][64];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int s0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    const int lr = tid >> 2, lc = (tid & 3) * 4;                   // this thread stages row lr, channels lc .. lc + 3 of both tiles
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 16) {
+        float4 vs = float4{0.f, 0.f, 0.f, 0.f}, vt = float4{0.f, 0.f, 0.f, 0.f};      // rows / channels past the end: zeros on both sides (difference 0)
+        if (c0 + lc < C) {                                             // C % 4 == 0
+            if (s0 + lr < ns) vs = *reinterpret_cast<const float4*>(S + (size_t)(s0 + lr) * C + c0 + lc);
+            if (t0 + lr < nt) vt = *reinterpret_cast<const float4*>(T + (size_t)(t0 + lr) * C + c0 + lc);
+        }
+        sS[lc][lr] = vs.x; sS[lc + 1][lr] = vs.y; sS[lc + 2][lr] = vs.z; sS[lc + 3][lr] = vs.w;
+        sT[lc][lr] = vt.x; sT[lc + 1][lr] = vt.y; sT[lc + 2][lr] = vt.z; sT[lc + 3][lr] = vt.w;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(&sS[k][ty * 4]), b = *reinterpret_cast<const float4*>(&sT[k][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = bv[j] - av[i]; acc[i][j] = __builtin_fmaf(d, d, acc[i][j]); }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float m = 3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (t0 + tx * 4 + j < nt) m = fminf(m, acc[i][j]);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) m = fminf(m, __shfl_xor(m, o));       // the sixteen threads of a source-row group are consecutive lanes
+        if (tx == 0 && s0 + ty * 4 + i < ns) atomicMin(out + s0 + ty * 4 + i, __float_as_uint(m));
+    }
+}
+
+extern "C" int visrep_masked_nn_min_f32(const float* src, const float* tgt, int ns, int nt, int C, float* min_d2, void* stream) {
+    if (ns <= 0) return 0;
+    if (!src || !tgt || !min_d2) return visrep_set_error(VISREP_ERR_ARG, "masked_nn_min: null pointer");
+    if (nt <= 0 || C <= 0 || (C & 3)) return visrep_set_error(VISREP_ERR_SHAPE, "masked_nn_min: need targets and C % 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(min_d2, 0x7f, (size_t)ns * sizeof(float), st) != hipSuccess)      // 0x7f7f7f7f = 3.39e38: above every squared distance of finite operands
+        return visrep_set_error(VISREP_ERR_LAUNCH, "masked_nn_min: memset failed");
+    hipLaunchKernelGGL(masked_nn_min, dim3((nt + 63) / 64, (ns + 63) / 64), dim3(256), 0, st, src, tgt, reinterpret_cast<unsigned*>(min_d2), ns, nt, C);
+    return hipGetLastError() == hipSuccess ? 0 : visrep_set_error(VISREP_ERR_LAUNCH, "masked_nn_min: launch failed");
+}
+
 extern "C" int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
                                       const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window,
                                       int soft_eval, float beta, float anno_stride, float anno_half, int layout, void* stream) {

@@ -9,6 +9,7 @@ Restates the zero-shot GeoAware-SC evaluation arithmetic of the reference:
   * get_flow / soft_argmax / softmax_with_temperature /
     unnormalise_and_convert_mapping_to_flow
                                         C_score/utils/utils_correspondence.py:297-337,234-256,226-232,258-277
+  * get_distance (mask-based)           C_score/utils/utils_correspondence.py:22-52
   * per-image PCK                       C_score/pck_train.py:101,142-163
   * per-keypoint PCK                    C_score/pck_train.py:210-226
   * weighted aggregation                C_score/utils/logger.py:22-72
@@ -156,6 +157,32 @@ def mutual_nn_distance(desc1: torch.Tensor, desc2: torch.Tensor) -> torch.Tensor
     nn12, nn21 = torch.argmin(d, dim=1), torch.argmin(d, dim=0)
     mutual = nn21[nn12] == torch.arange(d.shape[0])
     return torch.min(d, dim=1)[0][mutual].mean()
+
+
+def masked_nn_distance(desc1: torch.Tensor, desc2: torch.Tensor, mask1: torch.Tensor, mask2: torch.Tensor, resolution: int = 64) -> torch.Tensor:
+    """utils_correspondence.py:22-52 get_distance (the flip decision of ADAPT_FLIP without MUTUAL_NN, pck_train.py:122-124): descriptors
+    [1, P^2, C] -> [C, P, P] maps (the reference hard-codes P = 60; here P = sqrt(P^2)), bilinearly resized to resolution^2 (align_corners =
+    False), the binary masks [H, W] nearest-resized to the same grid; features outside a mask - and every element that is exactly 0, inside or
+    outside (line 36-37 compares elementwise) - become -100000; for every SOURCE cell inside its mask the Euclidean distance to the nearest
+    target cell (difference first, then the norm: line 47); the mean of those distances (nan when the source mask is empty, as in the
+    reference: the mean of an empty tensor)."""
+    import torch.nn.functional as F
+    P = int(round(desc1.shape[-2] ** 0.5))
+    R = resolution
+    m1 = F.interpolate(mask1.float()[None, None], size=(R, R), mode="nearest")[0, 0]
+    m2 = F.interpolate(mask2.float()[None, None], size=(R, R), mode="nearest")[0, 0]
+    f1 = F.interpolate(desc1.reshape(-1, desc1.shape[-1]).t().reshape(1, -1, P, P).float(), size=(R, R), mode="bilinear")[0]
+    f2 = F.interpolate(desc2.reshape(-1, desc2.shape[-1]).t().reshape(1, -1, P, P).float(), size=(R, R), mode="bilinear")[0]
+    f1, f2 = f1 * m1[None], f2 * m2[None]
+    f1 = torch.where(f1 == 0, torch.full_like(f1, -100000.0), f1)
+    f2 = torch.where(f2 == 0, torch.full_like(f2, -100000.0), f2)
+    s2d, t2d = f1.reshape(f1.shape[0], -1).t(), f2.reshape(f2.shape[0], -1).t()
+    src = s2d[m1.reshape(-1) == 1]
+    if src.shape[0] == 0:
+        return torch.tensor(float("nan"))
+    # lines 44-49 loop over the source cells with norm(tgt - src[i]); cdist without the matmul shortcut is the same difference-first
+    # arithmetic for all of them at once (the Gram form would cancel the 1e10-sized squares of the -100000 entries)
+    return torch.cdist(src, t2d, compute_mode="donot_use_mm_for_euclid_dist").min(dim=1).values.mean()
 
 
 def permute_indices(flip_list, vis=None):

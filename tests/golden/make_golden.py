@@ -1234,9 +1234,45 @@ def gen_projector():
     print("projector.npz ok")
 
 
+def gen_maskdist():
+    """utils_correspondence.get_distance (C_score/utils/utils_correspondence.py:22-52; the flip decision of ADAPT_FLIP without MUTUAL_NN,
+    pck_train.py:122-124) run as it stands - its `.cuda()` calls made no-ops, nothing else changed - on 60x60 descriptor maps (the only
+    grid it accepts) with blob masks of different sizes, one case with exact zeros inside the mask (the `== 0 -> -100000` line compares
+    elementwise) and one with a small source mask."""
+    sys.path.insert(0, f"{REF}/C_score")
+    import utils.utils_correspondence as UC
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    rs = np.random.RandomState(91)
+    out = {}
+
+    def blob(h, w, cy, cx, ry, rx):
+        yy, xx = np.mgrid[0:h, 0:w]
+        return (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).astype(np.float32)
+
+    cases = {"a": (12, blob(90, 120, 45, 60, 30, 40), blob(90, 120, 40, 70, 25, 45), False),
+             "b": (8, blob(77, 64, 30, 30, 12, 9), blob(77, 64, 40, 32, 30, 28), False),
+             "zeros": (8, blob(64, 64, 32, 32, 20, 20), blob(64, 64, 30, 34, 22, 18), True)}
+    for tag, (C, m1, m2, zeros) in cases.items():
+        base = rs.standard_normal((3600, C)).astype(np.float32)
+        f1 = base + 0.5 * rs.standard_normal((3600, C)).astype(np.float32)
+        f2 = np.roll(base, 61, axis=0) + 0.5 * rs.standard_normal((3600, C)).astype(np.float32)
+        if zeros:                                      # post-ReLU-like maps: exact zeros survive the bilinear resize where a 2x2 neighbourhood is zero
+            f1, f2 = np.maximum(f1, 0), np.maximum(f2, 0)
+            f1[:600, :3] = 0
+            f2[1000:1800, 2:5] = 0
+        d = UC.get_distance(torch.from_numpy(f1)[None], torch.from_numpy(f2)[None], torch.from_numpy(m1), torch.from_numpy(m2))
+        out[f"{tag}.f1"], out[f"{tag}.f2"], out[f"{tag}.m1"], out[f"{tag}.m2"] = f1.astype(np.float16).astype(np.float32), f2.astype(np.float16).astype(np.float32), m1.astype(np.uint8), m2.astype(np.uint8)
+        # the stored descriptors are the fp16-rounded ones (fixture size): recompute the distance on exactly what is stored
+        d = UC.get_distance(torch.from_numpy(out[f"{tag}.f1"])[None], torch.from_numpy(out[f"{tag}.f2"])[None], torch.from_numpy(m1), torch.from_numpy(m2))
+        out[f"{tag}.dist"] = np.float64(d.item())
+        out[f"{tag}.f1"], out[f"{tag}.f2"] = out[f"{tag}.f1"].astype(np.float16), out[f"{tag}.f2"].astype(np.float16)
+    np.savez_compressed(f"{HERE}/maskdist.npz", **out)
+    print("maskdist.npz:", {k: float(v) for k, v in out.items() if k.endswith(".dist")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet", "maskdist"]
     with torch.no_grad():
         for w in which:
             {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize,
-             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet}[w]()
+             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet, "maskdist": gen_maskdist}[w]()

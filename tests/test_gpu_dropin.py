@@ -427,6 +427,56 @@ def test_adapt_flip_eval_on_device_matches_reference_eval(tmp_path):
     np.testing.assert_allclose(np.stack([r["src_kpts_pred"] for r in results]), zf["eval.pred"], atol=5e-3)
 
 
+def test_mask_distance_matches_the_reference():
+    """ADAPT_FLIP without MUTUAL_NN: cscore_ops.masked_nn_distance / the drop-in get_distance (visrep_masked_nn_min_f32 behind torch's resize glue)
+    against the reference's get_distance run as it stands on 60 x 60 maps (tests/golden/maskdist.npz, incl. the exact-zeros case whose answer is
+    dominated by -100000 entries: difference-first arithmetic), then against the oracle on grids the reference cannot take (P = 16, 24; C not a
+    multiple of 4; a one-cell source mask; an empty one)."""
+    from law_of_vision_representation_in_mllms_amd import cscore_ops
+    from law_of_vision_representation_in_mllms_amd.C_score.utils import utils_correspondence as UC
+    from oracle import cscore as OC
+    z = np.load(f"{G}/maskdist.npz")
+    for tag in ("a", "b", "zeros"):
+        f1, f2 = (torch.from_numpy(z[f"{tag}.{k}"].astype(np.float32))[None] for k in ("f1", "f2"))
+        m1, m2 = (torch.from_numpy(z[f"{tag}.{k}"].astype(np.float32)) for k in ("m1", "m2"))
+        want = float(z[f"{tag}.dist"])
+        got = UC.get_distance(f1, f2, m1, m2)
+        assert got.dim() == 0 and abs(got.item() - want) <= 2e-6 * abs(want), (tag, got.item(), want)
+    g = torch.Generator().manual_seed(4)
+    for P, C_ in ((16, 64), (24, 30), (16, 1024)):
+        base = torch.randn(P * P, C_, generator=g)
+        f1 = OC.normalize_feats((base + 0.4 * torch.randn(P * P, C_, generator=g))[None])
+        f2 = OC.normalize_feats((base.roll(5, 0) + 0.4 * torch.randn(P * P, C_, generator=g))[None])
+        m1, m2 = (torch.rand(40, 56, generator=g) > 0.6).float(), (torch.rand(33, 47, generator=g) > 0.3).float()
+        want = OC.masked_nn_distance(f1, f2, m1, m2).item()
+        got = cscore_ops.masked_nn_distance(f1.to(DEV), f2.to(DEV), m1, m2).item()
+        assert abs(got - want) <= 2e-6 * abs(want), (P, C_, got, want)
+        one = torch.zeros(64, 64)
+        one[10, 20] = 1
+        assert abs(cscore_ops.masked_nn_distance(f1.to(DEV), f2.to(DEV), one, m2).item() - OC.masked_nn_distance(f1, f2, one, m2).item()) < 1e-5
+        assert torch.isnan(cscore_ops.masked_nn_distance(f1.to(DEV), f2.to(DEV), torch.zeros(8, 8), m2))
+    with pytest.raises(AttributeError, match="unsqueeze"):
+        cscore_ops.masked_nn_distance(f1.to(DEV), f2.to(DEV), None, m2)
+
+
+def test_adapt_flip_with_the_mask_distance_on_device(tmp_path):
+    """pck_train.eval with ADAPT_FLIP, MUTUAL_NN off, on the mini tree with `_mask.png` / `_mask_flip.png` files: the device route (transfer
+    kernel + visrep_masked_nn_min_f32) equals the oracle chain pair by pair, and both branches of the flip decision are taken."""
+    from test_host_cscore import make_flip_tree, masked_flip_expectation, write_masks
+    from oracle import cscore as OC
+    root, z, zf = make_flip_tree(str(tmp_path))
+    cats = {"aeroplane": 4, "cat": 3}
+    write_masks(root, cats)
+    a = eval_args(root, 16)
+    a.ADAPT_FLIP, a.MUTUAL_NN = True, False
+    p10, p05, p01, results = PT.eval(a, PT.DummyAggregationNetwork(), str(tmp_path), split="test")
+    want, flips = masked_flip_expectation(root, a, z, zf, cats, lambda *x: OC.masked_nn_distance(*x).item())
+    assert 0 < flips < len(want)
+    got = np.stack([r["src_kpts_pred"] for r in results])
+    for n, (w, used) in enumerate(want):
+        np.testing.assert_allclose(got[n][used.numpy()], w.numpy(), atol=5e-3, err_msg=str(n))
+
+
 @pytest.mark.parametrize("tag", ["small", "wide"])
 def test_aggregation_network_on_device_matches_reference(tag):
     """GeoAware-SC's supervised post-processor (projection_network.py:15-125) on the exact-fp32 path vs the reference module's output."""
