@@ -102,7 +102,9 @@ int visrep_debug_mfma_probe(int iters, int random, void* sink, double* flop, voi
  * pinned host memory; the following launches of that shape give every XCD whole rounds in proportion to its speed.  Results are bitwise
  * independent of the split.  OFF by default: a round of tiles is 2.8 % of a block's work at the headline shapes, as large as the effect, and
  * the same-box A/B measured +0.1 .. +0.3 % on the forward (profiles/round5_gemm.md section 3).  visrep_set_xcd_balance(1) (or
- * VISREP_XCD_BALANCE=1 in the environment) switches it on, process-wide; returns the previous setting.  visrep_debug_xcd_balance: the smoothed relative time per round of each XCD (1 = mean; rel8 may
+ * VISREP_XCD_BALANCE=1 in the environment) switches it on, process-wide; returns the previous setting.  Launches that are being CAPTURED into a
+ * HIP graph always run with equal shares and are never measurements (a plan baked into a graph would be replayed with capture-time bounds forever):
+ * the split serves eager launches only - the ViT / diffusion engines' graph replays are unaffected by it.  visrep_debug_xcd_balance: the smoothed relative time per round of each XCD (1 = mean; rel8 may
  * be NULL) of the shape launched most recently on the current device, and the number of measurements folded in so far; returns the setting. */
 int visrep_set_xcd_balance(int on);
 int visrep_debug_xcd_balance(float* rel8, unsigned* updates);
