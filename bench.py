@@ -478,7 +478,7 @@ def main():
                         "throttle": ("power cap" if (t.get("frac_of_cap_samples_ge_95pct") or 0) >= 0.5 else "none seen")}
             power = {"fc1_loop": brief(telemetry.measure(fc1, 1.0, index=local)), "forward": brief(telemetry.measure(step, 1.5, index=local)),
                      "how": "hwmon power1_input / freq1_input of the card this process computes on, background thread, while the launch repeats; "
-                            "sclk at the nominal peak is 2400 MHz"}
+                            "sclk at the nominal peak is 2400 MHz; ppt_residency is decoded from the binary gpu_metrics table without an independent check: indicative only"}
         except Exception as e:
             power = {"error": f"{type(e).__name__}: {e}"[:200]}
         traffic, traffic_src = fc1_traffic(args.gemm_variant, B)
