@@ -400,3 +400,77 @@ def test_world_8_processes(monkeypatch):
             a1, pck1 = single["per_setting"][st.name]["A"], single["per_setting"][st.name]["pck"]
             assert abs(per[st.name][0] - a1) <= 1e-6 * abs(a1), (rank, st.name, per[st.name][0], a1)
             np.testing.assert_array_equal(per[st.name][1], pck1, err_msg=f"rank {rank} {st.name}")
+
+
+# ------------------------------------------------------------------------------------------------ round 6: the x3 leg beside the x6 one; the scaling prediction
+class ThreeLegModel(TwoLegModel):
+    """reference mode with a second fp32 product set: `alt_c_towers` / `c_tokens_alt` (SettingModel(alt_fp32_products=...))"""
+
+    def __init__(self, st):
+        super().__init__(st)
+        self.alt_c_towers = [object()] if self.dtypes["c"] == "fp32" else None
+        if self.alt_c_towers:
+            self.dtypes["c_alt"] = "fp32[split-bf16 x3]"
+        self.calls["alt"] = 0
+
+    def c_tokens_alt(self, px):
+        self.calls["alt"] += 1
+        return FakeModel.tokens(self, px) + 0.25                      # the same maps as the C leg: the alternative set changes speed, not results
+
+
+def test_alt_product_set_runs_beside_the_reference_leg_and_the_split_timing_adds_up(cpu_ops):
+    """bench.py's sweep since round 6: `wall_s` = the fp32-equivalent (x6) C legs, `wall_s_fp32x3` = the same sweep with those legs swapped for the
+    throughput set's (timed the same way), per-setting "c_s_fp32x3" / "pck_fp32x3"; the C leg's wall-clock is split into its tower part and its
+    evaluation part (what predict_scaling shards differently)."""
+    models = {}
+
+    def build(st):
+        models[st.name] = ThreeLegModel(st)
+        return models[st.name]
+    out = S.run_sweep(SETTINGS, n_a_images=7, spair=spair_small(), device="cpu", build=build, pixels=fake_pixels, a_hooks=HOOKS, precision="reference",
+                      also_bf16=True, fp32_products=6, alt_fp32_products=3)
+    assert "wall_s_fp32x3" in out and "wall_s_all_bf16" in out
+    swap = 0.0
+    for st in SETTINGS:
+        ent, m = out["per_setting"][st.name], models[st.name]
+        assert abs(ent["c_tower_s"] + ent["c_eval_s"] - ent["c_s"]) < 5e-3 and ent["c_tower_s"] > 0 and ent["c_eval_s"] > 0
+        if m.alt_c_towers:
+            assert m.calls["alt"] > 0 and ent["dtype"]["c_alt"] == "fp32[split-bf16 x3]"
+            np.testing.assert_allclose(ent["pck_fp32x3"], ent["pck"], atol=1e-12)
+            swap += ent["c_s_fp32x3"] - ent["c_s"]
+        else:
+            assert m.calls["alt"] == 0 and "c_s_fp32x3" not in ent
+    assert abs(out["wall_s_fp32x3"] - (out["wall_s"] + swap)) < 0.05
+    # outside the reference mode the alternative set is ignored
+    plain = S.run_sweep(SETTINGS, n_a_images=7, spair=spair_small(), device="cpu", build=ThreeLegModel, pixels=fake_pixels, a_hooks=HOOKS, precision="bf16",
+                        alt_fp32_products=3)
+    assert "wall_s_fp32x3" not in plain
+
+
+def test_predict_scaling_is_arithmetic_on_the_measured_legs():
+    """sweep.predict_scaling: per setting c_tower_s x (a rank's launch-plan cost at world N / at world 1) + c_eval_s x the largest owner's share of
+    the pairs + a_s x the A-launch cost ratio + 25 ms; ViT launches cost images + 24 image-times, diffusion launches their images.  A model printed
+    beside the measured row, never a measurement - the test pins the arithmetic and the fields the bench line carries."""
+    spair = S.synthetic_spair()
+    settings = (S.Setting("V", "v", ("x",), 336, 256), S.Setting("D", "d", ("y",), 768, 16))
+    per = {"V": {"a_s": 0.04, "c_s": 3.5, "c_tower_s": 3.3, "c_eval_s": 0.2}, "D": {"a_s": 0.4, "c_s": 7.7, "c_tower_s": 7.5, "c_eval_s": 0.2}}
+    out = S.predict_scaling(per, settings, 100, spair)
+    assert set(out) >= {"n2", "n4", "n8", "from_wall_s", "model", "not_modelled"} and abs(out["from_wall_s"] - 11.64) < 1e-9
+    assert "RCCL" in out["not_modelled"] and "prediction" in out["model"]
+    n_pairs = sum(len(c.thresholds) for c in spair)
+    for n in (2, 4, 8):
+        owners = S.category_owners(spair, n)
+        load = [0] * n
+        for ci, c in enumerate(spair):
+            load[owners[ci]] += len(c.thresholds)
+        want = 0.0
+        for st in settings:
+            vit = st.batch > 32
+            cost = lambda plan: sum(x + (24 if vit else 0) for x in plan)
+            v = per[st.name]
+            want += v["c_tower_s"] * cost(S.c_launch_plan(spair, st.batch, n)) / cost(S.c_launch_plan(spair, st.batch, 1))
+            want += v["c_eval_s"] * max(load) / n_pairs
+            want += v["a_s"] * cost(S.plan_launches(-(-100 // n), st.batch, equal=False)) / cost(S.plan_launches(100, st.batch, equal=False)) + 0.025
+        assert abs(out[f"n{n}"]["wall_s"] - round(want, 2)) < 1e-9, (n, out[f"n{n}"], want)
+        assert 1.0 < out[f"n{n}"]["speedup"] <= n
+    assert out["n8"]["wall_s"] < out["n4"]["wall_s"] < out["n2"]["wall_s"] < out["from_wall_s"]
