@@ -201,7 +201,7 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page5[4] = {0u, 0u, 0u, 
 // padding fetches the zero page instead.  W, the ring, the ledger and the epilogues are the plain GEMM's.
 // GN_ (round 5, EPI_BIAS): the GroupNorm partial sums of the output (GemmArgs::gn_partial, as the 128x128 kernel's epilogue emits them) from a pass
 // over the accumulators in front of the plain epilogue (gemm_epilogue.h gemm_gn_partials_prepass, which also says why not inside it), in an
-// instantiation of its own.  Residual convolutions would need their residual tile twice and keep the separate statistics pass.
+// instantiation of its own.  Residual convolutions (round 6): the pre-pass reads their residual tile as well (RES), the epilogue reads it again.
 template <int EPI, bool OWN_, bool CONV_ = false, bool GN_ = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256q(const GemmArgs p) {
                 if constexpr (EPI == EPI_VT) gemm_epilogue_vt<8, 4>(p, acc, mb, nb, fr, hi);
                 else if constexpr (EPI == EPI_F32X) gemm_epilogue_f32x<8, 4>(p, acc, mb, nb, fr, hi);
                 else {
-                    if constexpr (GN_) gemm_gn_partials_prepass<8, 4>(p, acc, mb, nb, fr, hi);
+                    if constexpr (GN_) gemm_gn_partials_prepass<8, 4, EPI == EPI_RESID>(p, acc, mb, nb, fr, hi);
                     gemm_epilogue_rowmajor<EPI, 8, 4, true>(p, acc, mb, nb, fr, hi);
                 }
 #pragma unroll
@@ -652,14 +652,14 @@ bool visrep_gemm_v5_supports(const GemmArgs& a) {
 
 // implicit 3x3 convolution in the 256x256 kernel: whole column tiles, 64-channel K-tiles inside one tap, no upsampled source
 bool visrep_gemm_v5_supports_conv(const GemmArgs& a) {
-    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && (a.epi == EPI_BIAS || (a.epi == EPI_RESID && !a.gn_partial)) &&
+    return a.conv && a.N % TN == 0 && a.cC % TK == 0 && a.K == 9 * a.cC && a.cup == 0 && a.kslice == 0 && a.cWo >= 8 && (a.epi == EPI_BIAS || a.epi == EPI_RESID) &&
            (long)a.M / (a.cHo * a.cWo) * a.cH * a.cW * a.cC < (1L << 31) - (3L * a.cW + 3) * a.cC;     // 32-bit element offsets
 }
 
 int visrep_gemm_v5_dispatch(const GemmArgs& a, hipStream_t s) {
     if (a.conv) {
         if (!visrep_gemm_v5_supports_conv(a)) return visrep_set_error(VISREP_ERR_ARG, "gemm v5: unsupported convolution");
-        if (a.gn_partial) return launch5o<EPI_BIAS, false, true, true>(a, s);
+        if (a.gn_partial) return a.epi == EPI_BIAS ? launch5o<EPI_BIAS, false, true, true>(a, s) : launch5o<EPI_RESID, false, true, true>(a, s);
         return a.epi == EPI_BIAS ? launch5o<EPI_BIAS, false, true>(a, s) : launch5o<EPI_RESID, false, true>(a, s);
     }
 #ifndef V5_DEV_ONLY_CONV                                          // (development builds compile the convolution instantiations only)

@@ -125,7 +125,10 @@ VR_DEV void gn_partial_store(const GemmArgs& p, float2* dst, int G, float t1, fl
 // scratch, K loop included - that kernel sits at 252-256 registers and any live range added across its store stream cascades.  Here nothing is
 // live across the epilogue: per column quad two packed (v_pk_*) running pairs, the bias added on the fly, reduced and stored before the next quad.
 // The sums are those of the fp32 (unrounded) outputs, as the 128x128 kernel's; the order of summation differs (tests compare with a tolerance).
-template <int NI, int NJ, typename ACC>
+// RES (round 6, EPI_RESID convolutions): the sums are those of acc + bias + residual, so the pre-pass fetches the residual tile too - eight 8-byte
+// loads per column quad (this lane's four columns of its eight rows), consumed at once - and the epilogue fetches it again (from L2: 128 KB per
+// output tile); what that buys is the separate statistics pass over the output tensor (one more HBM read of it and a launch).
+template <int NI, int NJ, bool RES = false, typename ACC>
 VR_DEV void gemm_gn_partials_prepass(const GemmArgs& p, const ACC (&acc)[NI][NJ], int mb, int nb, int fr, int hg) {
     constexpr int RBLK = AccGeom<ACC>::RBLK;
     static_assert(AccGeom<ACC>::QN == 1 && NI * RBLK == 128, "16x16 accumulators, 128 rows per wave");
@@ -142,9 +145,19 @@ VR_DEV void gemm_gn_partials_prepass(const GemmArgs& p, const ACC (&acc)[NI][NJ]
     for (int c = 0; c < NJ; ++c) {
         const f32x2 b01 = {bq[c].x, bq[c].y}, b23 = {bq[c].z, bq[c].w};
         f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        u32x2 rq[RES ? NI : 1];
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                rq[RES ? i : 0] = *reinterpret_cast<const u32x2*>(p.resid + (size_t)(mb + i * RBLK + fr) * p.ldc + nb + c * RBLK + hg * 4);
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const f32x2 v01 = f32x2{acc[i][c][0], acc[i][c][1]} + b01, v23 = f32x2{acc[i][c][2], acc[i][c][3]} + b23;
+            f32x2 v01 = f32x2{acc[i][c][0], acc[i][c][1]} + b01, v23 = f32x2{acc[i][c][2], acc[i][c][3]} + b23;
+            if (RES) {
+                const u32x2 r = rq[RES ? i : 0];
+                v01 += f32x2{bf_lo(r[0]), bf_hi(r[0])}; v23 += f32x2{bf_lo(r[1]), bf_hi(r[1])};
+            }
             s01 += v01; s23 += v23;
             q01 = __builtin_elementwise_fma(v01, v01, q01); q23 = __builtin_elementwise_fma(v23, v23, q23);
         }

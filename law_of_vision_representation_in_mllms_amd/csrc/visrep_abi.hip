@@ -4,6 +4,7 @@
 
 #include <mutex>
 
+#include <cstdlib>
 #include "common.h"
 #include "visrep_internal.h"
 
@@ -217,15 +218,21 @@ extern "C" int visrep_conv3x3_bf16(const void* x, int B, int H, int W, int C, co
 
 // Rows and groups must fit the epilogue's slots (64-row slots inside one image, a group inside a lane quad pair / quartet), and asking for the
 // sums must not cost the convolution its kernel: the 128x128 kernel emits them from its epilogue for both epilogues, the 256x256 kernel (whole
-// rounds of its tiles, Cout % 256 == 0) for EPI_BIAS only (round 5: a pass over the accumulators in front of the epilogue; a residual
-// convolution there keeps the separate statistics pass).  visrep_conv_gn_supported is the round-4 query (no epilogue argument: the
+// rounds of its tiles, Cout % 256 == 0) for EPI_BIAS (round 5: a pass over the accumulators in front of the epilogue); a residual
+// convolution there keeps the separate statistics pass unless VISREP_GN_RESID_256=1 (round 6: built, measured slower, opt-in).  visrep_conv_gn_supported is the round-4 query (no epilogue argument: the
 // conservative answer that holds for both).
 extern "C" int visrep_conv_gn_supported_epi(int B, int HWo, int Cout, int groups, int epilogue) {
     if (B <= 0 || HWo <= 0 || Cout <= 0 || groups <= 0 || Cout % groups) return 0;
     if (epilogue != VISREP_EPI_BIAS && epilogue != VISREP_EPI_RESID) return 0;
     const int cpg = Cout / groups;
     if (!(HWo % 128 == 0 && Cout % 64 == 0 && (cpg == 4 || cpg == 8 || cpg == 16))) return 0;
-    if (epilogue != VISREP_EPI_BIAS && Cout % 256 == 0 && ((long)B * HWo + 255) / 256 * (Cout / 256) >= 2L * visrep_cu_count()) return 0;
+    // residual convolutions that the 256x256 kernel takes: round 6 built their partial sums too (gemm_gn_partials_prepass<.., RES>: the pre-pass reads
+    // the residual tile as well) and measured the SD1.5 forward 0.4-0.6 ms SLOWER with them than with the separate statistics pass (70.8 / 71.0 ->
+    // 71.2 / 71.6 ms, tools/diag/ab_gn_resid256.sh: the second fetch of the residual tile + 7 spilled registers cost what the pass saved) - opt-in:
+    // VISREP_GN_RESID_256=1 (read per call, so that tests can switch it)
+    const char* e_ = getenv("VISREP_GN_RESID_256");
+    const bool resid256 = e_ && e_[0] == '1';
+    if (!resid256 && epilogue != VISREP_EPI_BIAS && Cout % 256 == 0 && ((long)B * HWo + 255) / 256 * (Cout / 256) >= 2L * visrep_cu_count()) return 0;
     return 1;
 }
 extern "C" int visrep_conv_gn_supported(int B, int HWo, int Cout, int groups) {
