@@ -1,6 +1,7 @@
-// bf16 MFMA GEMM "duo" for gfx950 (round 6, gemm variant 6 - an A/B variant, not the default): TWO INDEPENDENT 4-wave workgroups per CU.
+// bf16 MFMA GEMM "duo" for gfx950 (round 6; gemm variants 6 / 7 / 8 - A/B variants, NOT the default: measured 20-30 % slower than v5 at every
+// headline shape, profiles/round6_gemm.md section 2): TWO INDEPENDENT 4-wave workgroups per CU.
 //
-//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )          same contract / epilogues as gemm_bf16.hip (v1), v2 and v5
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )          same contract / epilogues as gemm_bf16.hip (v1), v2 and v5; results BIT-IDENTICAL to v5's
 //
 // Why it exists.  The persistent 256x256 ping-pong kernel (v5) runs ONE 8-wave workgroup per CU: its two wave groups share
 // the W ring and every s_barrier, so both finish an output tile together and neither epilogue overlaps any MFMA work - a tile boundary costs
@@ -8,22 +9,21 @@
 // capacity without measuring it; this is that alternative, built to be measured: 256 x 128 output tiles, 4 waves (2 x 2, each 128 x 64 =
 // the v5 wave tile: 8 x 4 accumulators of 16x16x32 MFMAs), a private LDS ring per workgroup and barriers of its own, two workgroups resident
 // per CU (launch bounds 256 x 2, 72 KB of LDS each) - one workgroup's epilogue (and its pipeline fill, and its barrier waits) runs under the
-// other's MFMAs because nothing couples them.
+// other's MFMAs because nothing couples them.  One output tile per workgroup (grid = tiles, XCD-contiguous order), no persistence.
 //
 // What the 80 KB per workgroup force.  A K-tile of 64 (v5's 128-byte LDS rows) is 48 KB for a 256 x 128 tile: not even two stages fit.  So the
-// K-tile is 32 (64-byte LDS rows, v2's format): 16 KB of X + 8 KB of W = 24 KB per stage, a ring of THREE stages (72 KB) - stage s is consumed
-// while s + 1 and s + 2 stream in.  The price is v2's: every LDS-DMA instruction moves sixteen 64-byte HALF lines (the L2 serves requests, not
-// bytes), and a 256 x 128 tile stages 1.5x the operand bytes per FLOP of a 256 x 256 tile.  Measured in profiles/round6_gemm.md.
+// K-tile is 32 (64-byte LDS rows, v2's format): 16 KB of X + 8 KB of W = 24 KB per stage, a ring of THREE stages (72 KB).  The price is v2's:
+// every LDS-DMA instruction moves sixteen 64-byte HALF lines (the L2 serves requests, not bytes), and a 256 x 128 tile stages 1.5x the operand
+// bytes per FLOP of a 256 x 256 tile - which is what the measurement says decides it on a power-capped board.
 //
 // LDS layout: row r of an operand tile = 64 B = four 16-byte slots; slot s of row r sits at r * 64 + ((s ^ ((r >> 2) & 3)) << 4): a ds_read_b128
 // of {16 consecutive rows, one logical slot} - lane l: row l & 15, slot l >> 4 - touches sixteen distinct 16-byte chunks of every 256-byte bank
 // row (rows r .. r + 3 share a bank row and differ in (r & 3); rows r, r + 4, r + 8, r + 12 differ in the XOR term).  global_load_lds writes
 // lane-linear (lane l -> byte 16 l of the 1-KB piece = row l >> 2, physical slot l & 3), so the lane fetches LOGICAL slot (l & 3) ^ ((row >> 2) & 3).
 //
-// Per K-tile and wave: counted wait for its own six pieces of stage s | s_barrier (stage s visible to all, stage s - 1 read by all) | issue the
-// six pieces of stage s + 2 into the slot of s - 1 | twelve ds_read_b128 (8 X + 4 W fragments, hand-written: see gemm_bf16_v5.hip on why) |
-// 32 MFMAs.  One barrier per 512 matrix-pipe cycles - v5's cadence.  The fragment reads of a wave are NOT overlapped with its own MFMAs (one
-// fragment set: 128 accumulators + 48 fragment registers); the co-resident workgroup's wave on the same SIMD is what fills the pipe meanwhile.
+// Two schedules (template flag PIPE_, described at the kernel): the pipelined one (variants 6 / 7) overlaps a wave's fragment reads with its own
+// MFMAs; the first build (variant 8) reads 12 fragments, waits, issues 32 MFMAs and leaves the gaps to the co-resident workgroup.  Both: one
+// barrier per K-tile = per 512 matrix-pipe cycles (v5's cadence), counted vmcnt waits, hand-written ds_read_b128 (see gemm_bf16_v5.hip on why).
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "visrep_internal.h"
