@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .utils_dataset import preprocess_kps_pad
-from .utils_geoware import AP10K_GEO_AWARE, SPAIR_GEO_AWARE, geo_aware_points
+from .utils_geoware import AP10K_GEO_AWARE, SPAIR_FLIP, SPAIR_GEO_AWARE, geo_aware_points
 
 ALPHA = (0.1, 0.05, 0.01)
 
@@ -65,6 +65,10 @@ def _convert(result, dataset):
             groups, n_slots = SPAIR_GEO_AWARE[category], 30
             row.update(az=min(abs(az1 - az2), 8 - abs(az1 - az2)), mirror=mirror)
         vis = src_kps[:, 2] * trg_kps[:, 2] > 0
+        if dataset != "ap10k":
+            # eval_spair.py:164-175: mutually visible members of the left/right groups of which the SOURCE image shows at least two
+            # (the AP-10k converter has no flip groups: flip=True raises KeyError there, as in the reference)
+            row.update(flip_idx=geo_aware_points(SPAIR_FLIP[category], vis, src_kps[:, 2] > 0))
         row.update(src_kps=src_kps[:, [1, 0]], gt_kps=trg_kps[:, [1, 0]], pred_kps=pred, thresholds=torch.tensor(thr).float(),
                    used_points=[i for i in range(n_slots) if vis[i]], geo_aware_idx=geo_aware_points(groups, vis, trg_kps[:, 2] > 0))
         rows.append(row)
@@ -90,22 +94,19 @@ def _hits(item, idx):
 
 
 def get_std_result(all_results, cls=None, geo=False, flip=False, az=None):
-    """Key-point-level PCK over the selected pairs -> (correct[3], n_keypoints)."""
-    if flip:
-        raise NotImplementedError("flip groups belong to ADAPT_FLIP, which is not built")
-    hits = [_hits(r, r["geo_aware_idx"] if geo else r["used_points"]) for r in _selected(all_results, cls, az)]
+    """Key-point-level PCK over the selected pairs -> (correct[3], n_keypoints); geo / flip restrict it to the geometry-aware / the
+    left-right group key points (eval_spair.py:333-336: geo wins when both are set)."""
+    hits = [_hits(r, r["geo_aware_idx"] if geo else r["flip_idx"] if flip else r["used_points"]) for r in _selected(all_results, cls, az)]
     hits = torch.cat(hits, dim=1)
     return hits.sum(dim=-1).float() / hits.shape[1], hits.shape[1]
 
 
 def get_img_result(all_results, cls=None, geo=False, flip=False, az=None):
     """Mean over pairs of the per-pair PCK -> (correct[3], n_pairs counted); geo skips pairs without geometry-aware points."""
-    if flip:
-        raise NotImplementedError("flip groups belong to ADAPT_FLIP, which is not built")
     per_img = []
     for r in _selected(all_results, cls, az):
-        idx = r["geo_aware_idx"] if geo else r["used_points"]
-        if geo and len(idx) == 0:
+        idx = r["geo_aware_idx"] if geo else r["flip_idx"] if flip else r["used_points"]
+        if (geo or flip) and len(idx) == 0:
             continue
         h = _hits(r, idx)
         per_img.append(h.sum(dim=-1).float() / len(idx))

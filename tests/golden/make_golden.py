@@ -1270,9 +1270,46 @@ def gen_maskdist():
     print("maskdist.npz:", {k: float(v) for k, v in out.items() if k.endswith(".dist")})
 
 
+def gen_evalflip():
+    """utils/eval_spair.py with flip=True (C_score/utils/eval_spair.py:164-175,323-385: PCK over the key points of the left/right groups that
+    are visible on the source side) - the REAL module on the result list the reference's own eval() produced for the mini tree (its predictions
+    are in spair_host.npz, its file lists in the committed annotations): per-pair flip_idx, key-point-level and image-level PCK."""
+    import json
+    import importlib.util
+    import shutil
+    sys.path.insert(0, f"{REF}/C_score")
+    _stub_modules()
+    sys.modules.pop("utils.eval_spair", None)
+    spec = importlib.util.spec_from_file_location("utils.eval_spair", f"{REF}/C_score/utils/eval_spair.py")
+    ES = importlib.util.module_from_spec(spec)
+    sys.modules["utils.eval_spair"] = ES
+    spec.loader.exec_module(ES)
+    z = np.load(f"{HERE}/spair_host.npz")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = f"{tmp}/data/SPair-71k"
+        os.makedirs(f"{tmp}/data")
+        shutil.copytree(f"{HERE}/mini_spair", root)
+        results, k = [], 0
+        for cat in sorted(c for c in ("aeroplane", "cat")):
+            files = [os.path.join(root, f) for f in z[f"{cat}.files"].tolist()]
+            for n in range(len(files) // 2):
+                results.append({"src_fn": files[2 * n], "trg_fn": files[2 * n + 1], "src_kpts_pred": z["eval.pred"][k], "resize_resolution": 840})
+                k += 1
+        assert k == z["eval.pred"].shape[0]
+        conv = ES.convert_all_results(results)
+    out["flip_idx"] = np.array(json.dumps([[int(i) for i in r["flip_idx"]] for r in conv]))
+    out["std"] = np.concatenate([ES.get_std_result(conv, flip=True)[0].numpy(), ES.get_std_result(conv, cls="cat", flip=True)[0].numpy()])
+    out["img"] = np.concatenate([ES.get_img_result(conv, flip=True)[0].numpy(), ES.get_img_result(conv, cls="aeroplane", flip=True)[0].numpy()])
+    out["n"] = np.array([ES.get_std_result(conv, flip=True)[1], ES.get_std_result(conv, cls="cat", flip=True)[1], ES.get_img_result(conv, flip=True)[1],
+                         ES.get_img_result(conv, cls="aeroplane", flip=True)[1]])
+    np.savez_compressed(f"{HERE}/evalflip.npz", **out)
+    print("evalflip.npz:", out["std"], out["img"], out["n"], str(out["flip_idx"])[:120])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet", "maskdist"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet", "maskdist", "evalflip"]
     with torch.no_grad():
         for w in which:
             {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize,
-             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet, "maskdist": gen_maskdist}[w]()
+             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet, "maskdist": gen_maskdist, "evalflip": gen_evalflip}[w]()

@@ -234,6 +234,17 @@ def test_result_postprocessing_matches_reference(tmp_path, cpu_ops):
     np.testing.assert_allclose(std, z["post.std"], atol=1e-7)
     assert n == z["post.n"].tolist()
     assert ES.get_img_result(conv, cls="nope")[1] == 0
+    # flip=True (eval_spair.py:164-175,333-336,364-367): the left/right-group key points, against the reference module on the same results
+    import json
+    zf = np.load(f"{G}/evalflip.npz")
+    assert [r["flip_idx"] for r in conv] == json.loads(str(zf["flip_idx"]))
+    stdf = np.concatenate([ES.get_std_result(conv, flip=True)[0].numpy(), ES.get_std_result(conv, cls="cat", flip=True)[0].numpy()])
+    imgf = np.concatenate([ES.get_img_result(conv, flip=True)[0].numpy(), ES.get_img_result(conv, cls="aeroplane", flip=True)[0].numpy()])
+    nf = [ES.get_std_result(conv, flip=True)[1], ES.get_std_result(conv, cls="cat", flip=True)[1], ES.get_img_result(conv, flip=True)[1],
+          ES.get_img_result(conv, cls="aeroplane", flip=True)[1]]
+    np.testing.assert_allclose(stdf, zf["std"], atol=1e-7)
+    np.testing.assert_allclose(imgf, zf["img"], atol=1e-7)
+    assert nf == zf["n"].tolist()
 
 
 # ------------------------------------------------------------------------------------------------ ADAPT_FLIP (§8f N4)
