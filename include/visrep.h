@@ -371,7 +371,10 @@ int visrep_ascore_maxcos_refarith(const void* other, const void* ref, int n_img,
  * split = 0: one encoder (pck_train.py); split = C1 > 0: channels [0,C1) and [C1,C) are two encoders normalised separately,
  * concatenated and normalised again (C_score/pck_train_two.py:24-36 normalize_feats).
  * layout = 0: maps are [C, P*P] (the reference's on-disk [1, C, P, P]); layout = 1: [P*P, C], the towers' own token layout - a
- * keypoint's descriptor is then one contiguous row (C and split multiples of 4). */
+ * keypoint's descriptor is then one contiguous row (C and split multiples of 4).
+ * window: > 0 the (2w+1)^2 window around the argmax (get_flow :301-320: entries outside are ZERO and stay in the softmax); 0 the plain
+ * soft-argmax; < 0 (round 6) the Gaussian-kernel soft-argmax (:321-324 -> apply_gaussian_kernel :278-295, sigma = -window patches; the
+ * reference hard-wires a 60 x 60 grid there, these kernels take their own P). */
 int visrep_cscore_transfer(const float* feats, const int* img1, const int* img2, const int* patch_idx, const int* nkp,
                            const float* lin, float* xy, int n_pairs, int kmax, int P, int C, int split, int window, int soft_eval,
                            float beta, float anno_stride, float anno_half, int layout, void* stream);

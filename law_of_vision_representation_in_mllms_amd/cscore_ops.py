@@ -102,10 +102,8 @@ def transfer(bank: torch.Tensor, img1: torch.Tensor, img2: torch.Tensor, patch_i
     sort_pairs only concerns the one-tile-per-pair route (the packed route always groups by target image): asking for
     sort_pairs=False together with packing is refused instead of silently ignored.
     """
-    if soft_eval and window < 0:
-        # utils_correspondence.py:326-329: a negative window selects apply_gaussian_kernel (sigma = -window), which is hard-wired
-        # to 60 x 60 maps (np.linspace(0, 59, 60), l.285-288) and cannot run on any other grid in the reference either
-        raise NotImplementedError("SOFT_EVAL_WINDOW < 0 (Gaussian-kernel soft-argmax, 60x60 maps only in the reference) is not built")
+    # window < 0 (round 6): utils_correspondence.py:321-324 selects apply_gaussian_kernel (sigma = -window), hard-wired to 60 x 60 maps in the
+    # reference (np.linspace(0, 59, 60), l.285-288); the kernels weight with the same Gaussian over integer patch coordinates on any grid
     lib = _lib.require_gpu()
     if layout not in ("cp", "pc"):
         raise ValueError("layout must be 'cp' ([n, C, P*P]) or 'pc' ([n, P*P, C])")
@@ -251,8 +249,6 @@ def transfer_cpu(bank: torch.Tensor, img1, img2, patch_idx, nkp, P: int, window:
                  anno_size: int = 840, split: int = 0, layout: str = "cp", threads: int = 0) -> torch.Tensor:
     """transfer() on HOST cores (visrep_cscore_transfer_cpu, csrc/host_twins.hip: plain C++ fp32) - the `*_cpu` twin of SURVEY §8b.  CPU
     tensors in, xy fp32 [n, kmax, 2] out; same arguments and semantics as transfer(); never used as a fallback."""
-    if soft_eval and window < 0:
-        raise NotImplementedError("SOFT_EVAL_WINDOW < 0 (Gaussian-kernel soft-argmax, 60x60 maps only in the reference) is not built")
     lib = _lib.load()
     if layout not in ("cp", "pc"):
         raise ValueError("layout must be 'cp' ([n, C, P*P]) or 'pc' ([n, P*P, C])")

@@ -61,12 +61,17 @@ VR_DEV void soft_argmax_row(const CArgs& p, const float* row, int PP, int lane, 
             y0 = max(my - w, 0); y1 = min(my + w, p.P - 1);
         }
         const bool has_out = (x1 - x0 + 1) * (y1 - y0 + 1) < PP;
-        const float Mx = has_out ? fmaxf(bv, 0.f) : bv;
+        // w < 0: the "kernel soft-argmax" (apply_gaussian_kernel, utils_correspondence.py:278-295): a Gaussian of sigma = -w patches around the argmax
+        // target weights every similarity.  The weight is 1 at the argmax and < 1 elsewhere, so the weighted maximum is bv when bv >= 0 and lies in
+        // (bv, 0) otherwise: max(bv, 0) bounds it from above - the same stabiliser as with zeros outside a window.
+        const float Mx = (has_out || w < 0) ? fmaxf(bv, 0.f) : bv;
+        const float two_s2 = 2.f * (float)(w * w);
         float z = 0.f, ex = 0.f, ey = 0.f;
         for (int t = lane; t < PP; t += 64) {
             const int ty = t / p.P, tx = t - ty * p.P;
             const bool in = tx >= x0 && tx <= x1 && ty >= y0 && ty <= y1;
-            const float v = in ? row[t] : 0.f;
+            float v = in ? row[t] : 0.f;
+            if (w < 0) { const float dx = (float)(tx - mx), dy = (float)(ty - my); v *= expf(-(dx * dx + dy * dy) / two_s2); }
             const float e = expf((v - Mx) / p.beta);
             z += e; ex += e * p.lin[tx]; ey += e * p.lin[ty];
         }

@@ -246,7 +246,6 @@ extern "C" int visrep_cscore_transfer_cpu(const float* feats, const int* img1, c
     if (n_pairs <= 0) return 0;
     if (!feats || !img1 || !img2 || !patch_idx || !nkp || !lin || !xy) return visrep_set_error(VISREP_ERR_ARG, "cscore_transfer_cpu: null pointer");
     if (P <= 0 || C <= 0 || kmax <= 0 || split < 0 || split >= C) return visrep_set_error(VISREP_ERR_SHAPE, "cscore_transfer_cpu: bad shape");
-    if (soft_eval && window < 0) return visrep_set_error(VISREP_ERR_ARG, "cscore_transfer_cpu: SOFT_EVAL_WINDOW < 0 (Gaussian soft-argmax) is not built");
     const int PP = P * P;
     const size_t map = (size_t)PP * C;
     // descriptor of patch p of image im as a normalised C-vector (pck_train.py:24-29; two encoders: pck_train_two.py:24-36)
@@ -291,6 +290,14 @@ extern "C" int visrep_cscore_transfer_cpu(const float* feats, const int* img1, c
                     for (int q = 0; q < PP; ++q) {
                         const int qx = q % P, qy = q / P;
                         if (qx < x0 || qx > x1 || qy < y0 || qy > y1) sim[q] = 0.f;
+                    }
+                } else if (window < 0) {
+                    // "kernel soft-argmax" (apply_gaussian_kernel, utils_correspondence.py:278-295): a Gaussian of sigma = -window patches around the
+                    // argmax target weights every similarity before the softmax (the reference hard-wires a 60 x 60 grid; any P here)
+                    const float mx = (float)(am % P), my = (float)(am / P), two_s2 = 2.f * (float)(window * window);
+                    for (int q = 0; q < PP; ++q) {
+                        const float dx = (float)(q % P) - mx, dy = (float)(q / P) - my;
+                        sim[q] *= expf(-(dx * dx + dy * dy) / two_s2);
                     }
                 }
                 float mxv = sim[0];

@@ -18,6 +18,8 @@ Only the K keypoint rows of the [P^2, P^2] similarity are evaluated (the
 reference computes all rows then gathers, utils_correspondence.py:360,367-368);
 row results are independent so this is the same arithmetic.
 
+SOFT_EVAL_WINDOW < 0 is the Gaussian-kernel soft-argmax (apply_gaussian_kernel, utils_correspondence.py:278-295; round 6).
+
 Window soft-argmax semantics that must be preserved: entries
 outside the (2w+1)^2 window (clamped at the borders) are ZERO, not -inf, and
 still take part in the softmax over all P^2 targets.
@@ -69,6 +71,16 @@ def window_soft_argmax_rows(sim_rows: torch.Tensor, P: int, window: int, beta: f
         iny = (xs[None, :] >= (my[:, None] - window).clamp(0, P - 1)) & (xs[None, :] <= (my[:, None] + window).clamp(0, P - 1))
         mask = (iny[:, :, None] & inx[:, None, :]).reshape(K, P * P).to(corr.dtype)
         corr = corr * mask
+    elif window < 0:
+        # "kernel soft-argmax" (get_flow :321-324 -> apply_gaussian_kernel :278-295): every similarity is weighted by a Gaussian (sigma = -window
+        # patches) around the row's argmax target before the softmax.  The reference builds the kernel's coordinates with linspace(0, 59, 60),
+        # i.e. it only runs on 60 x 60 maps; integer patch coordinates 0 .. P - 1 are the same thing at P = 60 and the generalisation elsewhere.
+        am = torch.argmax(corr, dim=-1)
+        mx, my = (am % P).float(), (am // P).float()
+        xs = torch.arange(P).float()
+        sigma = float(-window)
+        g = torch.exp(-((xs[None, None, :] - mx[:, None, None]) ** 2 + (xs[None, :, None] - my[:, None, None]) ** 2) / (2 * sigma ** 2))    # [K, ty, tx]
+        corr = corr * g.reshape(K, P * P)
     M = corr.max(dim=1, keepdim=True).values
     e = torch.exp((corr - M) / beta)
     p = (e / e.sum(dim=1, keepdim=True)).view(K, P, P)            # [K, ty, tx]

@@ -1270,6 +1270,41 @@ def gen_maskdist():
     print("maskdist.npz:", {k: float(v) for k, v in out.items() if k.endswith(".dist")})
 
 
+def gen_gaussflow():
+    """SOFT_EVAL_WINDOW < 0: the Gaussian-kernel soft-argmax (utils_correspondence.py:321-324 get_flow -> :278-295 apply_gaussian_kernel), through
+    calculate_keypoint_transformation as it stands, on 60 x 60 maps - the only grid its hard-wired linspace(0, 59, 60) accepts.  Spatially smooth
+    descriptor maps (several targets carry weight under the kernel), sigma = 5 and 2."""
+    sys.path.insert(0, f"{REF}/C_score")
+    _stub_modules()
+    import utils.utils_correspondence as UC
+    rs = np.random.RandomState(97)
+    out = {}
+    P, C, K = 60, 12, 14
+    yy, xx = np.meshgrid(np.linspace(0, 4, P), np.linspace(0, 4, P), indexing="ij")
+    f1, f2 = np.zeros((C, P, P), np.float32), np.zeros((C, P, P), np.float32)
+    for c in range(C):
+        ph = rs.uniform(0, 6.28, 2)
+        f1[c] = np.sin(yy * (c % 5 + 1) + ph[0]) + np.cos(xx * (c % 3 + 1) + ph[1]) + 0.3 * rs.standard_normal((P, P))
+        f2[c] = np.sin(yy * (c % 5 + 1) + ph[0] + 0.25) + np.cos(xx * (c % 3 + 1) + ph[1] - 0.2) + 0.3 * rs.standard_normal((P, P))
+    f1, f2 = f1.astype(np.float16).astype(np.float32), f2.astype(np.float16).astype(np.float32)      # stored as fp16: the run consumes exactly what is stored
+    kps = np.zeros((K, 3), np.float32)
+    kps[:, :2] = rs.uniform(0, 839.9, (K, 2)).astype(np.float32)
+    kps[:, 2] = 1
+    kps[:2, :2] = [[0, 0], [839, 839]]                                # corner sources: the kernel's centre may sit on the border
+    d1 = torch.from_numpy(f1).reshape(1, 1, C, P * P).permute(0, 1, 3, 2)[0]
+    d2 = torch.from_numpy(f2).reshape(1, 1, C, P * P).permute(0, 1, 3, 2)[0]
+    d1 = d1 / (torch.linalg.norm(d1, dim=-1)[:, :, None] + 1e-10)
+    d2 = d2 / (torch.linalg.norm(d2, dim=-1)[:, :, None] + 1e-10)
+    out["f1"], out["f2"], out["kps"] = f1.astype(np.float16), f2.astype(np.float16), kps
+    for win in (-5, -2):
+        A = argparse.Namespace(ANNO_SIZE=840, SOFT_EVAL=True, SOFT_EVAL_WINDOW=win)
+        idx = UC.kpts_to_patch_idx(A, torch.from_numpy(kps), P)
+        out["patch_idx"] = np.asarray(idx, np.int32)
+        out[f"xy.w{-win}"] = UC.calculate_keypoint_transformation(A, d1, d2, idx, P).numpy()
+    np.savez_compressed(f"{HERE}/gaussflow.npz", **out)
+    print("gaussflow.npz:", out["xy.w5"][:3], out["xy.w2"][:3])
+
+
 def gen_evalflip():
     """utils/eval_spair.py with flip=True (C_score/utils/eval_spair.py:164-175,323-385: PCK over the key points of the left/right groups that
     are visible on the source side) - the REAL module on the result list the reference's own eval() produced for the mini tree (its predictions
@@ -1308,8 +1343,8 @@ def gen_evalflip():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet", "maskdist", "evalflip"]
+    which = sys.argv[1:] or ["ascore", "cscore", "vit", "vit_hip", "spair", "projector", "sd", "text", "dit", "imsd", "sd3", "policy", "nextsets", "georesize", "adaptflip", "aggnet", "maskdist", "evalflip", "gaussflow"]
     with torch.no_grad():
         for w in which:
             {"ascore": gen_ascore, "cscore": gen_cscore, "vit": gen_vit, "vit_hip": gen_vit_hip, "spair": gen_spair, "projector": gen_projector, "sd": gen_sd, "text": gen_text, "dit": gen_dit, "imsd": gen_imsd, "sd3": gen_sd3, "policy": gen_policy, "nextsets": gen_nextsets, "georesize": gen_georesize,
-             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet, "maskdist": gen_maskdist, "evalflip": gen_evalflip}[w]()
+             "adaptflip": gen_adaptflip, "aggnet": gen_aggnet, "maskdist": gen_maskdist, "evalflip": gen_evalflip, "gaussflow": gen_gaussflow}[w]()

@@ -227,6 +227,44 @@ def test_cscore_vs_oracle_full_width(P, C):
         assert (xy_pc[i, : nkp[i]] - want).abs().max().item() < 2e-2, i
 
 
+@pytest.mark.parametrize("window", [-5, -2])
+@pytest.mark.parametrize("P,C", [(16, 64), (24, 1024), (32, 320)])
+def test_cscore_gaussian_kernel_soft_argmax_vs_oracle(P, C, window):
+    """SOFT_EVAL_WINDOW < 0: the Gaussian-kernel soft-argmax (utils_correspondence.py:321-324 -> apply_gaussian_kernel :278-295; the oracle's branch is
+    pinned to the reference at its 60 x 60 grid, tests/golden/gaussflow.npz) on the device kernels' grids: spatially smooth maps (several targets
+    carry weight under the kernel), one-tile-per-pair and packed routes, both layouts, against the oracle."""
+    rs = np.random.RandomState(P * 10 - window)
+    n_img, n_pairs, K = 5, 9, 16
+    yy, xx = np.meshgrid(np.linspace(0, 4, P), np.linspace(0, 4, P), indexing="ij")
+    bank = np.zeros((n_img, C, P * P), np.float32)
+    for c in range(C):
+        ph = rs.uniform(0, 6.28, 2)
+        for i in range(n_img):
+            bank[i, c] = (np.sin(yy * (c % 5 + 1) + ph[0] + 0.2 * i) + np.cos(xx * (c % 3 + 1) + ph[1] - 0.15 * i) + 0.3 * rs.standard_normal((P, P))).reshape(-1)
+    bank_t = torch.from_numpy(bank)
+    i1, i2 = rs.randint(0, n_img, n_pairs).astype(np.int32), rs.randint(0, n_img, n_pairs).astype(np.int32)
+    kps = np.ones((n_pairs, K, 3), np.float32)
+    kps[:, :, :2] = rs.uniform(0, 839.9, (n_pairs, K, 2))
+    kps[0, :2, :2] = [[0, 0], [839, 839]]                                    # the kernel's centre on the border
+    nkp = rs.randint(3, K + 1, n_pairs).astype(np.int32)
+    idx = np.stack([OC.kpts_to_patch_idx(torch.from_numpy(kps[i]), P) for i in range(n_pairs)]).astype(np.int32)
+    a = (torch.from_numpy(i1), torch.from_numpy(i2), torch.from_numpy(idx), torch.from_numpy(nkp), P)
+    xy = cscore_ops.transfer(bank_t.to(DEV), *a, window=window).cpu()
+    pc = bank_t.transpose(1, 2).contiguous().to(DEV)
+    xy_pc = cscore_ops.transfer(pc, *a, window=window, layout="pc").cpu()                       # packed key-point tiles (default for "pc")
+    xy_one = cscore_ops.transfer(pc, *a, window=window, layout="pc", packed=False).cpu()
+    plain = cscore_ops.transfer(pc, *a, window=5, layout="pc").cpu()
+    moved = 0.0
+    for i in range(n_pairs):
+        d1 = OC.descriptors_from_map(bank_t[i1[i]].view(1, C, P, P), P)
+        d2 = OC.descriptors_from_map(bank_t[i2[i]].view(1, C, P, P), P)
+        want = OC.keypoint_transfer(d1, d2, idx[i][: nkp[i]], P, window=window)
+        for got in (xy, xy_pc, xy_one):
+            assert (got[i, : nkp[i]] - want).abs().max().item() < 2e-2, (i, P, C, window)
+        moved = max(moved, (plain[i, : nkp[i]] - want).abs().max().item())
+    assert moved > 1.0                                                        # the mode is not the window mode in disguise
+
+
 @pytest.mark.parametrize("P,C1,C2", [(16, 1024, 1024), (24, 1024, 1280), (16, 32, 24), (24, 1024, 2)])
 def test_cscore_two_encoder_split_vs_oracle(P, C1, C2):
     """pck_train_two.py normalisation (per-encoder L2, concat, L2 again) fused into the Gram kernel via `split`."""

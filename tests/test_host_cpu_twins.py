@@ -114,6 +114,32 @@ def test_cscore_transfer_cpu_matches_the_reference():
             np.testing.assert_allclose(xy, z[f"{name}.xy"], rtol=0, atol=5e-3, err_msg=f"{name} {layout}")
 
 
+def test_gaussian_kernel_soft_argmax_oracle_and_host_twin_match_the_reference():
+    """SOFT_EVAL_WINDOW < 0 (utils_correspondence.py:321-324 -> apply_gaussian_kernel :278-295) on the reference's own 60 x 60 grid
+    (tests/golden/gaussflow.npz: calculate_keypoint_transformation as it stands, sigma = 5 and 2): the oracle's branch and visrep_cscore_transfer_cpu,
+    1e-3 px in the 840-px frame; then the host twin against the oracle on a 16 x 16 grid, which the reference cannot take."""
+    from oracle import cscore as OC
+    z = np.load(f"{G}/gaussflow.npz")
+    P = 60
+    f1, f2 = torch.from_numpy(z["f1"].astype(np.float32)), torch.from_numpy(z["f2"].astype(np.float32))
+    d1, d2 = OC.descriptors_from_map(f1[None], P), OC.descriptors_from_map(f2[None], P)
+    bank = torch.stack([f1.reshape(-1, P * P), f2.reshape(-1, P * P)])
+    idx = torch.from_numpy(z["patch_idx"])[None]
+    for w in (5, 2):
+        want = torch.from_numpy(z[f"xy.w{w}"])
+        assert (OC.keypoint_transfer(d1, d2, z["patch_idx"], P, window=-w) - want).abs().max().item() < 1e-3
+        xy = cscore_ops.transfer_cpu(bank, [0], [1], idx, [idx.shape[1]], P, window=-w)[0]
+        assert (xy - want).abs().max().item() < 1e-3, w
+    assert (torch.from_numpy(z["xy.w5"]) - torch.from_numpy(z["xy.w2"])).abs().max().item() > 1.0       # sigma matters on these maps
+    g = torch.Generator().manual_seed(2)
+    P, C_ = 16, 24
+    bank = torch.randn(2, P * P, C_, generator=g) + torch.randn(1, P * P, C_, generator=g)
+    idx = torch.randint(0, P * P, (1, 9), generator=g).int()
+    want = OC.keypoint_transfer(OC.normalize_feats(bank[0][None]), OC.normalize_feats(bank[1][None]), idx[0].numpy(), P, window=-3)
+    got = cscore_ops.transfer_cpu(bank, [0], [1], idx, [9], P, window=-3, layout="pc")[0]
+    assert (got - want).abs().max().item() < 5e-3
+
+
 def test_cscore_two_encoder_split_and_pck_counts_cpu():
     """split > 0 (pck_train_two.py:24-36: per-encoder L2, concat, L2 again) against the oracle's normalize_feats_two chain; hit counts of
     visrep_pck_count_cpu against a direct numpy restatement of pck_train.py:149-163."""
