@@ -598,7 +598,10 @@ def main():
     sweep = None
     if args.sweep != "off":
         import threading
-        limit = float(os.environ.get("VISREP_SWEEP_LIMIT_S", "600" if args.sweep == "reduced" else "3600"))
+        # The headline line is printed AFTER the sweep (one JSON line per run), so a sweep that hangs must not take it down with it: the watchdog
+        # bounds it.  One GPU: the full sweep takes ~80 s with its setup (900 s allowed).  world > 1 has never run on hardware (RCCL all_to_all under
+        # persistent kernels): 420 s allowed - at N = 2 the sweep is ~30 s + ~25 s of setup - then rank 0 prints the line it has and every rank leaves.
+        limit = float(os.environ.get("VISREP_SWEEP_LIMIT_S", "600" if args.sweep == "reduced" else ("900" if world == 1 else "420")))
 
         def bail():
             emit({"error": f"sweep did not finish within {limit:.0f} s", "size": args.sweep})
