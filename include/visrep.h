@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VISREP_VERSION 600   /* round 6: reserved CUs, GEMM tile-window knob (new exports only).  500 = round 5: device CU count, routing counters, MFMA probe, A-score reference arithmetic, host twins (new exports only).  410 = round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
+#define VISREP_VERSION 600   /* round 6: reserved CUs, GEMM tile-walk knob, gemm variants 6-8, visrep_masked_nn_min_f32, window < 0 in the C-score transfers (new exports / newly accepted argument values only).  500 = round 5: device CU count, routing counters, MFMA probe, A-score reference arithmetic, host twins (new exports only).  410 = round 4: split-route `products`, stream-keyed scratch, per-thread knobs (changed signatures); 410: q_prescaled = 2, row-mapped GEMM, image-aligned / wide-head attention, conv + GroupNorm partials */
 
 enum { VISREP_BF16 = 0, VISREP_F32 = 1 };
 enum { VISREP_OK = 0, VISREP_ERR_ARG = -1, VISREP_ERR_SHAPE = -2, VISREP_ERR_LAUNCH = -3 };
