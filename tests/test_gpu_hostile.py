@@ -224,3 +224,65 @@ def test_groupnorm_with_large_group_means(B, HW, C, ratio):
     assert e_mean < 1e-5, (B, HW, C, ratio, e_mean)
     assert e_rstd < (3e-4 if ratio <= 30 else 2e-3), (B, HW, C, ratio, e_rstd)     # measured: 7e-6 / 6e-5..1.3e-4 / 1.7e-4..6.7e-4 at ratio 10 / 30 / 100
     assert err < 3e-3, (B, HW, C, ratio, err)                                        # measured 1.5e-3..1.7e-3 everywhere: the bf16 rounding of the OUTPUT
+
+
+# ------------------------------------------------------------------------------------------------ a diffusion tower on hostile weights
+def _hostile_sd_weights(wu, wv, seed=5):
+    """The SD family's analogue of hostile_weights: (a) OUTLIER CHANNELS - three output channels of every resnet conv2 (VAE encoder and UNet) scaled
+    30-100x with biases of +-(10-30): the residual stream of both networks carries channels 30-100x the others, and the GroupNorm groups they sit
+    in have |mean| >> std; (b) GroupNorm gains of 0.02 / 3 on those channels in every norm1 / norm2 behind them; (c) SHARP heads - to_q / to_k of every
+    self-attention x4 (logits x16), the VAE mid-block attention's too."""
+    rs = np.random.RandomState(seed)
+    wu, wv = {k: v.clone() for k, v in wu.items()}, {k: v.clone() for k, v in wv.items()}
+    for w in (wu, wv):
+        for name in [n for n in w if n.endswith("conv2.weight")]:
+            co = w[name].shape[0]
+            ch = rs.choice(co, 3, replace=False)
+            fac = np.exp(rs.uniform(np.log(30), np.log(100), 3)).astype(np.float32)
+            w[name][ch] *= torch.from_numpy(fac)[:, None, None, None]
+            w[name.replace("weight", "bias")][ch] = torch.from_numpy((rs.choice([-1.0, 1.0], 3) * rs.uniform(10, 30, 3)).astype(np.float32))
+        for name in [n for n in w if n.endswith(("norm1.weight", "norm2.weight")) and "transformer_blocks" not in n]:
+            c = w[name].shape[0]
+            ch = rs.choice(c, 4, replace=False)
+            w[name][ch[:2]] = 0.02
+            w[name][ch[2:]] = 3.0
+        for name in [n for n in w if n.endswith(("attn1.to_q.weight", "attn1.to_k.weight", "attentions.0.to_q.weight", "attentions.0.to_k.weight"))]:
+            w[name] *= 4.0
+    return wu, wv
+
+
+def test_sd_tower_on_hostile_weights():
+    """The composed SD featurizer (VAE encoder -> noisy latents -> UNet down / mid / first up blocks) on hostile weights, tiny SD1.5-shaped spec so that
+    the fp32 oracle runs in seconds: posterior moments and tower features against the fp32 oracle, bounded by twice the oracle's own bf16 run -
+    GroupNorm on groups with huge means, convolutions whose output has 100x outlier channels, attention with x16 logits."""
+    from law_of_vision_representation_in_mllms_amd import sd_engine as SE, sd_weights as SW
+    from oracle import diffusion as OD
+    bf = lambda t: t.to(torch.bfloat16)
+    sp = SW.tiny_sd_spec()
+    wu, wv = _hostile_sd_weights(SW.synthetic_unet(sp.unet, 21, n_up_blocks=1), SW.synthetic_vae(sp.vae, 22))
+    rs = np.random.RandomState(3)
+    B, side = 2, 64
+    img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32))
+    lat = side // 2 ** (len(sp.vae.block_out) - 1)
+    Z = sp.vae.latent_channels
+    post = torch.from_numpy(rs.standard_normal((B, Z, lat, lat)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((B, Z, lat, lat)).astype(np.float32))
+    pe = torch.from_numpy(rs.standard_normal((1, sp.text_len, sp.unet.cross_dim)).astype(np.float32))
+    eng = SE.SdEngine(sp, wu, wv, DEV, up_ft_index=0)
+    mom, h, w = eng.vae_moments(img.to(DEV))
+    untok = lambda y: y.view(B, h, w, -1).permute(0, 3, 1, 2)
+    mean, logvar = untok(mom[:, :Z]).float().cpu(), untok(mom[:, Z: 2 * Z]).float().cpu()
+    m32, l32 = OD.vae_encode_moments(sp.vae, wv, img)
+    m16, l16 = OD.vae_encode_moments(sp.vae, {k: bf(v) for k, v in wv.items()}, bf(img))
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    print("hostile SD moments", (rel(mean, m32), rel(m16, m32), rel(logvar, l32), rel(l16, l32)))
+    assert torch.isfinite(mean).all() and torch.isfinite(logvar).all()
+    assert rel(mean, m32) < max(2.0 * rel(m16, m32), 2e-2) and rel(logvar, l32) < max(2.0 * rel(l16, l32), 2e-2)
+    got = eng.forward(img, pe, t=261, ensemble_size=1, post_noise=post, ddim_noise=ddim)
+    want = OD.sd_features(sp, wu, wv, img, pe, post, ddim, t=261)
+    ref16 = OD.sd_features(sp, wu, wv, img, pe, post, ddim, t=261, dtype=torch.bfloat16)
+    got_tok = got.float().cpu().reshape(want.shape) if got.shape != want.shape else got.float().cpu()
+    e_hip, e_ref = rel(got_tok, want), rel(ref16, want)
+    print("hostile SD features", (e_hip, e_ref, tuple(got.shape), tuple(want.shape)))
+    assert torch.isfinite(got.float()).all()
+    assert e_hip < max(2.0 * e_ref, 3e-2), (e_hip, e_ref)
