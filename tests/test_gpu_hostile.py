@@ -286,3 +286,44 @@ def test_sd_tower_on_hostile_weights():
     print("hostile SD features", (e_hip, e_ref, tuple(got.shape), tuple(want.shape)))
     assert torch.isfinite(got.float()).all()
     assert e_hip < max(2.0 * e_ref, 3e-2), (e_hip, e_ref)
+
+
+def test_dit_tower_on_hostile_weights():
+    """DiT (adaLN-Zero blocks, heads of 72 padded to 128) on hostile weights, tiny spec (the reference-generated fixture's), 4 blocks: three rows of every
+    attention output projection and of every MLP fc2 scaled 30-100x with biases of +-(10-30) (outlier channels in the residual stream, which the
+    engine's LayerNorm-with-folded-modulation then normalises), the adaLN modulation tables (norm1.linear: shift / scale / gate of both halves) x4 - so that
+    (1 + scale) and the gates are far from the identity the engine's folds were only ever exercised near - and to_q / to_k x3 (logits x9)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_oracle_golden import load_dit_case
+    from law_of_vision_representation_in_mllms_amd import sd_weights as SW
+    from law_of_vision_representation_in_mllms_amd.dit_engine import DiTEngine
+    from oracle import dit as ODT
+    sp0, _, _, _, _ = load_dit_case("last")
+    from dataclasses import replace
+    sp = replace(sp0, core=replace(sp0.core, layers=4))
+    wd, wv = SW.synthetic_dit(sp.core, 41, n_layers=4), SW.synthetic_vae(sp.vae, 42)
+    rs = np.random.RandomState(6)
+    wd = {k: v.clone() for k, v in wd.items()}
+    for name in [n for n in wd if n.endswith(("attn1.to_out.0.weight", "ff.net.2.weight"))]:
+        ch = rs.choice(wd[name].shape[0], 3, replace=False)
+        wd[name][ch] *= torch.from_numpy(np.exp(rs.uniform(np.log(30), np.log(100), 3)).astype(np.float32))[:, None]
+        wd[name.replace("weight", "bias")][ch] = torch.from_numpy((rs.choice([-1.0, 1.0], 3) * rs.uniform(10, 30, 3)).astype(np.float32))
+    for name in [n for n in wd if n.endswith(("norm1.linear.weight", "norm1.linear.bias"))]:
+        wd[name] *= 4.0
+    for name in [n for n in wd if n.endswith(("attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_q.bias", "attn1.to_k.bias"))]:
+        wd[name] *= 3.0
+    B = 2
+    side = sp.core.sample_size * 2 ** (len(sp.vae.block_out) - 1)
+    img = torch.from_numpy(rs.uniform(-1, 1, (B, 3, side, side)).astype(np.float32))
+    lat = sp.core.sample_size
+    post = torch.from_numpy(rs.standard_normal((B, 4, lat, lat)).astype(np.float32))
+    ddim = torch.from_numpy(rs.standard_normal((B, 4, lat, lat)).astype(np.float32))
+    got = DiTEngine(sp, wd, wv, DEV, up_ft_index=3).forward(img, t=261, post_noise=post, ddim_noise=ddim)
+    want = ODT.dit_features(sp, wd, wv, img, post, ddim, t=261, up_ft_index=3)
+    ref16 = ODT.dit_features(sp, wd, wv, img, post, ddim, t=261, up_ft_index=3, dtype=torch.bfloat16)
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    e_hip, e_ref = rel(got, want), rel(ref16, want)
+    print("hostile DiT", (e_hip, e_ref, tuple(got.shape), want.abs().max().item()))
+    assert got.shape == want.shape and torch.isfinite(got.float()).all()
+    assert e_hip < max(2.0 * e_ref, 2e-2), (e_hip, e_ref)
