@@ -327,3 +327,35 @@ def test_dit_tower_on_hostile_weights():
     print("hostile DiT", (e_hip, e_ref, tuple(got.shape), want.abs().max().item()))
     assert got.shape == want.shape and torch.isfinite(got.float()).all()
     assert e_hip < max(2.0 * e_ref, 2e-2), (e_hip, e_ref)
+
+
+def test_sd3_tower_on_hostile_weights():
+    """SD3 (MMDiT: two token streams, joint attention, adaLN-Zero on both) on hostile weights - the reference-generated fixture's tiny spec and inputs,
+    weights perturbed: three rows of every output projection / fc2 of BOTH streams x30-100 with biases of +-(10-30), both streams' adaLN modulation tables
+    x4, the image stream's to_q / to_k and the context stream's add_q / add_k x3."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_oracle_golden import load_sd3_case
+    from law_of_vision_representation_in_mllms_amd.sd3_engine import Sd3Engine
+    from oracle import sd3 as O3
+    sp, wc, wv, inp, _ = load_sd3_case("last")
+    rs = np.random.RandomState(7)
+    wc = {k: v.clone() for k, v in wc.items()}
+    for name in [n for n in wc if n.endswith(("attn.to_out.0.weight", "attn.to_add_out.weight", "ff.net.2.weight", "ff_context.net.2.weight"))]:
+        ch = rs.choice(wc[name].shape[0], 3, replace=False)
+        wc[name][ch] *= torch.from_numpy(np.exp(rs.uniform(np.log(30), np.log(100), 3)).astype(np.float32))[:, None]
+        wc[name.replace("weight", "bias")][ch] = torch.from_numpy((rs.choice([-1.0, 1.0], 3) * rs.uniform(10, 30, 3)).astype(np.float32))
+    for name in [n for n in wc if n.endswith(("norm1.linear.weight", "norm1.linear.bias", "norm1_context.linear.weight", "norm1_context.linear.bias"))]:
+        wc[name] *= 4.0
+    for name in [n for n in wc if n.split(".")[-2] in ("to_q", "to_k", "add_q_proj", "add_k_proj")]:
+        wc[name] *= 3.0
+    kw = dict(t=inp["t"], post_noise=inp["post_noise"], ddim_noise=inp["noise"], pooled=inp["pooled"])
+    got = Sd3Engine(sp, wc, wv, DEV, up_ft_index=inp["up_ft_index"]).forward(inp["img"], inp["prompt_embeds"], **kw)
+    oa = (sp, wc, wv, inp["img"], inp["prompt_embeds"], inp["pooled"], inp["post_noise"], inp["noise"])
+    want = O3.sd3_features(*oa, t=inp["t"], up_ft_index=inp["up_ft_index"])
+    ref16 = O3.sd3_features(*oa, t=inp["t"], up_ft_index=inp["up_ft_index"], dtype=torch.bfloat16)
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    e_hip, e_ref = rel(got, want), rel(ref16, want)
+    print("hostile SD3", (e_hip, e_ref, tuple(got.shape), want.abs().max().item()))
+    assert got.shape == want.shape and torch.isfinite(got.float()).all()
+    assert e_hip < max(2.0 * e_ref, 2e-2), (e_hip, e_ref)
